@@ -1,0 +1,133 @@
+"""Seeded inputs / shapes shared by make_golden.py (reference side) and the parity tests.
+Pure torch CPU generators; no reference import, no oracle math."""
+import math
+import torch
+
+from oracle.unet_ref import UNetConfig
+
+DDPM_TS = (999, 500, 1, 0)
+DDIM_TS = (980, 500, 0)
+TEMB_TS = [0, 1, 2, 10, 100, 500, 998, 999]
+PIPE_SEED = 1234
+
+
+def _r(seed, *shape):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed))
+
+
+def sched_inputs():
+    return _r(11, 2, 3, 8, 8), _r(12, 2, 3, 8, 8), _r(13, 2, 3, 8, 8)       # x_t, eps_hat, z
+
+
+def qsample_inputs():
+    x0, R, eps = _r(21, 4, 3, 8, 8), _r(22, 4, 3, 8, 8), _r(23, 4, 3, 8, 8)
+    R[1] = 0                                                                  # a clean row
+    return x0, R, eps, torch.tensor([0, 10, 500, 999])
+
+
+def backdoor_images():
+    u8 = torch.randint(0, 256, (4, 32, 32, 3), generator=torch.Generator().manual_seed(31), dtype=torch.uint8)
+    x = u8.permute(0, 3, 1, 2).float() / 255.0
+    return ((x - 0.0) / (1.0 - 0.0 + 1e-5)) * 2.0 - 1.0
+
+
+# name -> (cin, cout, hw)
+RESNET_CASES = {"res_128_128": (128, 128, 8), "res_128_256": (128, 256, 8), "res_512_256": (512, 256, 4)}
+# name -> (C, hw, head_dim)
+ATTN_CASES = {"attn_256_h1": (256, 8, None), "attn_256_hd8": (256, 4, 8), "attn_128_h1": (128, 4, None)}
+# name -> (C, hw, padding)
+DOWN_CASES = {"down_128_p0": (128, 8, 0), "down_128_p1": (128, 8, 1)}
+UP_CASES = {"up_128": (128, 4)}
+MOD_B = 2
+
+
+def _module_shapes(name):
+    if name in RESNET_CASES:
+        cin, cout, _ = RESNET_CASES[name]
+        s = {"norm1.weight": (cin,), "norm1.bias": (cin,), "conv1.weight": (cout, cin, 3, 3), "conv1.bias": (cout,),
+             "time_emb_proj.weight": (cout, 512), "time_emb_proj.bias": (cout,),
+             "norm2.weight": (cout,), "norm2.bias": (cout,), "conv2.weight": (cout, cout, 3, 3), "conv2.bias": (cout,)}
+        if cin != cout:
+            s["conv_shortcut.weight"] = (cout, cin, 1, 1); s["conv_shortcut.bias"] = (cout,)
+        return s
+    if name in ATTN_CASES:
+        C = ATTN_CASES[name][0]
+        s = {"group_norm.weight": (C,), "group_norm.bias": (C,)}
+        for n in ("query", "key", "value", "proj_attn"):
+            s[n + ".weight"] = (C, C); s[n + ".bias"] = (C,)
+        return s
+    C = (DOWN_CASES.get(name) or UP_CASES.get(name))[0]
+    return {"conv.weight": (C, C, 3, 3), "conv.bias": (C,)}
+
+
+def module_params(name):
+    """Seeded parameters for a stand-alone module case (same recipe as oracle.unet_ref.gen_params)."""
+    out = {}
+    shapes = _module_shapes(name)
+    base = sum(ord(ch) for ch in name) * 7919
+    for i, (k, shp) in enumerate(shapes.items()):
+        g = torch.Generator().manual_seed(base + i)
+        u = torch.rand(shp, generator=g) * 2 - 1
+        if "norm" in k:
+            out[k] = 1 + 0.1 * u if k.endswith("weight") else 0.1 * u
+        else:
+            w = shapes[k[:-4] + "weight"] if k.endswith("bias") else shp
+            out[k] = u / math.sqrt(math.prod(w[1:]))
+    return out
+
+
+def resnet_inputs(name):
+    cin, cout, hw = RESNET_CASES[name]
+    return _r(41, MOD_B, cin, hw, hw), _r(42, MOD_B, 512), _r(43, MOD_B, cout, hw, hw)
+
+
+def attn_inputs(name):
+    C, hw, _ = ATTN_CASES[name]
+    return _r(51, MOD_B, C, hw, hw), _r(52, MOD_B, C, hw, hw)
+
+
+def down_inputs(name):
+    C, hw, _ = DOWN_CASES[name]
+    return _r(61, MOD_B, C, hw, hw), _r(62, MOD_B, C, hw // 2, hw // 2)
+
+
+def up_inputs(name):
+    C, hw = UP_CASES[name]
+    return _r(71, MOD_B, C, hw, hw), _r(72, MOD_B, C, 2 * hw, 2 * hw)
+
+
+SMALL_CFGS = {
+    # two levels, every layer kind of the CIFAR topology (attn down/up, 1x1 shortcut, pad-0 downsample, upsample)
+    "small": UNetConfig(sample_size=16, block_out_channels=(128, 256),
+                        down_block_types=("DownBlock2D", "AttnDownBlock2D"),
+                        up_block_types=("AttnUpBlock2D", "UpBlock2D"), layers_per_block=1),
+    # MODEL_DEFAULT-style knobs (model.py:654-680): pad 1, flip_sin_to_cos, freq_shift 0, eps 1e-5, head dim 8
+    "small_default": UNetConfig(sample_size=16, block_out_channels=(128, 256),
+                                down_block_types=("DownBlock2D", "AttnDownBlock2D"),
+                                up_block_types=("AttnUpBlock2D", "UpBlock2D"), layers_per_block=1,
+                                downsample_padding=1, flip_sin_to_cos=True, freq_shift=0, norm_eps=1e-5,
+                                attention_head_dim=8),
+}
+
+
+def train_inputs(cfg, B):
+    """(x0, R, t, eps) as in SURVEY 8d: uint8-derived images, every other row poisoned with BOX/CORNER-like R."""
+    S = cfg.sample_size
+    u8 = torch.randint(0, 256, (B, S, S, 3), generator=torch.Generator().manual_seed(0), dtype=torch.uint8)
+    x = (u8.permute(0, 3, 1, 2).float() / 255.0) / (1.0 + 1e-5) * 2.0 - 1.0
+    R = torch.zeros_like(x)
+    x0 = x.clone()
+    k = max(2, S // 2 - 2)
+    for b in range(0, B, 2):                                   # poisoned rows: grey box trigger, corner target
+        R[b] = x[b]
+        R[b, :, -(k + 2):-2, -(k + 2):-2] = 0.0
+        tgt = torch.full((3, S, S), -0.4)
+        tgt[:, : S // 3, : S // 3] = 0.0
+        x0[b] = tgt
+    eps = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(1))
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(2))
+    return x0, R, t, eps
+
+
+def pipeline_init(cfg, n=2):
+    return torch.randn(n, 3, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(0))

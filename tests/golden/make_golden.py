@@ -1,0 +1,272 @@
+"""Generate tests/golden/*.npz by IMPORTING THE REFERENCE in the build container.
+
+Run once, here (CPU), from the repo root:   python tests/golden/make_golden.py
+The reference (/root/reference, read-only) never travels to the GPU box; the vectors do.
+Import recipe = SURVEY.md Appendix C.  Every fixture is data only: seeded inputs are
+re-created by the tests from the same seeds, weights come from oracle.unet_ref.gen_params
+(loaded into the reference's own nn.Modules with load_state_dict), outputs are what the
+reference computed.
+
+Fixtures:
+  sched.npz     G1  tables, DDPM step (t x variance_type x clip), DDIM timesteps + step
+  qsample.npz   G2  loss.q_sample_diffuser in/out + p_losses_diffuser value with a linear model
+  backdoor.npz  G3  Backdoor box triggers, CORNER/TRIGGER/SHIFT targets, int masks, blend
+  temb.npz      G4  get_timestep_embedding
+  modules.npz   G5  ResnetBlock2D / AttentionBlock / Downsample2D / Upsample2D fwd + bwd
+  unet_small.npz G6 two-level UNet fwd/bwd + 2/3-step DDPM and DDIM pipeline images
+  unet_cifar.npz G7 full DDPM-CIFAR10-32 topology, B=2: output, loss, grad norms, one Adam step
+"""
+import os, sys, importlib.util, math
+sys.dont_write_bytecode = True
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+torch.set_num_threads(8)
+
+# ---- import shim -------------------------------------------------------
+import huggingface_hub, huggingface_hub.constants as c
+if not hasattr(c, "hf_cache_home"):
+    c.hf_cache_home = os.path.expanduser("~/.cache/huggingface")
+class _Stub:
+    def __init__(self, *a, **k): pass
+    @staticmethod
+    def get_token(): return None
+for n in ("HfFolder", "cached_download"):
+    if not hasattr(huggingface_hub, n):
+        setattr(huggingface_hub, n, _Stub)
+_orig = importlib.util.find_spec
+importlib.util.find_spec = lambda name, *a, **k: None if name == "transformers" else _orig(name, *a, **k)
+sys.path.insert(0, "/root/reference/diffusers/src")
+import diffusers
+importlib.util.find_spec = _orig
+import datasets  # noqa: real HF datasets must be imported before the stubs
+from unittest.mock import MagicMock
+for n in ("torchvision", "torchvision.transforms", "torchvision.utils", "torchvision.datasets",
+          "comet_ml", "wandb", "pytorch_fid", "pytorch_fid.inception", "torchmetrics"):
+    sys.modules[n] = MagicMock()
+sys.path.insert(0, "/root/reference")
+_cwd = os.getcwd(); os.chdir("/tmp")
+import loss as ref_loss, dataset as ref_dataset
+os.chdir(_cwd)
+from diffusers import UNet2DModel, DDPMScheduler, DDIMScheduler, DDPMPipeline, DDIMPipeline
+from diffusers.models.resnet import ResnetBlock2D, Downsample2D, Upsample2D
+from diffusers.models.attention import AttentionBlock
+from diffusers.models.embeddings import get_timestep_embedding
+
+from oracle import unet_ref as U          # only for gen_params / configs (no math used here)
+from tests.golden.cases import *          # shared seeds / shapes
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name)
+    np.savez_compressed(path, **{k: (v.detach().cpu().numpy() if torch.is_tensor(v) else np.asarray(v))
+                                 for k, v in kw.items()})
+    print(f"{name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+# ---- G1 schedulers ----------------------------------------------------------------------------
+def g1():
+    out = {}
+    s = DDPMScheduler(num_train_timesteps=1000)
+    out["betas"], out["alphas"], out["alphas_cumprod"] = s.betas, s.alphas, s.alphas_cumprod
+    x, eps, z = sched_inputs()
+    for vt in ("fixed_small", "fixed_large"):
+        for clip in (True, False):
+            s = DDPMScheduler(num_train_timesteps=1000, variance_type=vt, clip_sample=clip)
+            for t in DDPM_TS:
+                class G:  # hand the SAME noise to the reference through its randn_tensor call
+                    pass
+                import diffusers.schedulers.scheduling_ddpm as M
+                keep = M.randn_tensor
+                M.randn_tensor = lambda *a, **k: z.clone()
+                r = s.step(eps, t, x)
+                M.randn_tensor = keep
+                out[f"ddpm_{vt}_{int(clip)}_{t}_prev"] = r.prev_sample
+                out[f"ddpm_{vt}_{int(clip)}_{t}_x0"] = r.pred_original_sample
+    s = DDPMScheduler(num_train_timesteps=1000, clip_sample=False, clip_defense=True, clip_defense_range=0.5)
+    import diffusers.schedulers.scheduling_ddpm as M
+    keep = M.randn_tensor; M.randn_tensor = lambda *a, **k: z.clone()
+    out["ddpm_clipdef_500_prev"] = s.step(eps, 500, x).prev_sample
+    M.randn_tensor = keep
+    s = DDPMScheduler(num_train_timesteps=1000); s.set_timesteps(50)
+    out["ddpm_ts50"] = s.timesteps
+    for clip in (True, False):
+        d = DDIMScheduler(num_train_timesteps=1000, clip_sample=clip); d.set_timesteps(50)
+        out["ddim_ts50"] = d.timesteps
+        for t in DDIM_TS:
+            r = d.step(eps, t, x)
+            out[f"ddim_{int(clip)}_{t}_prev"] = r.prev_sample
+        r = d.step(eps, 500, x, eta=0.5, variance_noise=z)
+        out[f"ddim_{int(clip)}_500_eta_prev"] = r.prev_sample
+    out["add_noise"] = DDPMScheduler().add_noise(x, eps, torch.tensor([3, 977]))
+    save("sched.npz", **out)
+
+
+# ---- G2 q_sample / loss -----------------------------------------------------------------------
+def g2():
+    s = DDPMScheduler(num_train_timesteps=1000)
+    x0, R, eps, t = qsample_inputs()
+    xn, tgt = ref_loss.q_sample_diffuser(s, x0, R, t, eps)
+    lin = torch.nn.Module(); lin.forward = None
+    class Lin(torch.nn.Module):
+        def forward(self, x, t, return_dict=False):
+            return (0.5 * x - 0.01 * t.reshape(-1, 1, 1, 1).float() / 1000,)
+    l2 = ref_loss.p_losses_diffuser(s, Lin(), x0, R, t, eps, "l2")
+    l1 = ref_loss.p_losses_diffuser(s, Lin(), x0, R, t, eps, "l1")
+    hub = ref_loss.p_losses_diffuser(s, Lin(), x0, R, t, eps, "huber")
+    save("qsample.npz", x_noisy=xn, target=tgt, l2=l2, l1=l1, huber=hub)
+
+
+# ---- G3 backdoor --------------------------------------------------------------------------------
+def g3():
+    bd = ref_dataset.Backdoor(root="/tmp")
+    out = {}
+    for S in (32, 256):
+        for trig in ("BOX_4", "BOX_8", "BOX_11", "BOX_14", "BOX_18", "SM_BOX", "NONE"):
+            g = bd.get_trigger(type=trig, channel=3, image_size=S)
+            out[f"trig_{trig}_{S}"] = g
+            out[f"mask_{trig}_{S}"] = torch.where(g > -1.0, 0, 1)          # dataset.py:275-276
+            if S == 32 or trig == "BOX_14":
+                for tg in ("CORNER", "TRIGGER", "SHIFT"):
+                    out[f"tgt_{tg}_{trig}_{S}"] = bd.get_target(type=tg, trigger=g)
+    # blend of dataset.py:306-315 on a seeded batch, BOX_14 / CORNER @32
+    img = backdoor_images()
+    g = bd.get_trigger(type="BOX_14", channel=3, image_size=32)
+    m = torch.where(g > -1.0, 0, 1).repeat(img.shape[0], 1, 1, 1)
+    out["blend_BOX_14_32"] = m * img + (1 - m) * g.repeat(img.shape[0], 1, 1, 1)
+    import util as ref_util
+    out["normalize_u8"] = ref_util.normalize(vmin_in=0.0, vmax_in=1.0, vmin_out=-1.0, vmax_out=1.0,
+                                             x=torch.arange(256, dtype=torch.float32) / 255.0)
+    save("backdoor.npz", **out)
+
+
+# ---- G4 timestep embedding ------------------------------------------------------------------------
+def g4():
+    t = torch.tensor(TEMB_TS)
+    save("temb.npz",
+         cifar=get_timestep_embedding(t, 128, flip_sin_to_cos=False, downscale_freq_shift=1),
+         default=get_timestep_embedding(t, 128, flip_sin_to_cos=True, downscale_freq_shift=0))
+
+
+# ---- G5 modules --------------------------------------------------------------------------------------
+def load_sub(mod, P, prefix):
+    sd = {k[len(prefix):]: v for k, v in P.items() if k.startswith(prefix)}
+    mod.load_state_dict(sd)
+    return mod
+
+
+def grads_summary(mod, prefix=""):
+    out = {}
+    for k, p in mod.named_parameters():
+        out[f"{prefix}gn_{k}"] = p.grad.double().norm().float()
+        out[f"{prefix}g8_{k}"] = p.grad.flatten()[:8]
+    return out
+
+
+def g5():
+    out = {}
+    for name, (cin, cout, hw) in RESNET_CASES.items():
+        P = module_params(name)
+        m = load_sub(ResnetBlock2D(in_channels=cin, out_channels=cout, temb_channels=512, eps=1e-6, groups=32), P, "")
+        x, temb, dy = resnet_inputs(name)
+        x.requires_grad_(True); temb.requires_grad_(True)
+        y = m(x, temb); y.backward(dy)
+        out[f"{name}_y"] = y; out[f"{name}_dx"] = x.grad; out[f"{name}_dtemb"] = temb.grad
+        out.update(grads_summary(m, name + "_"))
+    for name, (C, hw, hd) in ATTN_CASES.items():
+        P = module_params(name)
+        m = load_sub(AttentionBlock(C, num_head_channels=hd, norm_num_groups=32, eps=1e-6), P, "")
+        x, dy = attn_inputs(name); x.requires_grad_(True)
+        y = m(x); y.backward(dy)
+        out[f"{name}_y"] = y; out[f"{name}_dx"] = x.grad
+        out.update(grads_summary(m, name + "_"))
+    for name, (C, hw, pad) in DOWN_CASES.items():
+        P = module_params(name)
+        m = load_sub(Downsample2D(C, use_conv=True, out_channels=C, padding=pad, name="op"), P, "")
+        x, dy = down_inputs(name); x.requires_grad_(True)
+        y = m(x); y.backward(dy)
+        out[f"{name}_y"] = y; out[f"{name}_dx"] = x.grad
+        out.update(grads_summary(m, name + "_"))
+    for name, (C, hw) in UP_CASES.items():
+        P = module_params(name)
+        m = load_sub(Upsample2D(C, use_conv=True, out_channels=C), P, "")
+        x, dy = up_inputs(name); x.requires_grad_(True)
+        y = m(x); y.backward(dy)
+        out[f"{name}_y"] = y; out[f"{name}_dx"] = x.grad
+        out.update(grads_summary(m, name + "_"))
+    save("modules.npz", **out)
+
+
+def ref_unet(cfg, P):
+    m = UNet2DModel(sample_size=cfg.sample_size, in_channels=cfg.in_channels, out_channels=cfg.out_channels,
+                    block_out_channels=cfg.block_out_channels, down_block_types=cfg.down_block_types,
+                    up_block_types=cfg.up_block_types, layers_per_block=cfg.layers_per_block,
+                    downsample_padding=cfg.downsample_padding, flip_sin_to_cos=cfg.flip_sin_to_cos,
+                    freq_shift=cfg.freq_shift, norm_eps=cfg.norm_eps, norm_num_groups=cfg.norm_num_groups,
+                    attention_head_dim=cfg.attention_head_dim)
+    missing = m.load_state_dict(P, strict=True)
+    return m
+
+
+def train_step_fixture(cfg, seed, B, tag, lr=2e-4):
+    out = {}
+    P = U.gen_params(cfg, seed)
+    m = ref_unet(cfg, P); m.train()
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    x0, R, t, eps = train_inputs(cfg, B)
+    y = m(q := ref_loss.q_sample_diffuser(sched, x0, R, t, eps)[0], t, return_dict=False)[0]
+    out[f"{tag}_pred"] = y.detach()
+    opt = torch.optim.Adam(m.parameters(), lr=lr)                      # baddiffusion.py:320
+    loss = ref_loss.p_losses_diffuser(sched, m, x_start=x0, R=R, timesteps=t, noise=eps, loss_type="l2")
+    loss.backward()                                                     # baddiffusion.py:607-608
+    out[f"{tag}_loss"] = loss.detach()
+    names = [k for k, _ in m.named_parameters()]
+    out[f"{tag}_gradnorms"] = torch.stack([p.grad.double().norm().float() for _, p in m.named_parameters()])
+    out[f"{tag}_grad8"] = torch.stack([torch.nn.functional.pad(p.grad.flatten()[:8], (0, max(0, 8 - p.numel())))
+                                       for _, p in m.named_parameters()])
+    out[f"{tag}_names"] = np.array(names)
+    gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)           # baddiffusion.py:612
+    out[f"{tag}_total_norm"] = gn
+    opt.step()
+    out[f"{tag}_p8_after"] = torch.stack([torch.nn.functional.pad(p.detach().flatten()[:8], (0, max(0, 8 - p.numel())))
+                                          for _, p in m.named_parameters()])
+    return out, m
+
+
+# ---- G6 small UNet + pipelines ---------------------------------------------------------------------------
+def g6():
+    out = {}
+    for tag, cfg in SMALL_CFGS.items():
+        o, m = train_step_fixture(cfg, 7, 2, tag)
+        out.update(o)
+    cfg = SMALL_CFGS["small"]
+    m = ref_unet(cfg, U.gen_params(cfg, 7)).eval()
+    init = pipeline_init(cfg)
+    for clip in (True, False):
+        for vt in ("fixed_small", "fixed_large"):
+            pipe = DDPMPipeline(m, DDPMScheduler(num_train_timesteps=1000, clip_sample=clip, variance_type=vt))
+            pipe.set_progress_bar_config(disable=True)
+            g = torch.Generator().manual_seed(PIPE_SEED)
+            r = pipe(batch_size=init.shape[0], generator=g, init=init, output_type=None, num_inference_steps=3)
+            out[f"ddpm3_{int(clip)}_{vt}"] = r.images
+        pipe = DDIMPipeline(m, DDIMScheduler(num_train_timesteps=1000, clip_sample=clip))
+        pipe.set_progress_bar_config(disable=True)
+        r = pipe(batch_size=init.shape[0], init=init, output_type=None, num_inference_steps=4)
+        out[f"ddim4_{int(clip)}"] = r.images
+    save("unet_small.npz", **out)
+
+
+# ---- G7 full CIFAR topology ---------------------------------------------------------------------------------
+def g7():
+    out, _ = train_step_fixture(U.CIFAR10_32, 0, 2, "cifar")
+    save("unet_cifar.npz", **out)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    for w in which:
+        globals()[w]()

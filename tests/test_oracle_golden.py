@@ -1,0 +1,251 @@
+"""Pin the CPU oracle: (1) against the vectors captured from the imported reference
+(tests/golden/*.npz, made by tests/golden/make_golden.py), (2) against the known answers the
+reference's own diffusers tests hold (file:line cited per test).  CPU only."""
+import math
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import backdoor_ref as BD
+from oracle import loss_ref, sched_ref, train_ref
+from oracle import unet_ref as U
+from tests.golden import cases as C
+
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5, atol=1e-6):
+    a = a.detach().numpy() if torch.is_tensor(a) else np.asarray(a)
+    np.testing.assert_allclose(a, np.asarray(b), rtol=rtol, atol=atol)
+
+
+# ------------------------------------------------------------------ G1 + upstream scheduler KATs
+def test_tables_bit_exact(golden):
+    g = golden("sched")
+    b, a, ac = sched_ref.make_tables()
+    assert np.array_equal(b.numpy(), g["betas"]) and np.array_equal(a.numpy(), g["alphas"])
+    assert np.array_equal(ac.numpy(), g["alphas_cumprod"])
+
+
+def test_ddpm_variance_kat():
+    # diffusers/tests/schedulers/test_scheduler_ddpm.py:62-69
+    _, _, ac = sched_ref.make_tables()
+    assert abs(float(sched_ref.ddpm_variance(ac, 0, -1)) - 0.0) < 1e-5
+    assert abs(float(sched_ref.ddpm_variance(ac, 487, 486)) - 0.00979) < 1e-5
+    assert abs(float(sched_ref.ddpm_variance(ac, 999, 998)) - 0.02) < 1e-5
+
+
+def _dummy_sample_deter():
+    # diffusers/tests/schedulers/test_schedulers.py:222-234
+    n = 4 * 3 * 8 * 8
+    s = torch.arange(n).reshape(3, 8, 8, 4) / n
+    return s.permute(3, 0, 1, 2)
+
+
+def test_ddpm_full_loop_kat():
+    # test_scheduler_ddpm.py:71-100 -> sum 258.9606, mean 0.3372 (fixed_small, clip_sample=True)
+    _, _, ac = sched_ref.make_tables()
+    sample = _dummy_sample_deter()
+    gen = torch.manual_seed(0)
+    for t in reversed(range(1000)):
+        residual = sample * t / (t + 1)                                  # test_schedulers.py:239-243
+        noise = torch.randn(sample.shape, generator=gen) if t > 0 else None
+        sample, _ = sched_ref.ddpm_step(ac, residual, t, sample, noise)
+    assert abs(float(sample.abs().sum()) - 258.9606) < 1e-2
+    assert abs(float(sample.abs().mean()) - 0.3372) < 1e-3
+
+
+def test_ddim_variance_and_loop_kat():
+    # test_scheduler_ddim.py:94-113
+    _, _, ac = sched_ref.make_tables()
+
+    def var(t, p):
+        return float(((1 - ac[p]) / (1 - ac[t])) * (1 - ac[t] / ac[p]))
+    assert abs(var(420, 400) - 0.14771) < 1e-5 and abs(var(980, 960) - 0.32460) < 1e-5
+    sample = _dummy_sample_deter()
+    for t in sched_ref.ddim_timesteps(10):
+        residual = sample * int(t) / (int(t) + 1)
+        sample, _ = sched_ref.ddim_step(ac, residual, int(t), sample, 10)
+    assert abs(float(sample.abs().sum()) - 172.0067) < 1e-2
+    assert abs(float(sample.abs().mean()) - 0.223967) < 1e-3
+
+
+def test_ddim_steps_offset_kat():
+    # test_scheduler_ddim.py:46-54
+    assert list(sched_ref.ddim_timesteps(5, steps_offset=1)) == [801, 601, 401, 201, 1]
+
+
+def test_sched_steps_vs_reference(golden):
+    g = golden("sched")
+    _, _, ac = sched_ref.make_tables()
+    x, eps, z = C.sched_inputs()
+    for vt in ("fixed_small", "fixed_large"):
+        for clip in (True, False):
+            for t in C.DDPM_TS:
+                prev, x0 = sched_ref.ddpm_step(ac, eps, t, x, z, variance_type=vt, clip_sample=clip)
+                close(prev, g[f"ddpm_{vt}_{int(clip)}_{t}_prev"], 1e-6, 1e-6)
+                close(x0, g[f"ddpm_{vt}_{int(clip)}_{t}_x0"], 1e-6, 1e-6)
+    prev, _ = sched_ref.ddpm_step(ac, eps, 500, x, z, clip_sample=False, clip_defense=True, clip_defense_range=0.5)
+    close(prev, g["ddpm_clipdef_500_prev"], 1e-6, 1e-6)
+    assert np.array_equal(sched_ref.ddpm_timesteps(50), g["ddpm_ts50"])
+    assert np.array_equal(sched_ref.ddim_timesteps(50), g["ddim_ts50"])
+    for clip in (True, False):
+        for t in C.DDIM_TS:
+            prev, _ = sched_ref.ddim_step(ac, eps, t, x, 50, clip_sample=clip)
+            close(prev, g[f"ddim_{int(clip)}_{t}_prev"], 1e-6, 1e-6)
+        prev, _ = sched_ref.ddim_step(ac, eps, 500, x, 50, eta=0.5, noise=z, clip_sample=clip)
+        close(prev, g[f"ddim_{int(clip)}_500_eta_prev"], 1e-6, 1e-6)
+    close(sched_ref.add_noise(ac, x, eps, torch.tensor([3, 977])), g["add_noise"], 1e-6, 1e-7)
+
+
+# ------------------------------------------------------------------ G2
+def test_qsample_vs_reference(golden):
+    g = golden("qsample")
+    _, a, ac = sched_ref.make_tables()
+    x0, R, eps, t = C.qsample_inputs()
+    xn, tgt = loss_ref.q_sample(a, ac, x0, R, t, eps)
+    assert np.array_equal(xn.numpy(), g["x_noisy"]) and np.array_equal(tgt.numpy(), g["target"])
+    # rho(t) for t in {0,10,500,999}
+    rho = (1 - a[t] ** 0.5) * (1 - ac[t]) ** 0.5 / (1 - a[t])
+    close(rho, [0.0050004, 0.0234175, 0.4813690, 0.5025141], 1e-5, 1e-7)
+    model = lambda x, tt: 0.5 * x - 0.01 * tt.reshape(-1, 1, 1, 1).float() / 1000
+    for lt in ("l2", "l1", "huber"):
+        close(loss_ref.p_losses(a, ac, model, x0, R, t, eps, lt), g[lt], 1e-6, 1e-7)
+
+
+# ------------------------------------------------------------------ G3
+def test_backdoor_vs_reference(golden):
+    g = golden("backdoor")
+    for S in (32, 256):
+        for trig in ("BOX_4", "BOX_8", "BOX_11", "BOX_14", "BOX_18", "SM_BOX", "NONE"):
+            t = BD.get_trigger(trig, 3, S)
+            assert np.array_equal(t.numpy(), g[f"trig_{trig}_{S}"])
+            m = BD.get_mask(t)
+            assert m.dtype == torch.int64 and np.array_equal(m.numpy(), g[f"mask_{trig}_{S}"])     # bit-exact
+            if S == 32 or trig == "BOX_14":
+                for tg in ("CORNER", "TRIGGER", "SHIFT"):
+                    assert np.array_equal(BD.get_target(tg, t).numpy(), g[f"tgt_{tg}_{trig}_{S}"])
+    assert int((BD.get_trigger("BOX_14", 3, 32) > -1).sum()) == 588                              # SURVEY a-1
+    img = C.backdoor_images()
+    trig = BD.get_trigger("BOX_14", 3, 32)
+    R, x0 = BD.make_batch(img, torch.ones(4, dtype=torch.bool), trig, BD.get_target("CORNER", trig))
+    assert np.array_equal(R.numpy(), g["blend_BOX_14_32"])
+    R, x0 = BD.make_batch(img, torch.tensor([True, False, False, True]), trig, BD.get_target("CORNER", trig))
+    assert float(R[1].abs().max()) == 0.0 and torch.equal(x0[1], img[1])
+    assert np.array_equal(BD.normalize(torch.arange(256, dtype=torch.float32) / 255.0).numpy(), g["normalize_u8"])
+
+
+# ------------------------------------------------------------------ G4 + upstream embedding KAT
+def test_timestep_embedding(golden):
+    g = golden("temb")
+    t = torch.tensor(C.TEMB_TS)
+    close(U.timestep_embedding(t, 128, False, 1), g["cifar"], 1e-6, 1e-6)
+    close(U.timestep_embedding(t, 128, True, 0), g["default"], 1e-6, 1e-6)
+
+
+# ------------------------------------------------------------------ G5 modules (fwd + bwd)
+def _grads_ok(P, g, name, rtol=2e-4):
+    for k, p in P.items():
+        gn = float(p.grad.double().norm())
+        assert abs(gn - float(g[f"{name}_gn_{k}"])) <= rtol * max(1.0, gn), (name, k)
+        close(p.grad.flatten()[:8], g[f"{name}_g8_{k}"], 1e-3, 1e-5)
+
+
+def test_modules_vs_reference(golden):
+    g = golden("modules")
+    for name in C.RESNET_CASES:
+        P = {k: v.requires_grad_(True) for k, v in C.module_params(name).items()}
+        x, temb, dy = C.resnet_inputs(name)
+        x.requires_grad_(True); temb.requires_grad_(True)
+        y = U.resnet_block(P, "", x, temb, 32, 1e-6)
+        y.backward(dy)
+        close(y, g[f"{name}_y"], 1e-5, 1e-5); close(x.grad, g[f"{name}_dx"], 1e-4, 1e-5)
+        close(temb.grad, g[f"{name}_dtemb"], 1e-4, 1e-5)
+        _grads_ok(P, g, name)
+    for name, (Cc, hw, hd) in C.ATTN_CASES.items():
+        P = {k: v.requires_grad_(True) for k, v in C.module_params(name).items()}
+        x, dy = C.attn_inputs(name); x.requires_grad_(True)
+        y = U.attention_block(P, "", x, 32, 1e-6, hd)
+        y.backward(dy)
+        close(y, g[f"{name}_y"], 1e-5, 1e-5); close(x.grad, g[f"{name}_dx"], 1e-4, 1e-5)
+        _grads_ok(P, g, name)
+    for name, (Cc, hw, pad) in C.DOWN_CASES.items():
+        P = {k: v.requires_grad_(True) for k, v in C.module_params(name).items()}
+        x, dy = C.down_inputs(name); x.requires_grad_(True)
+        y = U.downsample(P, "", x, pad); y.backward(dy)
+        close(y, g[f"{name}_y"], 1e-5, 1e-5); close(x.grad, g[f"{name}_dx"], 1e-4, 1e-5)
+        _grads_ok(P, g, name)
+    for name in C.UP_CASES:
+        P = {k: v.requires_grad_(True) for k, v in C.module_params(name).items()}
+        x, dy = C.up_inputs(name); x.requires_grad_(True)
+        y = U.upsample(P, "", x); y.backward(dy)
+        close(y, g[f"{name}_y"], 1e-5, 1e-5); close(x.grad, g[f"{name}_dx"], 1e-4, 1e-5)
+        _grads_ok(P, g, name)
+
+
+# ------------------------------------------------------------------ G6 / G7 whole UNet + one train step
+def _train_step_check(cfg, seed, B, tag, g, lr=2e-4):
+    _, a, ac = sched_ref.make_tables()
+    P = U.gen_params(cfg, seed)
+    x0, R, t, eps = C.train_inputs(cfg, B)
+    xn, _ = loss_ref.q_sample(a, ac, x0, R, t, eps)
+    with torch.no_grad():
+        pred = U.unet_forward(cfg, P, xn, t)
+    close(pred, g[f"{tag}_pred"], 1e-4, 2e-5)
+    loss, G = train_ref.loss_and_grads(cfg, P, a, ac, x0, R, t, eps)
+    close(loss, g[f"{tag}_loss"], 1e-5, 1e-6)
+    names = [str(s) for s in g[f"{tag}_names"]]
+    assert set(names) == set(P.keys())
+    gn = np.array([float(G[k].double().norm()) for k in names])
+    np.testing.assert_allclose(gn, g[f"{tag}_gradnorms"], rtol=2e-3, atol=1e-7)
+    g8 = np.stack([np.pad(G[k].flatten()[:8].numpy(), (0, max(0, 8 - G[k].numel()))) for k in names])
+    np.testing.assert_allclose(g8, g[f"{tag}_grad8"], rtol=5e-3, atol=2e-6)
+    newP, _, norm = train_ref.clip_and_adam(P, G, {}, lr, 1)
+    close(norm, g[f"{tag}_total_norm"], 1e-4, 1e-6)
+    p8 = np.stack([np.pad(newP[k].flatten()[:8].numpy(), (0, max(0, 8 - newP[k].numel()))) for k in names])
+    np.testing.assert_allclose(p8, g[f"{tag}_p8_after"], rtol=1e-4, atol=2e-6)
+
+
+def test_small_unet_train_step(golden):
+    for tag, cfg in C.SMALL_CFGS.items():
+        _train_step_check(cfg, 7, 2, tag, golden("unet_small"))
+
+
+def test_cifar_unet_train_step(golden):
+    torch.set_num_threads(8)
+    _train_step_check(U.CIFAR10_32, 0, 2, "cifar", golden("unet_cifar"))
+
+
+def test_pipelines_vs_reference(golden):
+    g = golden("unet_small")
+    cfg = C.SMALL_CFGS["small"]
+    P = U.gen_params(cfg, 7)
+    _, _, ac = sched_ref.make_tables()
+    init = C.pipeline_init(cfg)
+    with torch.no_grad():
+        for clip in (True, False):
+            for vt in ("fixed_small", "fixed_large"):
+                gen = torch.Generator().manual_seed(C.PIPE_SEED)
+                x = init.clone()
+                for t in sched_ref.ddpm_timesteps(3):
+                    e = U.unet_forward(cfg, P, x, int(t))
+                    z = torch.randn(x.shape, generator=gen) if t > 0 else None      # randn_tensor order
+                    x, _ = sched_ref.ddpm_step(ac, e, int(t), x, z, num_inference_steps=3,
+                                               variance_type=vt, clip_sample=clip)
+                close(sched_ref.to_image(x), g[f"ddpm3_{int(clip)}_{vt}"], 1e-4, 2e-5)
+            x = init.clone()
+            for t in sched_ref.ddim_timesteps(4):
+                e = U.unet_forward(cfg, P, x, int(t))
+                x, _ = sched_ref.ddim_step(ac, e, int(t), x, 4, clip_sample=clip)
+            close(sched_ref.to_image(x), g[f"ddim4_{int(clip)}"], 1e-4, 2e-5)
+
+
+def test_cosine_lr_closed_form():
+    # optimization.py:134-138 ; baddiffusion.py:327-331 (warmup 500)
+    T_ = 469 * 50
+    f = lambda s: train_ref.cosine_lr_lambda(s, 500, T_)
+    assert f(0) == 0.0 and abs(f(1) - 1 / 500) < 1e-12 and abs(f(499) - 499 / 500) < 1e-12
+    assert f(500) == 1.0 and abs(f(T_)) < 1e-12
+    mid = 500 + (T_ - 500) // 2
+    assert abs(f(mid) - 0.5 * (1 + math.cos(math.pi * (mid - 500) / (T_ - 500)))) < 1e-12
