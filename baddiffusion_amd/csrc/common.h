@@ -1,0 +1,71 @@
+// Shared host/device helpers for libbd_hip.so (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdarg.h>
+#include "../../include/bd_hip.h"
+
+namespace bd {
+
+void set_error(const char* fmt, ...);
+
+#define BD_CHECK(cond, status, ...)                 \
+    do {                                            \
+        if (!(cond)) {                              \
+            ::bd::set_error(__VA_ARGS__);           \
+            return (status);                        \
+        }                                           \
+    } while (0)
+
+#define BD_LAUNCH_CHECK(name)                                                         \
+    do {                                                                              \
+        hipError_t e__ = hipGetLastError();                                           \
+        if (e__ != hipSuccess) {                                                      \
+            ::bd::set_error("%s: launch failed: %s", (name), hipGetErrorString(e__)); \
+            return BD_ERR_LAUNCH;                                                     \
+        }                                                                             \
+    } while (0)
+
+#define BD_TRY(expr)                  \
+    do {                              \
+        int s__ = (expr);             \
+        if (s__ != BD_OK) return s__; \
+    } while (0)
+
+static inline hipStream_t S(bd_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+static inline bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int64_t cdiv(int64_t a, int64_t b) { return (a + b - 1) / b; }
+static inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
+
+// ---- wave64 reductions (DPP/shuffle, no LDS) --------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+    return v;
+}
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.0f + expf(-z)); }
+// d/dz [z * sigmoid(z)] = s * (1 + z * (1 - s))
+__device__ __forceinline__ float silu_grad_f(float z) {
+    float s = 1.0f / (1.0f + expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+// ---- internal (non-ABI) launchers shared between files -------------------------------------------
+int igemm_launch(const bd_igemm_desc& d, hipStream_t stream);
+size_t igemm_workspace_bytes(const bd_igemm_desc& d);
+int add_launch(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int C, float scale, int acc,
+               hipStream_t st);
+
+}  // namespace bd

@@ -1,0 +1,330 @@
+// GroupNorm (+SiLU) forward / backward over NHWC(ld) activations, gfx950.
+//
+// A group is `cpg` ADJACENT channels x all pixels of one sample, so in NHWC the reduction is strided:
+// every pixel contributes cpg*4 contiguous bytes.  Workgroups therefore read whole pixel rows (all C
+// channels, float4 per lane, fully coalesced) and keep per-channel partials; channels are folded into
+// groups afterwards.  Reductions are two-stage and fixed-order (deterministic): per-(sample, split)
+// partials -> tiny finalize.  HBM-bound: stats pass reads x once, apply pass reads x + writes y.
+//
+// Replaces aten::native_group_norm / native_group_norm_backward / silu / silu_backward
+// (resnet.py:559,591; attention.py:125; unet_2d.py:312-313).
+#include "common.h"
+
+namespace bd {
+
+constexpr int GN_MAX_SPLITS = 16;
+
+static int gn_splits(int B, int HW) {
+    int s = 512 / (B > 0 ? B : 1);
+    if (s < 1) s = 1;
+    if (s > GN_MAX_SPLITS) s = GN_MAX_SPLITS;
+    while (s > 1 && HW / s < 32) s >>= 1;
+    return s;
+}
+// threads = (C/4) * r, r pixel rows in flight
+static void gn_block(int C, int& threads, int& r) {
+    const int q = C / 4;
+    r = 256 / q;
+    if (r < 1) r = 1;
+    threads = q * r;
+}
+
+__device__ __forceinline__ float silu_dev(float z) { return z / (1.0f + expf(-z)); }
+__device__ __forceinline__ float silu_grad_dev(float z) {
+    const float s = 1.0f / (1.0f + expf(-z));
+    return s * (1.0f + z * (1.0f - s));
+}
+
+// ---- forward stats: per (b, split) partial (sum, sumsq) per group, in double -----------------------
+__global__ void gn_stats_kernel(const float* __restrict__ x, long long ldx, int HW, int C, int G, int r, int S,
+                                double* __restrict__ part /* [B][S][G][2] */) {
+    extern __shared__ float sh[];  // [r][C][2]
+    const int q = C / 4;
+    const int t = threadIdx.x;
+    const int cq = t % q, prow = t / q;
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int per = (HW + S - 1) / S;
+    const int p0 = s * per;
+    int p1 = p0 + per;
+    if (p1 > HW) p1 = HW;
+    float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + (long long)b * HW * ldx + cq * 4;
+    for (int p = p0 + prow; p < p1; p += r) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (long long)p * ldx);
+        sm[0] += v.x; sm[1] += v.y; sm[2] += v.z; sm[3] += v.w;
+        sq[0] += v.x * v.x; sq[1] += v.y * v.y; sq[2] += v.z * v.z; sq[3] += v.w * v.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sh[(prow * C + cq * 4 + j) * 2 + 0] = sm[j];
+        sh[(prow * C + cq * 4 + j) * 2 + 1] = sq[j];
+    }
+    __syncthreads();
+    const int cpg = C / G;
+    for (int g = t; g < G; g += blockDim.x) {
+        double a = 0.0, c2 = 0.0;
+        for (int pr = 0; pr < r; ++pr)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                a += (double)sh[(pr * C + c) * 2 + 0];
+                c2 += (double)sh[(pr * C + c) * 2 + 1];
+            }
+        double* o = part + (((long long)b * S + s) * G + g) * 2;
+        o[0] = a;
+        o[1] = c2;
+    }
+}
+
+__global__ void gn_finalize_kernel(const double* __restrict__ part, int B, int S, int G, double n, float eps,
+                                   float* __restrict__ mean, float* __restrict__ rstd) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i - b * G;
+    double a = 0.0, c2 = 0.0;
+    for (int s = 0; s < S; ++s) {
+        const double* p = part + (((long long)b * S + s) * G + g) * 2;
+        a += p[0];
+        c2 += p[1];
+    }
+    const double mu = a / n;
+    double var = c2 / n - mu * mu;
+    if (var < 0.0) var = 0.0;
+    mean[i] = (float)mu;
+    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
+}
+
+// ---- forward apply: y = silu?((x - mean) * rstd * gamma + beta) ------------------------------------
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
+                                                     long long ldy, long long total4, int HW, int C, int G,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                     int silu) {
+    const int q = C / 4, cpg = C / G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % q) * 4;
+        const long long pix = i / q;
+        const int b = (int)(pix / HW);
+        const float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        float in[4] = {v.x, v.y, v.z, v.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w}, o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (c + j) / cpg;
+            const float mu = mean[b * G + g], rs = rstd[b * G + g];
+            float z = (in[j] - mu) * rs * gg[j] + bb[j];
+            o[j] = silu ? silu_dev(z) : z;
+        }
+        *reinterpret_cast<float4*>(y + pix * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+// ---- backward pass 1: per (b, split) per-channel partial (sum dz, sum dz*xhat) ----------------------
+__global__ void gn_bwd_stats_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy, long long lddy,
+                                    int HW, int C, int G, int r, int S, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, int silu, float* __restrict__ part /* [B][S][C][2] */) {
+    extern __shared__ float sh[];  // [r][C][2]
+    const int q = C / 4, cpg = C / G;
+    const int t = threadIdx.x;
+    const int cq = t % q, prow = t / q;
+    const int b = blockIdx.y, s = blockIdx.x;
+    const int per = (HW + S - 1) / S;
+    const int p0 = s * per;
+    int p1 = p0 + per;
+    if (p1 > HW) p1 = HW;
+    float mu[4], rs[4], gg[4], bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = cq * 4 + j;
+        const int g = c / cpg;
+        mu[j] = mean[b * G + g];
+        rs[j] = rstd[b * G + g];
+        gg[j] = gamma[c];
+        bb[j] = beta[c];
+    }
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    const float* xb = x + (long long)b * HW * ldx + cq * 4;
+    const float* db = dy + (long long)b * HW * lddy + cq * 4;
+    for (int p = p0 + prow; p < p1; p += r) {
+        const float4 v = *reinterpret_cast<const float4*>(xb + (long long)p * ldx);
+        const float4 d = *reinterpret_cast<const float4*>(db + (long long)p * lddy);
+        const float in[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float xh = (in[j] - mu[j]) * rs[j];
+            float dz = dd[j];
+            if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
+            s0[j] += dz;
+            s1[j] += dz * xh;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        sh[(prow * C + cq * 4 + j) * 2 + 0] = s0[j];
+        sh[(prow * C + cq * 4 + j) * 2 + 1] = s1[j];
+    }
+    __syncthreads();
+    for (int c = t; c < C; c += blockDim.x) {
+        float a = 0.f, e = 0.f;
+        for (int pr = 0; pr < r; ++pr) {
+            a += sh[(pr * C + c) * 2 + 0];
+            e += sh[(pr * C + c) * 2 + 1];
+        }
+        float* o = part + (((long long)b * S + s) * C + c) * 2;
+        o[0] = a;
+        o[1] = e;
+    }
+}
+
+// ---- backward finalize: role A (blocks [0, nbc)): dgamma/dbeta per channel; role B: (b,g) sums -------
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, int B, int S, int C, int G,
+                                                            const float* __restrict__ gamma, int nbc,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            float* __restrict__ ds /* [B][G][2] */) {
+    if ((int)blockIdx.x < nbc) {
+        const int c = blockIdx.x * 256 + threadIdx.x;
+        if (c >= C) return;
+        double a = 0.0, e = 0.0;
+        for (int bs = 0; bs < B * S; ++bs) {
+            const float* p = part + ((long long)bs * C + c) * 2;
+            a += (double)p[0];
+            e += (double)p[1];
+        }
+        dbeta[c] = (float)a;
+        dgamma[c] = (float)e;
+    } else {
+        const int i = (blockIdx.x - nbc) * 256 + threadIdx.x;
+        if (i >= B * G) return;
+        const int b = i / G, g = i - b * G;
+        const int cpg = C / G;
+        double a = 0.0, e = 0.0;
+        for (int s = 0; s < S; ++s)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                const float* p = part + (((long long)b * S + s) * C + c) * 2;
+                a += (double)p[0] * gamma[c];
+                e += (double)p[1] * gamma[c];
+            }
+        ds[i * 2 + 0] = (float)a;
+        ds[i * 2 + 1] = (float)e;
+    }
+}
+
+// ---- backward apply: dx (+)= rstd * (dz*gamma - (s1 + xhat*s2)/n) -----------------------------------
+__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, long long ldx,
+                                                         const float* __restrict__ dy, long long lddy,
+                                                         float* __restrict__ dx, long long lddx, long long total4, int HW,
+                                                         int C, int G, const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta, const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd, const float* __restrict__ ds,
+                                                         float inv_n, int silu, int acc) {
+    const int q = C / 4, cpg = C / G;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
+        const int c = (int)(i % q) * 4;
+        const long long pix = i / q;
+        const int b = (int)(pix / HW);
+        const float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + c);
+        const float4 d = *reinterpret_cast<const float4*>(dy + pix * lddy + c);
+        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
+        const float4 be = *reinterpret_cast<const float4*>(beta + c);
+        const float in[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w};
+        const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int g = (c + j) / cpg;
+            const float mu = mean[b * G + g], rs = rstd[b * G + g];
+            const float s1 = ds[(b * G + g) * 2 + 0], s2 = ds[(b * G + g) * 2 + 1];
+            const float xh = (in[j] - mu) * rs;
+            float dz = dd[j];
+            if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
+            o[j] = rs * (dz * gg[j] - (s1 + xh * s2) * inv_n);
+        }
+        float4* dst = reinterpret_cast<float4*>(dx + pix * lddx + c);
+        if (acc) {
+            const float4 e = *dst;
+            o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
+        }
+        *dst = make_float4(o[0], o[1], o[2], o[3]);
+    }
+}
+
+static int gn_common_checks(const char* who, int B, int HW, int C, int G, const void* x, long long ldx) {
+    BD_CHECK(B > 0 && HW > 0 && C > 0 && G > 0, BD_ERR_INVALID, "%s: bad shape", who);
+    BD_CHECK(C % G == 0, BD_ERR_INVALID, "%s: C=%d not divisible by G=%d", who, C, G);
+    BD_CHECK((C & 3) == 0 && (ldx & 3) == 0 && aligned16(x), BD_ERR_UNSUPPORTED,
+             "%s: needs C and ld multiples of 4 and a 16B-aligned pointer (C=%d ld=%lld)", who, C, ldx);
+    BD_CHECK(C / 4 <= 1024, BD_ERR_UNSUPPORTED, "%s: C=%d too large", who, C);
+    BD_CHECK(B <= 65535, BD_ERR_UNSUPPORTED, "%s: B=%d too large", who, B);
+    return BD_OK;
+}
+
+}  // namespace bd
+
+using namespace bd;
+
+extern "C" size_t bd_gn_workspace_bytes(int B, int C) {
+    // fwd: [B][S][G<=C][2] doubles ; bwd: [B][S][C][2] floats + [B][G][2] floats
+    size_t fwd = (size_t)B * GN_MAX_SPLITS * (size_t)C * 2 * sizeof(double);
+    size_t bwd = (size_t)B * GN_MAX_SPLITS * (size_t)C * 2 * sizeof(float) + (size_t)B * C * 2 * sizeof(float) + 256;
+    return fwd > bwd ? fwd : bwd;
+}
+
+extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
+    BD_CHECK(d, BD_ERR_INVALID, "bd_gn_fwd: null descriptor");
+    BD_TRY(gn_common_checks("bd_gn_fwd", d->B, d->HW, d->C, d->G, d->x, d->ldx));
+    BD_CHECK(d->gamma && d->beta && d->y && d->mean && d->rstd && d->workspace, BD_ERR_INVALID, "bd_gn_fwd: null pointer");
+    BD_CHECK((d->ldy & 3) == 0 && aligned16(d->y) && aligned16(d->gamma) && aligned16(d->beta), BD_ERR_UNSUPPORTED,
+             "bd_gn_fwd: y/gamma/beta must be 16B aligned, ldy multiple of 4");
+    const int S_ = gn_splits(d->B, d->HW);
+    const size_t need = (size_t)d->B * S_ * d->G * 2 * sizeof(double);
+    BD_CHECK(d->workspace_bytes >= need, BD_ERR_WORKSPACE, "bd_gn_fwd: workspace %zu < %zu", d->workspace_bytes, need);
+    int threads, r;
+    gn_block(d->C, threads, r);
+    double* part = reinterpret_cast<double*>(d->workspace);
+    hipLaunchKernelGGL(gn_stats_kernel, dim3(S_, d->B), dim3(threads), (size_t)r * d->C * 2 * sizeof(float), S(stream), d->x,
+                       (long long)d->ldx, d->HW, d->C, d->G, r, S_, part);
+    BD_LAUNCH_CHECK("gn_stats");
+    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)cdiv(d->B * d->G, 256)), dim3(256), 0, S(stream), part, d->B, S_,
+                       d->G, (double)d->HW * (d->C / d->G), d->eps, d->mean, d->rstd);
+    BD_LAUNCH_CHECK("gn_finalize");
+    const long long total4 = (long long)d->B * d->HW * (d->C / 4);
+    long long nb = cdiv(total4, 256);
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nb), dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->y,
+                       (long long)d->ldy, total4, d->HW, d->C, d->G, d->gamma, d->beta, d->mean, d->rstd, d->silu);
+    BD_LAUNCH_CHECK("gn_apply");
+    return BD_OK;
+}
+
+extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
+    BD_CHECK(d, BD_ERR_INVALID, "bd_gn_bwd: null descriptor");
+    BD_TRY(gn_common_checks("bd_gn_bwd", d->B, d->HW, d->C, d->G, d->x, d->ldx));
+    BD_CHECK(d->gamma && d->beta && d->mean && d->rstd && d->dy && d->dx && d->dgamma && d->dbeta && d->workspace,
+             BD_ERR_INVALID, "bd_gn_bwd: null pointer");
+    BD_CHECK((d->lddy & 3) == 0 && (d->lddx & 3) == 0 && aligned16(d->dy) && aligned16(d->dx) && aligned16(d->gamma) &&
+                 aligned16(d->beta), BD_ERR_UNSUPPORTED, "bd_gn_bwd: pointers must be 16B aligned, ld multiples of 4");
+    const int S_ = gn_splits(d->B, d->HW);
+    const size_t part_bytes = align_up((size_t)d->B * S_ * d->C * 2 * sizeof(float), 256);
+    const size_t need = part_bytes + (size_t)d->B * d->G * 2 * sizeof(float);
+    BD_CHECK(d->workspace_bytes >= need, BD_ERR_WORKSPACE, "bd_gn_bwd: workspace %zu < %zu", d->workspace_bytes, need);
+    float* part = reinterpret_cast<float*>(d->workspace);
+    float* ds = reinterpret_cast<float*>(reinterpret_cast<char*>(d->workspace) + part_bytes);
+    int threads, r;
+    gn_block(d->C, threads, r);
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(S_, d->B), dim3(threads), (size_t)r * d->C * 2 * sizeof(float), S(stream), d->x,
+                       (long long)d->ldx, d->dy, (long long)d->lddy, d->HW, d->C, d->G, r, S_, d->gamma, d->beta, d->mean,
+                       d->rstd, d->silu, part);
+    BD_LAUNCH_CHECK("gn_bwd_stats");
+    const int nbc = (int)cdiv(d->C, 256), nbg = (int)cdiv(d->B * d->G, 256);
+    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(nbc + nbg), dim3(256), 0, S(stream), part, d->B, S_, d->C, d->G, d->gamma,
+                       nbc, d->dgamma, d->dbeta, ds);
+    BD_LAUNCH_CHECK("gn_bwd_finalize");
+    const long long total4 = (long long)d->B * d->HW * (d->C / 4);
+    long long nb = cdiv(total4, 256);
+    if (nb > 16384) nb = 16384;
+    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)nb), dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->dy,
+                       (long long)d->lddy, d->dx, (long long)d->lddx, total4, d->HW, d->C, d->G, d->gamma, d->beta, d->mean,
+                       d->rstd, ds, 1.0f / ((float)d->HW * (d->C / d->G)), d->silu, d->accumulate_dx);
+    BD_LAUNCH_CHECK("gn_bwd_apply");
+    return BD_OK;
+}

@@ -1,0 +1,511 @@
+// Implicit-GEMM engine for gfx950 on the f32 MFMA (v_mfma_f32_32x32x2_f32).
+//
+//   C[m,n] = epilogue( sum_k A(m,k) * B(n,k) )
+//
+// One workgroup = 4 waves (2x2) computing a BMxBN tile (128x128 or 64x64), K walked in chunks of 32.
+// Operand tiles are staged global -> registers -> LDS in the layout their memory contiguity dictates:
+//   KC ("k contiguous"):   LDS [rows][32+4]  -> fragments read with one ds_read_b128 per 4 MFMAs
+//   RC ("row contiguous"): LDS [32][rows+4]  -> fragments read with ds_read_b32 (transpose for free)
+// The f32 MFMA takes ONE float per lane per operand (lane l: row l&31, k-slot l>>5), so any
+// (row,k) -> memory map works without a transpose pass; the K order inside a chunk is permuted
+// identically for A and B (k(g,j,h) = 8g + 4h + j) which leaves the dot product unchanged.
+// Results are bit-identical to a k-ordered fmaf chain per (m,n) within one K chunk order
+// (cdna_hip_programming.md section 3), i.e. fp32 everywhere: no reduced-precision inputs.
+//
+// Operand kinds (bd_hip.h): DENSE, CONV (3x3 gather, fwd and wgrad), TCONV (dgrad gather), WGT
+// (weights seen from the dgrad side).  Replaces aten::convolution(_backward), addmm/mm/bmm/baddbmm
+// in the reference's UNet.
+#include "common.h"
+
+namespace bd {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+
+constexpr int BK = 32;
+constexpr int LDK = BK + 4;  // KC row stride (floats): 16B-aligned rows, conflict-free b128 reads
+
+struct Opnd {
+    const float* p;
+    long long ld;
+    int kind, vec;
+    int C, Hs, Ws, Ho, Wo, stride, pad_t, pad_l, ups;
+    int rows;  // number of valid rows (M for A, N for B)
+};
+
+struct IGemmParams {
+    Opnd A, B;
+    int M, N, K;
+    int tiles_m, tiles_n;
+    int batch_inner, ksplit, chunks_per_split;
+    long long a_bso, a_bsi, b_bso, b_bsi, c_bso, c_bsi;
+    float* C;
+    long long ldc;
+    float alpha, out_scale;
+    const float* bias;
+    const float* rowbias;
+    long long ld_rowbias;
+    int rows_per_group;
+    const float* residual;
+    long long ldr;
+    int accumulate;
+    float* partial;  // [batch*ksplit][M][N] when ksplit > 1
+};
+
+__device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+
+// ------------------------------------------------------------------------------------------------
+// KC loader: tile [R rows][32 k]; thread t owns float4 column k4 = (t&7)*4 of rows (t>>3) + 32*i.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+struct LoaderKC {
+    static constexpr int NI = R / 32;
+    long long base[NI];  // DENSE: row*ld ; CONV/TCONV: image offset b*Hs*Ws*ld
+    int yb[NI], xb[NI];  // CONV: y*stride - pad_t ; TCONV: yi + pad_t   (invalid row: very negative)
+    int k4;
+
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid) {
+        k4 = (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int r = row0 + (tid >> 3) + 32 * i;
+            bool ok = r < o.rows;
+            if (o.kind == BD_OPK_DENSE) {
+                base[i] = (long long)r * o.ld;
+                yb[i] = ok ? 0 : -(1 << 28);
+                xb[i] = 0;
+            } else {
+                int hw = o.Ho * o.Wo;
+                int b = r / hw;
+                int rem = r - b * hw;
+                int y = rem / o.Wo;
+                int x = rem - y * o.Wo;
+                base[i] = (long long)b * o.Hs * o.Ws * o.ld;
+                if (o.kind == BD_OPK_CONV) {
+                    yb[i] = ok ? y * o.stride - o.pad_t : -(1 << 28);
+                    xb[i] = x * o.stride - o.pad_l;
+                } else {  // TCONV
+                    yb[i] = ok ? y + o.pad_t : -(1 << 28);
+                    xb[i] = x + o.pad_l;
+                }
+            }
+        }
+    }
+
+    // address (element offset) of (row slot i, absolute k) or -1 if it reads as zero
+    __device__ __forceinline__ long long addr(const Opnd& o, int i, int k, int K) const {
+        if (k >= K) return -1;
+        if (o.kind == BD_OPK_DENSE) return yb[i] < 0 ? -1 : base[i] + k;
+        int tap = k / o.C;
+        int c = k - tap * o.C;
+        int kh = tap / 3, kw = tap - kh * 3;
+        if (o.kind == BD_OPK_CONV) {
+            int ys = yb[i] + kh, xs = xb[i] + kw;
+            if (ys < 0 || xs < 0 || ys >= (o.Hs << o.ups) || xs >= (o.Ws << o.ups)) return -1;
+            return base[i] + ((long long)(ys >> o.ups) * o.Ws + (xs >> o.ups)) * o.ld + c;
+        } else {
+            int yn = yb[i] - kh, xn = xb[i] - kw;
+            if (yn < 0 || xn < 0) return -1;
+            if (o.stride == 2) {
+                if ((yn | xn) & 1) return -1;
+                yn >>= 1;
+                xn >>= 1;
+            }
+            if (yn >= o.Hs || xn >= o.Ws) return -1;
+            return base[i] + ((long long)yn * o.Ws + xn) * o.ld + c;
+        }
+    }
+
+    __device__ __forceinline__ void load(const Opnd& o, int kbase, int K, float4 (&v)[NI]) const {
+        int k = kbase + k4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            if (o.vec) {
+                long long a = addr(o, i, k, K);
+                v[i] = a >= 0 ? ld4(o.p + a) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    long long a = addr(o, i, k + j, K);
+                    e[j] = a >= 0 ? o.p[a] : 0.f;
+                }
+                v[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* s, int tid, const float4 (&v)[NI]) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i)
+            *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * i) * LDK + k4) = v[i];
+    }
+};
+
+// ------------------------------------------------------------------------------------------------
+// RC loader: tile [32 k][R rows]; thread t owns float4 at rows r4 = (t % (R/4))*4, k = t/(R/4) + KS*i.
+// ------------------------------------------------------------------------------------------------
+template <int R>
+struct LoaderRC {
+    static constexpr int NI = R / 32;
+    static constexpr int KS = 1024 / R;
+    static constexpr int LDR = R + 4;
+    int r4, k0, row;
+    // CONV: (tap, ci) of row..row+3 is fixed per thread
+    int kh[4], kw[4], ci[4];
+    bool rok[4];
+
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid) {
+        r4 = (tid % (R / 4)) * 4;
+        k0 = tid / (R / 4);
+        row = row0 + r4;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            int r = row + j;
+            rok[j] = r < o.rows;
+            if (o.kind == BD_OPK_CONV) {
+                int tap = r / o.C;
+                ci[j] = r - tap * o.C;
+                kh[j] = tap / 3;
+                kw[j] = tap - kh[j] * 3;
+                if (tap >= 9) rok[j] = false;
+            } else {
+                ci[j] = r;
+                kh[j] = kw[j] = 0;
+            }
+        }
+    }
+
+    __device__ __forceinline__ long long addr(const Opnd& o, int j, int k, int K) const {
+        if (k >= K || !rok[j]) return -1;
+        if (o.kind == BD_OPK_DENSE) return (long long)k * o.ld + ci[j];
+        if (o.kind == BD_OPK_WGT) {  // k = tap*C + co ; W[(co*9 + tap)*ld + ci]
+            int tap = k / o.C;
+            int co = k - tap * o.C;
+            return ((long long)co * 9 + tap) * o.ld + ci[j];
+        }
+        // CONV (wgrad): k = output pixel
+        int hw = o.Ho * o.Wo;
+        int b = k / hw;
+        int rem = k - b * hw;
+        int y = rem / o.Wo;
+        int x = rem - y * o.Wo;
+        int ys = y * o.stride - o.pad_t + kh[j], xs = x * o.stride - o.pad_l + kw[j];
+        if (ys < 0 || xs < 0 || ys >= (o.Hs << o.ups) || xs >= (o.Ws << o.ups)) return -1;
+        return ((long long)b * o.Hs * o.Ws + (long long)(ys >> o.ups) * o.Ws + (xs >> o.ups)) * o.ld + ci[j];
+    }
+
+    __device__ __forceinline__ void load(const Opnd& o, int kbase, int K, float4 (&v)[NI]) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            int k = kbase + k0 + KS * i;
+            if (o.vec) {
+                long long a = addr(o, 0, k, K);
+                v[i] = a >= 0 ? ld4(o.p + a) : make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+                float e[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    long long a = addr(o, j, k, K);
+                    e[j] = a >= 0 ? o.p[a] : 0.f;
+                }
+                v[i] = make_float4(e[0], e[1], e[2], e[3]);
+            }
+        }
+    }
+
+    __device__ __forceinline__ void store(float* s, int tid, const float4 (&v)[NI]) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + (k0 + KS * i) * LDR + r4) = v[i];
+    }
+};
+
+template <int R, bool KC>
+struct LoaderSel {
+    typedef LoaderKC<R> type;
+};
+template <int R>
+struct LoaderSel<R, false> {
+    typedef LoaderRC<R> type;
+};
+
+template <int R, bool KC>
+constexpr int lds_floats() {
+    return KC ? R * LDK : BK * (R + 4);
+}
+
+// ------------------------------------------------------------------------------------------------
+template <int BM, int BN, bool A_KC, bool B_KC>
+__global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    __shared__ __attribute__((aligned(16))) float sA[lds_floats<BM, A_KC>()];
+    __shared__ __attribute__((aligned(16))) float sB[lds_floats<BN, B_KC>()];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+
+    // tile coordinates: n fastest so neighbouring workgroups share the A (activation) panel
+    int tile = blockIdx.x;
+    const int tn_i = tile % p.tiles_n, tm_i = tile / p.tiles_n;
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int bz = blockIdx.z / p.ksplit, ks = blockIdx.z - bz * p.ksplit;
+    const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
+
+    Opnd A = p.A, B = p.B;
+    A.p += bo * p.a_bso + bi * p.a_bsi;
+    B.p += bo * p.b_bso + bi * p.b_bsi;
+
+    typename LoaderSel<BM, A_KC>::type la;
+    typename LoaderSel<BN, B_KC>::type lb;
+    la.init(A, m0, tid);
+    lb.init(B, n0, tid);
+
+    floatx16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    const int nchunks_total = (p.K + BK - 1) / BK;
+    const int c_begin = ks * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > nchunks_total) c_end = nchunks_total;
+
+    float4 ra[BM / 32], rb[BN / 32];
+    if (c_begin < c_end) {
+        la.load(A, c_begin * BK, p.K, ra);
+        lb.load(B, c_begin * BK, p.K, rb);
+    }
+    for (int c = c_begin; c < c_end; ++c) {
+        la.store(sA, tid, ra);
+        lb.store(sB, tid, rb);
+        __syncthreads();
+        if (c + 1 < c_end) {  // prefetch the next chunk into registers while this one is computed
+            la.load(A, (c + 1) * BK, p.K, ra);
+            lb.load(B, (c + 1) * BK, p.K, rb);
+        }
+#pragma unroll
+        for (int g = 0; g < BK / 8; ++g) {
+            float fa[TM][4], fb[TN][4];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const int r = wm * WM + i * 32 + li;
+                if (A_KC) {
+                    float4 v = *reinterpret_cast<const float4*>(sA + r * LDK + g * 8 + 4 * h);
+                    fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fa[i][j] = sA[(g * 8 + 4 * h + j) * (BM + 4) + r];
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int r = wn * WN + i * 32 + li;
+                if (B_KC) {
+                    float4 v = *reinterpret_cast<const float4*>(sB + r * LDK + g * 8 + 4 * h);
+                    fb[i][0] = v.x; fb[i][1] = v.y; fb[i][2] = v.z; fb[i][3] = v.w;
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) fb[i][j] = sB[(g * 8 + 4 * h + j) * (BN + 4) + r];
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < TN; ++q)
+                        acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[q][j], acc[i][q], 0, 0, 0);
+        }
+        __syncthreads();
+    }
+
+    // ---- epilogue: lane holds column (n) li of rows (r&3) + 8*(r>>2) + 4*h -----------------------
+    const long long coff = bo * p.c_bso + bi * p.c_bsi;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < TN; ++q) {
+            const int n = n0 + wn * WN + q * 32 + li;
+            if (n >= p.N) continue;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = acc[i][q][r];
+                if (p.ksplit > 1) {
+                    p.partial[((long long)blockIdx.z * p.M + m) * p.N + n] = v;
+                } else {
+                    v *= p.alpha;
+                    if (p.bias) v += p.bias[n];
+                    if (p.rowbias) v += p.rowbias[(long long)(m / p.rows_per_group) * p.ld_rowbias + n];
+                    if (p.residual) v += p.residual[coff + (long long)m * p.ldr + n];
+                    v *= p.out_scale;
+                    float* dst = p.C + coff + (long long)m * p.ldc + n;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
+
+// split-K second pass: fixed-order (deterministic) sum of the partial slabs + epilogue
+__global__ __launch_bounds__(256) void igemm_splitk_reduce(IGemmParams p, int nbatch) {
+    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long per = (long long)p.M * p.N;
+    if (idx >= per * nbatch) return;
+    int bz = (int)(idx / per);
+    long long mn = idx - (long long)bz * per;
+    int m = (int)(mn / p.N), n = (int)(mn - (long long)m * p.N);
+    float v = 0.f;
+    for (int s = 0; s < p.ksplit; ++s) v += p.partial[((long long)(bz * p.ksplit + s)) * per + mn];
+    const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
+    const long long coff = bo * p.c_bso + bi * p.c_bsi;
+    v *= p.alpha;
+    if (p.bias) v += p.bias[n];
+    if (p.rowbias) v += p.rowbias[(long long)(m / p.rows_per_group) * p.ld_rowbias + n];
+    if (p.residual) v += p.residual[coff + (long long)m * p.ldr + n];
+    v *= p.out_scale;
+    float* dst = p.C + coff + (long long)m * p.ldc + n;
+    if (p.accumulate) v += *dst;
+    *dst = v;
+}
+
+// ------------------------------------------------------------------------------------------------
+static bool operand_vec_ok(const bd_operand& o, int rows, int K) {
+    if (!aligned16(o.p) || (o.ld & 3) || (o.bs_outer & 3) || (o.bs_inner & 3)) return false;
+    if (o.kc) {
+        if (o.kind == BD_OPK_DENSE) return (K & 3) == 0;
+        return (o.C & 3) == 0;  // CONV / TCONV: a float4 never straddles a tap
+    }
+    // RC: float4 along rows
+    if (o.kind == BD_OPK_CONV) return (o.C & 3) == 0;
+    return (rows & 3) == 0;
+}
+
+static int validate_operand(const bd_operand& o, const char* which) {
+    BD_CHECK(o.p != nullptr, BD_ERR_INVALID, "igemm: operand %s is null", which);
+    if (o.kc) {
+        BD_CHECK(o.kind == BD_OPK_DENSE || o.kind == BD_OPK_CONV || o.kind == BD_OPK_TCONV, BD_ERR_INVALID,
+                 "igemm: operand %s: kind %d not valid for KC storage", which, o.kind);
+    } else {
+        BD_CHECK(o.kind == BD_OPK_DENSE || o.kind == BD_OPK_CONV || o.kind == BD_OPK_WGT, BD_ERR_INVALID,
+                 "igemm: operand %s: kind %d not valid for RC storage", which, o.kind);
+    }
+    if (o.kind != BD_OPK_DENSE) {
+        BD_CHECK(o.C > 0, BD_ERR_INVALID, "igemm: operand %s: C must be > 0", which);
+        if (o.kind != BD_OPK_WGT) {
+            BD_CHECK(o.Hs > 0 && o.Ws > 0 && o.Ho > 0 && o.Wo > 0, BD_ERR_INVALID,
+                     "igemm: operand %s: bad conv geometry", which);
+            BD_CHECK(o.stride == 1 || o.stride == 2, BD_ERR_UNSUPPORTED, "igemm: stride %d unsupported", o.stride);
+            BD_CHECK(o.ups == 0 || o.ups == 1, BD_ERR_UNSUPPORTED, "igemm: ups %d unsupported", o.ups);
+            BD_CHECK(!(o.ups && o.kind == BD_OPK_TCONV), BD_ERR_UNSUPPORTED, "igemm: TCONV with ups");
+        }
+    }
+    return BD_OK;
+}
+
+static Opnd make_opnd(const bd_operand& o, int rows, int K) {
+    Opnd r;
+    r.p = o.p; r.ld = o.ld; r.kind = o.kind; r.vec = operand_vec_ok(o, rows, K) ? 1 : 0;
+    r.C = o.C > 0 ? o.C : 1; r.Hs = o.Hs; r.Ws = o.Ws; r.Ho = o.Ho > 0 ? o.Ho : 1; r.Wo = o.Wo > 0 ? o.Wo : 1;
+    r.stride = o.stride > 0 ? o.stride : 1; r.pad_t = o.pad_t; r.pad_l = o.pad_l; r.ups = o.ups; r.rows = rows;
+    return r;
+}
+
+struct Choice {
+    int tile, ksplit, cps;
+};
+
+static Choice choose(const bd_igemm_desc& d) {
+    Choice c;
+    const int nb = d.batch_outer * d.batch_inner;
+    auto tiles = [&](int t) { return cdiv(d.M, t) * cdiv(d.N, t) * nb; };
+    c.tile = d.tile ? d.tile : ((d.M >= 128 && d.N >= 128 && tiles(128) >= 192) ? 128 : 64);
+    const int nchunks = (int)cdiv(d.K, BK);
+    int ks = d.ksplit;
+    if (ks <= 0) {
+        long long t = tiles(c.tile);
+        ks = 1;
+        if (t < 256) {
+            ks = (int)cdiv(512, t);
+            int maxks = nchunks / 4;
+            if (maxks < 1) maxks = 1;
+            if (ks > maxks) ks = maxks;
+            if (ks > 128) ks = 128;
+        }
+    }
+    if (ks > nchunks) ks = nchunks;
+    if (ks < 1) ks = 1;
+    c.cps = (int)cdiv(nchunks, ks);
+    c.ksplit = (int)cdiv(nchunks, c.cps);  // no empty splits
+    return c;
+}
+
+size_t igemm_workspace_bytes(const bd_igemm_desc& d) {
+    Choice c = choose(d);
+    if (c.ksplit <= 1) return 0;
+    return (size_t)d.batch_outer * d.batch_inner * c.ksplit * (size_t)d.M * d.N * sizeof(float);
+}
+
+template <int T>
+static void launch_tile(const IGemmParams& p, bool akc, bool bkc, dim3 grid, hipStream_t st) {
+    if (akc && bkc) hipLaunchKernelGGL((igemm_kernel<T, T, true, true>), grid, dim3(256), 0, st, p);
+    else if (akc && !bkc) hipLaunchKernelGGL((igemm_kernel<T, T, true, false>), grid, dim3(256), 0, st, p);
+    else if (!akc && !bkc) hipLaunchKernelGGL((igemm_kernel<T, T, false, false>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<T, T, false, true>), grid, dim3(256), 0, st, p);
+}
+
+int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
+    BD_CHECK(d.M > 0 && d.N > 0 && d.K > 0, BD_ERR_INVALID, "igemm: M,N,K must be > 0 (got %d,%d,%d)", d.M, d.N, d.K);
+    BD_CHECK(d.batch_outer >= 1 && d.batch_inner >= 1, BD_ERR_INVALID, "igemm: batch counts must be >= 1");
+    BD_CHECK(d.C != nullptr, BD_ERR_INVALID, "igemm: C is null");
+    BD_CHECK(d.tile == 0 || d.tile == 64 || d.tile == 128, BD_ERR_INVALID, "igemm: tile must be 0, 64 or 128");
+    BD_TRY(validate_operand(d.A, "A"));
+    BD_TRY(validate_operand(d.B, "B"));
+    BD_CHECK(!(d.rowbias && d.rows_per_group <= 0), BD_ERR_INVALID, "igemm: rowbias needs rows_per_group > 0");
+
+    Choice c = choose(d);
+    IGemmParams p;
+    p.A = make_opnd(d.A, d.M, d.K);
+    p.B = make_opnd(d.B, d.N, d.K);
+    p.M = d.M; p.N = d.N; p.K = d.K;
+    p.tiles_m = (int)cdiv(d.M, c.tile); p.tiles_n = (int)cdiv(d.N, c.tile);
+    p.batch_inner = d.batch_inner; p.ksplit = c.ksplit; p.chunks_per_split = c.cps;
+    p.a_bso = d.A.bs_outer; p.a_bsi = d.A.bs_inner; p.b_bso = d.B.bs_outer; p.b_bsi = d.B.bs_inner;
+    p.c_bso = d.c_bs_outer; p.c_bsi = d.c_bs_inner;
+    p.C = d.C; p.ldc = d.ldc; p.alpha = d.alpha; p.out_scale = d.out_scale;
+    p.bias = d.bias; p.rowbias = d.rowbias; p.ld_rowbias = d.ld_rowbias;
+    p.rows_per_group = d.rows_per_group > 0 ? d.rows_per_group : 1;
+    p.residual = d.residual; p.ldr = d.ldr; p.accumulate = d.accumulate;
+    p.partial = nullptr;
+    const int nb = d.batch_outer * d.batch_inner;
+    if (c.ksplit > 1) {
+        size_t need = (size_t)nb * c.ksplit * (size_t)d.M * d.N * sizeof(float);
+        BD_CHECK(d.workspace && d.workspace_bytes >= need, BD_ERR_WORKSPACE,
+                 "igemm: split-K needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
+        p.partial = reinterpret_cast<float*>(d.workspace);
+    }
+    dim3 grid(p.tiles_m * p.tiles_n, 1, nb * c.ksplit);
+    BD_CHECK(grid.z <= 65535, BD_ERR_UNSUPPORTED, "igemm: batch*ksplit %u too large", grid.z);
+    if (c.tile == 128) launch_tile<128>(p, d.A.kc != 0, d.B.kc != 0, grid, stream);
+    else launch_tile<64>(p, d.A.kc != 0, d.B.kc != 0, grid, stream);
+    BD_LAUNCH_CHECK("igemm");
+    if (c.ksplit > 1) {
+        long long total = (long long)d.M * d.N * nb;
+        hipLaunchKernelGGL(igemm_splitk_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, p, nb);
+        BD_LAUNCH_CHECK("igemm_splitk_reduce");
+    }
+    return BD_OK;
+}
+
+}  // namespace bd
+
+extern "C" size_t bd_igemm_workspace_bytes(const bd_igemm_desc* d) { return d ? bd::igemm_workspace_bytes(*d) : 0; }
+extern "C" int bd_igemm(const bd_igemm_desc* d, bd_stream_t stream) {
+    BD_CHECK(d != nullptr, BD_ERR_INVALID, "bd_igemm: null descriptor");
+    return bd::igemm_launch(*d, bd::S(stream));
+}

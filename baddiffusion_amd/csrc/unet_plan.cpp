@@ -1,0 +1,900 @@
+// UNet2DModel as a static execution plan (host-only object; all device memory is the caller's).
+//
+// Mirrors the topology built by /root/reference/diffusers/src/diffusers/models/unet_2d.py:82-217 and the
+// forward of :229-326, with ResnetBlock2D (resnet.py:551-601), AttentionBlock (attention.py:121-174),
+// Downsample2D (resnet.py:199-208), Upsample2D (resnet.py:126-161) and the skip bookkeeping of
+// unet_2d_blocks.py (DownBlock2D, AttnDownBlock2D, UNetMidBlock2D, UpBlock2D, AttnUpBlock2D).
+//
+// MI355X-first choices:
+//  * activations NHWC with a leading dimension: every skip tensor is BORN inside the concat buffer of the
+//    up-block resnet that will consume it, so torch.cat (13 copies/forward in the reference) disappears;
+//  * parameters / gradients are ONE flat fp32 buffer each (time-embedding projections of all resnets are
+//    contiguous => one GEMM; Adam + clip are single launches; DP all-reduce buckets are plain ranges);
+//  * every parameter receives exactly one gradient contribution => grads are written, never accumulated;
+//  * forward and backward are fixed launch sequences on one stream: hipGraph-capturable, no host sync.
+#include "common.h"
+
+#include <functional>
+#include <string>
+#include <vector>
+#include <cmath>
+
+namespace bd {
+
+int conv3x3_fwd(const bd_conv3x3_fwd_desc& d, hipStream_t st);
+int conv3x3_dgrad(const bd_conv3x3_dgrad_desc& d, hipStream_t st);
+int conv3x3_wgrad(const bd_conv3x3_wgrad_desc& d, hipStream_t st);
+
+struct View {
+    int buf = -1;   // value buffer id
+    int coff = 0;   // channel offset inside the buffer
+    int C = 0, ld = 0, H = 0, W = 0;
+};
+
+enum Region { R_VALUE = 0, R_GRAD = 1, R_SCRATCH = 2 };
+struct Buf {
+    int64_t per_sample = 0, fixed = 0;
+    int region = R_VALUE, group = 0;
+    int64_t off = 0;  // floats, filled by layout()
+    int gbuf = -1;    // grad buffer of a value buffer
+};
+
+struct Param {
+    std::string name;
+    int64_t off;
+    int rank;
+    int64_t shape[4];
+    int layout;
+};
+
+struct Ctx {
+    bool dry = false;
+    int B = 0;
+    float* ws = nullptr;
+    const float* params = nullptr;
+    float* grads = nullptr;
+    hipStream_t st = nullptr;
+    const float* x = nullptr; int64_t ldx = 0;
+    const int64_t* t = nullptr; int t_stride = 0;
+    float* out = nullptr; int64_t ldo = 0;
+    const float* dout = nullptr; int64_t lddo = 0;
+    char* opws = nullptr; size_t opws_bytes = 0; size_t opws_need = 0;
+    std::vector<char> ginit;
+};
+
+typedef std::function<int(Ctx&)> Step;
+
+}  // namespace bd
+
+using namespace bd;
+
+struct bd_unet {
+    bd_unet_config cfg;
+    std::vector<Buf> bufs;
+    std::vector<Param> params;
+    int64_t nparams = 0;
+    std::vector<Step> fwd;
+    struct BStep { Step fn; int seg; };
+    std::vector<BStep> bwd;  // in FORWARD emission order; executed reversed
+    struct Seg { int64_t lo, hi; };
+    std::vector<Seg> segs;   // indexed by segment id (backward order)
+    int cur_seg = 0, cur_group = 0;
+    // layout cache
+    int lay_B = -1, lay_train = -1;
+    int64_t value_floats = 0, grad_floats = 0, scratch_floats = 0;
+    size_t opws_bytes = 0;
+    int T = 0, sumC = 0;     // time-embed dim, total time_emb_proj rows
+    int64_t p_tw = 0, p_tb = 0;  // offsets of the batched time_emb_proj weight / bias
+    int b_tproj = -1, b_dtproj = -1, b_embs = -1;
+
+    // ---------------------------------------------------------------- construction helpers
+    int new_buf(int64_t per_sample, int64_t fixed, int region) {
+        Buf b;
+        b.per_sample = per_sample; b.fixed = fixed; b.region = region; b.group = cur_group;
+        bufs.push_back(b);
+        return (int)bufs.size() - 1;
+    }
+    View new_tensor(int H, int W, int C) {  // standalone value tensor with a grad buffer
+        View v;
+        v.buf = new_buf((int64_t)H * W * C, 0, R_VALUE);
+        bufs[v.buf].gbuf = new_buf((int64_t)H * W * C, 0, R_GRAD);
+        v.coff = 0; v.C = C; v.ld = C; v.H = H; v.W = W;
+        return v;
+    }
+    View slice(const View& v, int coff, int C) const {
+        View s = v;
+        s.coff = v.coff + coff; s.C = C;
+        return s;
+    }
+    int scratch(int64_t per_sample, int64_t fixed = 0) { return new_buf(per_sample, fixed, R_SCRATCH); }
+    int64_t add_param(const std::string& name, std::initializer_list<int64_t> shape, int layout = 0) {
+        Param p;
+        p.name = name; p.rank = (int)shape.size(); p.layout = layout;
+        int64_t n = 1; int i = 0;
+        for (auto s : shape) { p.shape[i++] = s; n *= s; }
+        for (; i < 4; ++i) p.shape[i] = 1;
+        nparams = (nparams + 3) / 4 * 4;  // 16-byte aligned start
+        p.off = nparams;
+        nparams += n;
+        params.push_back(p);
+        if (!segs.empty()) {
+            Seg& s = segs[cur_seg];
+            if (s.lo < 0 || p.off < s.lo) s.lo = p.off;
+            if (p.off + n > s.hi) s.hi = p.off + n;
+        }
+        return p.off;
+    }
+    void alias_param(const std::string& name, int64_t off, std::initializer_list<int64_t> shape) {
+        Param p;
+        p.name = name; p.rank = (int)shape.size(); p.layout = 0; p.off = off;
+        int i = 0;
+        for (auto s : shape) p.shape[i++] = s;
+        for (; i < 4; ++i) p.shape[i] = 1;
+        params.push_back(p);
+    }
+    void F(Step s) { fwd.push_back(std::move(s)); }
+    void Bk(Step s) { bwd.push_back({std::move(s), cur_seg}); }
+
+    // ---------------------------------------------------------------- run-time helpers
+    float* VP(Ctx& c, const View& v) const { return c.ws + bufs[v.buf].off + v.coff; }
+    float* GP(Ctx& c, const View& v) const { return c.ws + bufs[bufs[v.buf].gbuf].off + v.coff; }
+    float* BP(Ctx& c, int b) const { return c.ws + bufs[b].off; }
+    static int64_t rows(const Ctx& c, const View& v) { return (int64_t)c.B * v.H * v.W; }
+
+    int igemm(Ctx& c, bd_igemm_desc& g) const {
+        g.workspace = c.opws; g.workspace_bytes = c.opws_bytes;
+        if (c.dry) {
+            size_t n = igemm_workspace_bytes(g);
+            if (n > c.opws_need) c.opws_need = n;
+            return BD_OK;
+        }
+        return igemm_launch(g, c.st);
+    }
+    static bd_operand dense(const float* p, int64_t ld, int kc) {
+        bd_operand o = {};
+        o.kind = BD_OPK_DENSE; o.kc = kc; o.p = p; o.ld = ld;
+        return o;
+    }
+    // C[M,N] = alpha * A[M,K] * W[N,K]^T (+bias) (+residual)*out_scale        (Linear / 1x1 conv forward)
+    int linear_fwd(Ctx& c, const float* A, int64_t lda, const float* W, const float* bias, float* C, int64_t ldc, int M, int N,
+                   int K, const float* residual = nullptr, int64_t ldr = 0, float out_scale = 1.f) const {
+        bd_igemm_desc g = {};
+        g.A = dense(A, lda, 1); g.B = dense(W, K, 1);
+        g.M = M; g.N = N; g.K = K; g.batch_outer = g.batch_inner = 1;
+        g.C = C; g.ldc = ldc; g.alpha = 1.f; g.out_scale = out_scale; g.bias = bias; g.residual = residual; g.ldr = ldr;
+        return igemm(c, g);
+    }
+    // dX[M,K] (+)= dY[M,N] * W[N,K]
+    int linear_dgrad(Ctx& c, const float* dY, int64_t lddy, const float* W, float* dX, int64_t lddx, int M, int N, int K,
+                     int acc) const {
+        bd_igemm_desc g = {};
+        g.A = dense(dY, lddy, 1); g.B = dense(W, K, 0);
+        g.M = M; g.N = K; g.K = N; g.batch_outer = g.batch_inner = 1;
+        g.C = dX; g.ldc = lddx; g.alpha = 1.f; g.out_scale = 1.f; g.accumulate = acc;
+        return igemm(c, g);
+    }
+    // dW[N,K] = dY[M,N]^T * X[M,K]
+    int linear_wgrad(Ctx& c, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int M, int N, int K) const {
+        bd_igemm_desc g = {};
+        g.A = dense(dY, lddy, 0); g.B = dense(X, ldx, 0);
+        g.M = N; g.N = K; g.K = M; g.batch_outer = g.batch_inner = 1;
+        g.C = dW; g.ldc = K; g.alpha = 1.f; g.out_scale = 1.f;
+        return igemm(c, g);
+    }
+    int colsum(Ctx& c, const float* x, int64_t ldx, int64_t nrows, int N, int64_t rpg, float* out, int64_t ldo) const {
+        if (c.dry) return BD_OK;
+        return bd_colsum(x, ldx, nrows, N, rpg, out, ldo, 0, c.st);
+    }
+    // bias gradient: per-sample column sums (scratch [B,N]) then a sum over the batch (fixed order)
+    int bias_grad(Ctx& c, const float* dY, int64_t ld, int HW, int N, int scratch_buf, float* db, float* db2 = nullptr) const {
+        float* s = BP(c, scratch_buf);
+        BD_TRY(colsum(c, dY, ld, (int64_t)c.B * HW, N, HW, s, N));
+        BD_TRY(colsum(c, s, N, c.B, N, c.B, db, N));
+        if (db2) BD_TRY(colsum(c, s, N, c.B, N, c.B, db2, N));
+        return BD_OK;
+    }
+    int gn_fwd(Ctx& c, const View& x, int64_t pg, int64_t pb, float* y, int64_t ldy, int stats_buf, int silu) const {
+        bd_gn_fwd_desc d = {};
+        d.B = c.B; d.HW = x.H * x.W; d.C = x.C; d.G = cfg.norm_num_groups; d.eps = cfg.norm_eps; d.silu = silu;
+        d.x = VP(c, x); d.ldx = x.ld; d.gamma = c.params + pg; d.beta = c.params + pb; d.y = y; d.ldy = ldy;
+        d.mean = BP(c, stats_buf); d.rstd = d.mean + (int64_t)c.B * d.G;
+        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+        if (c.dry) {
+            size_t n = bd_gn_workspace_bytes(c.B, x.C);
+            if (n > c.opws_need) c.opws_need = n;
+            return BD_OK;
+        }
+        return bd_gn_fwd(&d, (bd_stream_t)c.st);
+    }
+    int gn_bwd(Ctx& c, const View& x, int64_t pg, int64_t pb, int stats_buf, const float* dy, int64_t lddy, int silu) {
+        bd_gn_bwd_desc d = {};
+        d.B = c.B; d.HW = x.H * x.W; d.C = x.C; d.G = cfg.norm_num_groups; d.silu = silu;
+        d.x = VP(c, x); d.ldx = x.ld; d.gamma = c.params + pg; d.beta = c.params + pb;
+        d.mean = BP(c, stats_buf); d.rstd = d.mean + (int64_t)c.B * d.G;
+        d.dy = dy; d.lddy = lddy; d.dx = GP(c, x); d.lddx = x.ld;
+        d.accumulate_dx = c.ginit[x.buf];
+        c.ginit[x.buf] = 1;
+        d.dgamma = c.grads + pg; d.dbeta = c.grads + pb;
+        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+        if (c.dry) return BD_OK;
+        return bd_gn_bwd(&d, (bd_stream_t)c.st);
+    }
+    int add(Ctx& c, const float* src, int64_t lds, float* dst, int64_t ldd, int64_t nrows, int C, float scale, int acc) const {
+        if (c.dry) return BD_OK;
+        return add_launch(src, lds, dst, ldd, nrows, C, scale, acc, c.st);
+    }
+    int conv_f(Ctx& c, bd_conv3x3_fwd_desc& d) const {
+        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+        if (c.dry) { note_conv(c); return BD_OK; }
+        return conv3x3_fwd(d, c.st);
+    }
+    int conv_d(Ctx& c, bd_conv3x3_dgrad_desc& d) const {
+        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+        if (c.dry) { note_conv(c); return BD_OK; }
+        return conv3x3_dgrad(d, c.st);
+    }
+    int conv_w(Ctx& c, bd_conv3x3_wgrad_desc& d) const {
+        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+        if (c.dry) { note_conv(c); return BD_OK; }
+        return conv3x3_wgrad(d, c.st);
+    }
+    static void note_conv(Ctx& c) {
+        size_t n = bd_conv3x3_workspace_bytes(0, 0, 0, 0, 0, 0, 0, 0);
+        if (n > c.opws_need) c.opws_need = n;
+    }
+
+    // ---------------------------------------------------------------- nodes
+    struct ConvSpec { int Cin, Cout, stride, pad_t, pad_l, ups; };
+
+    void build();
+    void node_time_embed();
+    void node_conv_in(const View& y);
+    void node_resnet(const std::string& pre, const View& x, const View& y, int toff, float scale);
+    void node_attention(const std::string& pre, const View& x, const View& y, float scale);
+    void node_downsample(const std::string& pre, const View& x, const View& y);
+    void node_upsample(const std::string& pre, const View& x, const View& y);
+    void node_conv_out(const View& x);
+    void layout(int B, int training);
+};
+
+// ----------------------------------------------------------------------------------------------------
+void bd_unet::node_time_embed() {
+    const int c0 = cfg.block_out_channels[0];
+    const int64_t pw1 = add_param("time_embedding.linear_1.weight", {T, c0});
+    const int64_t pb1 = add_param("time_embedding.linear_1.bias", {T});
+    const int64_t pw2 = add_param("time_embedding.linear_2.weight", {T, T});
+    const int64_t pb2 = add_param("time_embedding.linear_2.bias", {T});
+    // batched time_emb_proj of every resnet: one [sumC, T] weight, one [sumC] bias (aliases registered per resnet)
+    nparams = (nparams + 3) / 4 * 4;
+    p_tw = nparams; nparams += (int64_t)sumC * T;
+    p_tb = nparams; nparams += sumC;
+    segs[cur_seg].hi = nparams;
+    const int b_tsin = new_buf(c0, 0, R_VALUE), b_e1 = new_buf(T, 0, R_VALUE), b_e1s = new_buf(T, 0, R_VALUE);
+    const int b_emb = new_buf(T, 0, R_VALUE);
+    b_embs = new_buf(T, 0, R_VALUE);
+    b_tproj = new_buf(sumC, 0, R_VALUE);
+    b_dtproj = new_buf(sumC, 0, R_GRAD);
+    const int b_dembs = scratch(T), b_demb = scratch(T), b_de1s = scratch(T), b_de1 = scratch(T);
+    F([=](Ctx& c) {
+        if (!c.dry)
+            BD_TRY(bd_timestep_embedding(c.t, c.t_stride, c.B, c0, cfg.flip_sin_to_cos, cfg.freq_shift, BP(c, b_tsin), (bd_stream_t)c.st));
+        BD_TRY(linear_fwd(c, BP(c, b_tsin), c0, c.params + pw1, c.params + pb1, BP(c, b_e1), T, c.B, T, c0));
+        if (!c.dry) BD_TRY(bd_silu_fwd(BP(c, b_e1), BP(c, b_e1s), (int64_t)c.B * T, (bd_stream_t)c.st));
+        BD_TRY(linear_fwd(c, BP(c, b_e1s), T, c.params + pw2, c.params + pb2, BP(c, b_emb), T, c.B, T, T));
+        if (!c.dry) BD_TRY(bd_silu_fwd(BP(c, b_emb), BP(c, b_embs), (int64_t)c.B * T, (bd_stream_t)c.st));
+        BD_TRY(linear_fwd(c, BP(c, b_embs), T, c.params + p_tw, c.params + p_tb, BP(c, b_tproj), sumC, c.B, sumC, T));
+        return (int)BD_OK;
+    });
+    Bk([=](Ctx& c) {
+        float* dtp = BP(c, b_dtproj);
+        BD_TRY(linear_wgrad(c, dtp, sumC, BP(c, b_embs), T, c.grads + p_tw, c.B, sumC, T));
+        BD_TRY(colsum(c, dtp, sumC, c.B, sumC, c.B, c.grads + p_tb, sumC));
+        BD_TRY(linear_dgrad(c, dtp, sumC, c.params + p_tw, BP(c, b_dembs), T, c.B, sumC, T, 0));
+        if (!c.dry) BD_TRY(bd_silu_bwd(BP(c, b_emb), BP(c, b_dembs), BP(c, b_demb), (int64_t)c.B * T, 0, (bd_stream_t)c.st));
+        BD_TRY(linear_wgrad(c, BP(c, b_demb), T, BP(c, b_e1s), T, c.grads + pw2, c.B, T, T));
+        BD_TRY(colsum(c, BP(c, b_demb), T, c.B, T, c.B, c.grads + pb2, T));
+        BD_TRY(linear_dgrad(c, BP(c, b_demb), T, c.params + pw2, BP(c, b_de1s), T, c.B, T, T, 0));
+        if (!c.dry) BD_TRY(bd_silu_bwd(BP(c, b_e1), BP(c, b_de1s), BP(c, b_de1), (int64_t)c.B * T, 0, (bd_stream_t)c.st));
+        BD_TRY(linear_wgrad(c, BP(c, b_de1), T, BP(c, b_tsin), c0, c.grads + pw1, c.B, T, c0));
+        BD_TRY(colsum(c, BP(c, b_de1), T, c.B, T, c.B, c.grads + pb1, T));
+        return (int)BD_OK;
+    });
+}
+
+void bd_unet::node_conv_in(const View& y) {
+    const int Cin = cfg.in_channels, Cout = y.C, S_ = cfg.sample_size;
+    const int64_t pw = add_param("conv_in.weight", {Cout, Cin, 3, 3}, 1);
+    const int64_t pb = add_param("conv_in.bias", {Cout});
+    const int b_bs = scratch(Cout);
+    F([=](Ctx& c) {
+        bd_conv3x3_fwd_desc d = {};
+        d.B = c.B; d.Hs = S_; d.Ws = S_; d.Cin = Cin; d.Cout = Cout; d.stride = 1; d.pad_t = 1; d.pad_l = 1; d.Ho = S_; d.Wo = S_;
+        d.x = c.x; d.ldx = c.ldx; d.w = c.params + pw; d.bias = c.params + pb; d.out_scale = 1.f;
+        d.y = VP(c, y); d.ldy = y.ld;
+        return conv_f(c, d);
+    });
+    Bk([=](Ctx& c) {
+        const float* dy = GP(c, y);
+        BD_TRY(bias_grad(c, dy, y.ld, S_ * S_, Cout, b_bs, c.grads + pb));
+        bd_conv3x3_wgrad_desc d = {};
+        d.B = c.B; d.Hs = S_; d.Ws = S_; d.Cin = Cin; d.Cout = Cout; d.stride = 1; d.pad_t = 1; d.pad_l = 1; d.Ho = S_; d.Wo = S_;
+        d.x = c.x; d.ldx = c.ldx; d.dy = dy; d.lddy = y.ld; d.dw = c.grads + pw;
+        return conv_w(c, d);
+    });
+}
+
+void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, int toff, float scale) {
+    const int Cin = x.C, Cout = y.C, H = x.H, W = x.W, HW = H * W;
+    const bool shortcut = Cin != Cout;
+    const int64_t pn1w = add_param(pre + "norm1.weight", {Cin}), pn1b = add_param(pre + "norm1.bias", {Cin});
+    const int64_t pc1w = add_param(pre + "conv1.weight", {Cout, Cin, 3, 3}, 1), pc1b = add_param(pre + "conv1.bias", {Cout});
+    alias_param(pre + "time_emb_proj.weight", p_tw + (int64_t)toff * T, {Cout, T});
+    alias_param(pre + "time_emb_proj.bias", p_tb + toff, {Cout});
+    const int64_t pn2w = add_param(pre + "norm2.weight", {Cout}), pn2b = add_param(pre + "norm2.bias", {Cout});
+    const int64_t pc2w = add_param(pre + "conv2.weight", {Cout, Cout, 3, 3}, 1), pc2b = add_param(pre + "conv2.bias", {Cout});
+    int64_t psw = -1, psb = -1;
+    if (shortcut) {
+        psw = add_param(pre + "conv_shortcut.weight", {Cout, Cin, 1, 1}, 1);
+        psb = add_param(pre + "conv_shortcut.bias", {Cout});
+    }
+    const int b_a1 = new_buf((int64_t)HW * Cin, 0, R_VALUE), b_h1 = new_buf((int64_t)HW * Cout, 0, R_VALUE);
+    const int b_a2 = new_buf((int64_t)HW * Cout, 0, R_VALUE);
+    const int G = cfg.norm_num_groups;
+    const int b_st1 = new_buf(2 * G, 0, R_VALUE), b_st2 = new_buf(2 * G, 0, R_VALUE);
+    View h1v; h1v.buf = b_h1; h1v.coff = 0; h1v.C = Cout; h1v.ld = Cout; h1v.H = H; h1v.W = W;
+    bufs[b_h1].gbuf = -1;
+    const int b_dys = scale != 1.f ? scratch((int64_t)HW * Cout) : -1;
+    const int b_bs = scratch(Cout), b_da2 = scratch((int64_t)HW * Cout), b_dh1 = scratch((int64_t)HW * Cout);
+    const int b_da1 = scratch((int64_t)HW * Cin);
+    const float inv = 1.f / scale;
+    const int sumC_ = sumC;
+
+    F([=](Ctx& c) {
+        BD_TRY(gn_fwd(c, x, pn1w, pn1b, BP(c, b_a1), Cin, b_st1, 1));
+        bd_conv3x3_fwd_desc d = {};
+        d.B = c.B; d.Hs = H; d.Ws = W; d.Cin = Cin; d.Cout = Cout; d.stride = 1; d.pad_t = 1; d.pad_l = 1; d.Ho = H; d.Wo = W;
+        d.x = BP(c, b_a1); d.ldx = Cin; d.w = c.params + pc1w; d.bias = c.params + pc1b;
+        d.rowbias = BP(c, b_tproj) + toff; d.ld_rowbias = sumC_; d.out_scale = 1.f;
+        d.y = BP(c, b_h1); d.ldy = Cout;
+        BD_TRY(conv_f(c, d));
+        BD_TRY(gn_fwd(c, h1v, pn2w, pn2b, BP(c, b_a2), Cout, b_st2, 1));
+        const float* res = VP(c, x); int64_t ldr = x.ld;
+        if (shortcut) {
+            BD_TRY(linear_fwd(c, VP(c, x), x.ld, c.params + psw, c.params + psb, VP(c, y), y.ld, (int)rows(c, x), Cout, Cin));
+            res = VP(c, y); ldr = y.ld;
+        }
+        bd_conv3x3_fwd_desc e = {};
+        e.B = c.B; e.Hs = H; e.Ws = W; e.Cin = Cout; e.Cout = Cout; e.stride = 1; e.pad_t = 1; e.pad_l = 1; e.Ho = H; e.Wo = W;
+        e.x = BP(c, b_a2); e.ldx = Cout; e.w = c.params + pc2w; e.bias = c.params + pc2b;
+        e.residual = res; e.ldr = ldr; e.out_scale = inv;
+        e.y = VP(c, y); e.ldy = y.ld;
+        return conv_f(c, e);
+    });
+    Bk([=](Ctx& c) {
+        const int M = (int)rows(c, x);
+        const float* dy = GP(c, y); int64_t lddy = y.ld;
+        if (b_dys >= 0) {
+            BD_TRY(add(c, dy, lddy, BP(c, b_dys), Cout, M, Cout, inv, 0));
+            dy = BP(c, b_dys); lddy = Cout;
+        }
+        BD_TRY(bias_grad(c, dy, lddy, HW, Cout, b_bs, c.grads + pc2b, shortcut ? c.grads + psb : nullptr));
+        bd_conv3x3_wgrad_desc w2 = {};
+        w2.B = c.B; w2.Hs = H; w2.Ws = W; w2.Cin = Cout; w2.Cout = Cout; w2.stride = 1; w2.pad_t = 1; w2.pad_l = 1; w2.Ho = H; w2.Wo = W;
+        w2.x = BP(c, b_a2); w2.ldx = Cout; w2.dy = dy; w2.lddy = lddy; w2.dw = c.grads + pc2w;
+        BD_TRY(conv_w(c, w2));
+        bd_conv3x3_dgrad_desc g2 = {};
+        g2.B = c.B; g2.Hs = H; g2.Ws = W; g2.Cin = Cout; g2.Cout = Cout; g2.stride = 1; g2.pad_t = 1; g2.pad_l = 1; g2.Ho = H; g2.Wo = W;
+        g2.dy = dy; g2.lddy = lddy; g2.w = c.params + pc2w; g2.dx = BP(c, b_da2); g2.lddx = Cout;
+        BD_TRY(conv_d(c, g2));
+        {   // norm2 backward: dh1 = gn_silu_bwd(h1, da2)   (h1 has no persistent grad buffer: write to scratch)
+            bd_gn_bwd_desc d = {};
+            d.B = c.B; d.HW = HW; d.C = Cout; d.G = G; d.silu = 1;
+            d.x = BP(c, b_h1); d.ldx = Cout; d.gamma = c.params + pn2w; d.beta = c.params + pn2b;
+            d.mean = BP(c, b_st2); d.rstd = d.mean + (int64_t)c.B * G;
+            d.dy = BP(c, b_da2); d.lddy = Cout; d.dx = BP(c, b_dh1); d.lddx = Cout; d.accumulate_dx = 0;
+            d.dgamma = c.grads + pn2w; d.dbeta = c.grads + pn2b;
+            d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+            if (!c.dry) BD_TRY(bd_gn_bwd(&d, (bd_stream_t)c.st));
+        }
+        // time-embedding gradient (per-sample column sums of dh1) and conv1 bias gradient
+        float* dtp = BP(c, b_dtproj) + toff;
+        BD_TRY(colsum(c, BP(c, b_dh1), Cout, M, Cout, HW, dtp, sumC_));
+        BD_TRY(colsum(c, dtp, sumC_, c.B, Cout, c.B, c.grads + pc1b, Cout));
+        bd_conv3x3_wgrad_desc w1 = {};
+        w1.B = c.B; w1.Hs = H; w1.Ws = W; w1.Cin = Cin; w1.Cout = Cout; w1.stride = 1; w1.pad_t = 1; w1.pad_l = 1; w1.Ho = H; w1.Wo = W;
+        w1.x = BP(c, b_a1); w1.ldx = Cin; w1.dy = BP(c, b_dh1); w1.lddy = Cout; w1.dw = c.grads + pc1w;
+        BD_TRY(conv_w(c, w1));
+        bd_conv3x3_dgrad_desc g1 = {};
+        g1.B = c.B; g1.Hs = H; g1.Ws = W; g1.Cin = Cin; g1.Cout = Cout; g1.stride = 1; g1.pad_t = 1; g1.pad_l = 1; g1.Ho = H; g1.Wo = W;
+        g1.dy = BP(c, b_dh1); g1.lddy = Cout; g1.w = c.params + pc1w; g1.dx = BP(c, b_da1); g1.lddx = Cin;
+        BD_TRY(conv_d(c, g1));
+        BD_TRY(gn_bwd(c, x, pn1w, pn1b, b_st1, BP(c, b_da1), Cin, 1));
+        // residual path
+        if (shortcut) {
+            BD_TRY(linear_wgrad(c, dy, lddy, VP(c, x), x.ld, c.grads + psw, M, Cout, Cin));
+            BD_TRY(linear_dgrad(c, dy, lddy, c.params + psw, GP(c, x), x.ld, M, Cout, Cin, 1));
+        } else {
+            BD_TRY(add(c, dy, lddy, GP(c, x), x.ld, M, Cout, 1.f, 1));
+        }
+        return (int)BD_OK;
+    });
+}
+
+void bd_unet::node_attention(const std::string& pre, const View& x, const View& y, float scale) {
+    const int C = x.C, H = x.H, W = x.W, N = H * W;
+    const int heads = cfg.attention_head_dim > 0 ? C / cfg.attention_head_dim : 1;
+    const int dh = C / heads;
+    const float sm_scale = 1.0f / std::sqrt((float)C / (float)heads);
+    const int64_t pgw = add_param(pre + "group_norm.weight", {C}), pgb = add_param(pre + "group_norm.bias", {C});
+    const int64_t pqw = add_param(pre + "query.weight", {C, C});
+    add_param(pre + "key.weight", {C, C});
+    add_param(pre + "value.weight", {C, C});
+    const int64_t pqb = add_param(pre + "query.bias", {C});
+    add_param(pre + "key.bias", {C});
+    add_param(pre + "value.bias", {C});
+    const int64_t ppw = add_param(pre + "proj_attn.weight", {C, C}), ppb = add_param(pre + "proj_attn.bias", {C});
+    const int G = cfg.norm_num_groups;
+    const int b_n = new_buf((int64_t)N * C, 0, R_VALUE), b_qkv = new_buf((int64_t)N * 3 * C, 0, R_VALUE);
+    const int b_p = new_buf((int64_t)heads * N * N, 0, R_VALUE), b_o = new_buf((int64_t)N * C, 0, R_VALUE);
+    const int b_st = new_buf(2 * G, 0, R_VALUE);
+    const int b_dys = scale != 1.f ? scratch((int64_t)N * C) : -1;
+    const int b_bs = scratch(3 * C), b_do = scratch((int64_t)N * C), b_dp = scratch((int64_t)heads * N * N);
+    const int b_dqkv = scratch((int64_t)N * 3 * C), b_dn = scratch((int64_t)N * C);
+    const float inv = 1.f / scale;
+
+    auto batched = [=](bd_igemm_desc& g, int B) {
+        g.batch_outer = B; g.batch_inner = heads;
+    };
+    F([=](Ctx& c) {
+        const int M = (int)rows(c, x);
+        BD_TRY(gn_fwd(c, x, pgw, pgb, BP(c, b_n), C, b_st, 0));
+        BD_TRY(linear_fwd(c, BP(c, b_n), C, c.params + pqw, c.params + pqb, BP(c, b_qkv), 3 * C, M, 3 * C, C));
+        float* qkv = BP(c, b_qkv);
+        {   // S = scale * Q K^T
+            bd_igemm_desc g = {};
+            g.A = dense(qkv, 3 * C, 1); g.A.bs_outer = (int64_t)N * 3 * C; g.A.bs_inner = dh;
+            g.B = dense(qkv + C, 3 * C, 1); g.B.bs_outer = (int64_t)N * 3 * C; g.B.bs_inner = dh;
+            g.M = N; g.N = N; g.K = dh; batched(g, c.B);
+            g.C = BP(c, b_p); g.ldc = N; g.c_bs_outer = (int64_t)heads * N * N; g.c_bs_inner = (int64_t)N * N;
+            g.alpha = sm_scale; g.out_scale = 1.f;
+            BD_TRY(igemm(c, g));
+        }
+        if (!c.dry) BD_TRY(bd_softmax_fwd(BP(c, b_p), BP(c, b_p), (int64_t)c.B * heads * N, N, (bd_stream_t)c.st));
+        {   // O = P V
+            bd_igemm_desc g = {};
+            g.A = dense(BP(c, b_p), N, 1); g.A.bs_outer = (int64_t)heads * N * N; g.A.bs_inner = (int64_t)N * N;
+            g.B = dense(qkv + 2 * C, 3 * C, 0); g.B.bs_outer = (int64_t)N * 3 * C; g.B.bs_inner = dh;
+            g.M = N; g.N = dh; g.K = N; batched(g, c.B);
+            g.C = BP(c, b_o); g.ldc = C; g.c_bs_outer = (int64_t)N * C; g.c_bs_inner = dh;
+            g.alpha = 1.f; g.out_scale = 1.f;
+            BD_TRY(igemm(c, g));
+        }
+        return linear_fwd(c, BP(c, b_o), C, c.params + ppw, c.params + ppb, VP(c, y), y.ld, M, C, C, VP(c, x), x.ld, inv);
+    });
+    Bk([=](Ctx& c) {
+        const int M = (int)rows(c, x);
+        const float* dy = GP(c, y); int64_t lddy = y.ld;
+        if (b_dys >= 0) {
+            BD_TRY(add(c, dy, lddy, BP(c, b_dys), C, M, C, inv, 0));
+            dy = BP(c, b_dys); lddy = C;
+        }
+        float* qkv = BP(c, b_qkv); float* dqkv = BP(c, b_dqkv); float* P = BP(c, b_p); float* dP = BP(c, b_dp);
+        float* dO = BP(c, b_do);
+        BD_TRY(bias_grad(c, dy, lddy, N, C, b_bs, c.grads + ppb));
+        BD_TRY(linear_wgrad(c, dy, lddy, BP(c, b_o), C, c.grads + ppw, M, C, C));
+        BD_TRY(linear_dgrad(c, dy, lddy, c.params + ppw, dO, C, M, C, C, 0));
+        {   // dP = dO V^T
+            bd_igemm_desc g = {};
+            g.A = dense(dO, C, 1); g.A.bs_outer = (int64_t)N * C; g.A.bs_inner = dh;
+            g.B = dense(qkv + 2 * C, 3 * C, 1); g.B.bs_outer = (int64_t)N * 3 * C; g.B.bs_inner = dh;
+            g.M = N; g.N = N; g.K = dh; batched(g, c.B);
+            g.C = dP; g.ldc = N; g.c_bs_outer = (int64_t)heads * N * N; g.c_bs_inner = (int64_t)N * N;
+            g.alpha = 1.f; g.out_scale = 1.f;
+            BD_TRY(igemm(c, g));
+        }
+        {   // dV = P^T dO
+            bd_igemm_desc g = {};
+            g.A = dense(P, N, 0); g.A.bs_outer = (int64_t)heads * N * N; g.A.bs_inner = (int64_t)N * N;
+            g.B = dense(dO, C, 0); g.B.bs_outer = (int64_t)N * C; g.B.bs_inner = dh;
+            g.M = N; g.N = dh; g.K = N; batched(g, c.B);
+            g.C = dqkv + 2 * C; g.ldc = 3 * C; g.c_bs_outer = (int64_t)N * 3 * C; g.c_bs_inner = dh;
+            g.alpha = 1.f; g.out_scale = 1.f;
+            BD_TRY(igemm(c, g));
+        }
+        if (!c.dry) BD_TRY(bd_softmax_bwd(P, dP, dP, (int64_t)c.B * heads * N, N, (bd_stream_t)c.st));
+        {   // dQ = scale * dS K
+            bd_igemm_desc g = {};
+            g.A = dense(dP, N, 1); g.A.bs_outer = (int64_t)heads * N * N; g.A.bs_inner = (int64_t)N * N;
+            g.B = dense(qkv + C, 3 * C, 0); g.B.bs_outer = (int64_t)N * 3 * C; g.B.bs_inner = dh;
+            g.M = N; g.N = dh; g.K = N; batched(g, c.B);
+            g.C = dqkv; g.ldc = 3 * C; g.c_bs_outer = (int64_t)N * 3 * C; g.c_bs_inner = dh;
+            g.alpha = sm_scale; g.out_scale = 1.f;
+            BD_TRY(igemm(c, g));
+        }
+        {   // dK = scale * dS^T Q
+            bd_igemm_desc g = {};
+            g.A = dense(dP, N, 0); g.A.bs_outer = (int64_t)heads * N * N; g.A.bs_inner = (int64_t)N * N;
+            g.B = dense(qkv, 3 * C, 0); g.B.bs_outer = (int64_t)N * 3 * C; g.B.bs_inner = dh;
+            g.M = N; g.N = dh; g.K = N; batched(g, c.B);
+            g.C = dqkv + C; g.ldc = 3 * C; g.c_bs_outer = (int64_t)N * 3 * C; g.c_bs_inner = dh;
+            g.alpha = sm_scale; g.out_scale = 1.f;
+            BD_TRY(igemm(c, g));
+        }
+        BD_TRY(bias_grad(c, dqkv, 3 * C, N, 3 * C, b_bs, c.grads + pqb));
+        BD_TRY(linear_wgrad(c, dqkv, 3 * C, BP(c, b_n), C, c.grads + pqw, M, 3 * C, C));
+        BD_TRY(linear_dgrad(c, dqkv, 3 * C, c.params + pqw, BP(c, b_dn), C, M, 3 * C, C, 0));
+        BD_TRY(gn_bwd(c, x, pgw, pgb, b_st, BP(c, b_dn), C, 0));
+        return add(c, dy, lddy, GP(c, x), x.ld, M, C, 1.f, 1);
+    });
+}
+
+void bd_unet::node_downsample(const std::string& pre, const View& x, const View& y) {
+    const int C = x.C, H = x.H, W = x.W, Ho = y.H, Wo = y.W;
+    const int pad = cfg.downsample_padding ? 1 : 0;
+    const int64_t pw = add_param(pre + "conv.weight", {C, C, 3, 3}, 1), pb = add_param(pre + "conv.bias", {C});
+    const int b_bs = scratch(C);
+    F([=](Ctx& c) {
+        bd_conv3x3_fwd_desc d = {};
+        d.B = c.B; d.Hs = H; d.Ws = W; d.Cin = C; d.Cout = C; d.stride = 2; d.pad_t = pad; d.pad_l = pad; d.Ho = Ho; d.Wo = Wo;
+        d.x = VP(c, x); d.ldx = x.ld; d.w = c.params + pw; d.bias = c.params + pb; d.out_scale = 1.f;
+        d.y = VP(c, y); d.ldy = y.ld;
+        return conv_f(c, d);
+    });
+    Bk([=](Ctx& c) {
+        const float* dy = GP(c, y);
+        BD_TRY(bias_grad(c, dy, y.ld, Ho * Wo, C, b_bs, c.grads + pb));
+        bd_conv3x3_wgrad_desc w = {};
+        w.B = c.B; w.Hs = H; w.Ws = W; w.Cin = C; w.Cout = C; w.stride = 2; w.pad_t = pad; w.pad_l = pad; w.Ho = Ho; w.Wo = Wo;
+        w.x = VP(c, x); w.ldx = x.ld; w.dy = dy; w.lddy = y.ld; w.dw = c.grads + pw;
+        BD_TRY(conv_w(c, w));
+        bd_conv3x3_dgrad_desc g = {};
+        g.B = c.B; g.Hs = H; g.Ws = W; g.Cin = C; g.Cout = C; g.stride = 2; g.pad_t = pad; g.pad_l = pad; g.Ho = Ho; g.Wo = Wo;
+        g.dy = dy; g.lddy = y.ld; g.w = c.params + pw; g.dx = GP(c, x); g.lddx = x.ld; g.accumulate = c.ginit[x.buf];
+        c.ginit[x.buf] = 1;
+        return conv_d(c, g);
+    });
+}
+
+void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y) {
+    const int C = x.C, H = x.H, W = x.W;
+    const int64_t pw = add_param(pre + "conv.weight", {C, C, 3, 3}, 1), pb = add_param(pre + "conv.bias", {C});
+    const int b_bs = scratch(C), b_du = scratch((int64_t)4 * H * W * C);
+    F([=](Ctx& c) {
+        bd_conv3x3_fwd_desc d = {};
+        d.B = c.B; d.Hs = H; d.Ws = W; d.Cin = C; d.Cout = C; d.stride = 1; d.pad_t = 1; d.pad_l = 1; d.ups = 1; d.Ho = 2 * H; d.Wo = 2 * W;
+        d.x = VP(c, x); d.ldx = x.ld; d.w = c.params + pw; d.bias = c.params + pb; d.out_scale = 1.f;
+        d.y = VP(c, y); d.ldy = y.ld;
+        return conv_f(c, d);
+    });
+    Bk([=](Ctx& c) {
+        const float* dy = GP(c, y);
+        BD_TRY(bias_grad(c, dy, y.ld, 4 * H * W, C, b_bs, c.grads + pb));
+        bd_conv3x3_wgrad_desc w = {};
+        w.B = c.B; w.Hs = H; w.Ws = W; w.Cin = C; w.Cout = C; w.stride = 1; w.pad_t = 1; w.pad_l = 1; w.ups = 1; w.Ho = 2 * H; w.Wo = 2 * W;
+        w.x = VP(c, x); w.ldx = x.ld; w.dy = dy; w.lddy = y.ld; w.dw = c.grads + pw;
+        BD_TRY(conv_w(c, w));
+        bd_conv3x3_dgrad_desc g = {};
+        g.B = c.B; g.Hs = H; g.Ws = W; g.Cin = C; g.Cout = C; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.ups = 1; g.Ho = 2 * H; g.Wo = 2 * W;
+        g.dy = dy; g.lddy = y.ld; g.w = c.params + pw; g.dx = BP(c, b_du); g.lddx = C;
+        BD_TRY(conv_d(c, g));
+        const int acc = c.ginit[x.buf];
+        c.ginit[x.buf] = 1;
+        if (c.dry) return (int)BD_OK;
+        return bd_sum2x2(BP(c, b_du), C, GP(c, x), x.ld, c.B, H, W, C, acc, (bd_stream_t)c.st);
+    });
+}
+
+void bd_unet::node_conv_out(const View& x) {
+    const int C = x.C, H = x.H, W = x.W, Co = cfg.out_channels;
+    const int64_t pnw = add_param("conv_norm_out.weight", {C}), pnb = add_param("conv_norm_out.bias", {C});
+    const int64_t pw = add_param("conv_out.weight", {Co, C, 3, 3}, 1), pb = add_param("conv_out.bias", {Co});
+    const int G = cfg.norm_num_groups;
+    const int b_a = new_buf((int64_t)H * W * C, 0, R_VALUE), b_st = new_buf(2 * G, 0, R_VALUE);
+    const int b_bs = scratch(Co), b_da = scratch((int64_t)H * W * C);
+    F([=](Ctx& c) {
+        BD_TRY(gn_fwd(c, x, pnw, pnb, BP(c, b_a), C, b_st, 1));
+        bd_conv3x3_fwd_desc d = {};
+        d.B = c.B; d.Hs = H; d.Ws = W; d.Cin = C; d.Cout = Co; d.stride = 1; d.pad_t = 1; d.pad_l = 1; d.Ho = H; d.Wo = W;
+        d.x = BP(c, b_a); d.ldx = C; d.w = c.params + pw; d.bias = c.params + pb; d.out_scale = 1.f;
+        d.y = c.out; d.ldy = c.ldo;
+        return conv_f(c, d);
+    });
+    Bk([=](Ctx& c) {
+        BD_TRY(bias_grad(c, c.dout, c.lddo, H * W, Co, b_bs, c.grads + pb));
+        bd_conv3x3_wgrad_desc w = {};
+        w.B = c.B; w.Hs = H; w.Ws = W; w.Cin = C; w.Cout = Co; w.stride = 1; w.pad_t = 1; w.pad_l = 1; w.Ho = H; w.Wo = W;
+        w.x = BP(c, b_a); w.ldx = C; w.dy = c.dout; w.lddy = c.lddo; w.dw = c.grads + pw;
+        BD_TRY(conv_w(c, w));
+        bd_conv3x3_dgrad_desc g = {};
+        g.B = c.B; g.Hs = H; g.Ws = W; g.Cin = C; g.Cout = Co; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.Ho = H; g.Wo = W;
+        g.dy = c.dout; g.lddy = c.lddo; g.w = c.params + pw; g.dx = BP(c, b_da); g.lddx = C;
+        BD_TRY(conv_d(c, g));
+        return gn_bwd(c, x, pnw, pnb, b_st, BP(c, b_da), C, 1);
+    });
+}
+
+// ----------------------------------------------------------------------------------------------------
+void bd_unet::build() {
+    const int n = cfg.num_blocks, L = cfg.layers_per_block, S0 = cfg.sample_size;
+    const int* boc = cfg.block_out_channels;
+    T = 4 * boc[0];
+    // ---- pass 1: architecture enumeration -----------------------------------------------------------
+    // skips (down path outputs, in push order) and up resnets (pop order)
+    struct Skip { int C, H; };
+    std::vector<Skip> skips;
+    skips.push_back({boc[0], S0});
+    {
+        int res = S0;
+        for (int i = 0; i < n; ++i) {
+            for (int j = 0; j < L; ++j) skips.push_back({boc[i], res});
+            if (i != n - 1) { res /= 2; skips.push_back({boc[i], res}); }
+        }
+    }
+    struct UpRes { int C1, C2, Cout, H; };
+    std::vector<std::vector<UpRes>> ups(n);
+    {
+        int sk = (int)skips.size();
+        int res = S0 >> (n - 1);
+        for (int i = 0; i < n; ++i) {
+            const int out = boc[n - 1 - i];
+            const int prev = i == 0 ? boc[n - 1] : boc[n - i];
+            for (int j = 0; j <= L; ++j) {
+                const Skip& s = skips[--sk];
+                ups[i].push_back({j == 0 ? prev : out, s.C, out, res});
+            }
+            if (i != n - 1) res *= 2;
+        }
+    }
+    // total time_emb_proj rows, in forward order: down resnets, mid x2, up resnets
+    sumC = 0;
+    for (int i = 0; i < n; ++i) sumC += L * boc[i];
+    sumC += 2 * boc[n - 1];
+    for (int i = 0; i < n; ++i) for (auto& u : ups[i]) sumC += u.Cout;
+
+    // segments in BACKWARD order: 0 = out, 1..n = up blocks n-1..0, n+1 = mid, n+2..2n+1 = down n-1..0, 2n+2 = conv_in, 2n+3 = time
+    const int nseg = 2 * n + 4;
+    segs.assign(nseg, Seg{-1, -1});
+    auto seg_out = 0;
+    auto seg_up = [&](int i) { return 1 + (n - 1 - i); };
+    const int seg_mid = n + 1;
+    auto seg_down = [&](int i) { return n + 2 + (n - 1 - i); };
+    const int seg_in = 2 * n + 2, seg_time = 2 * n + 3;
+
+    // concat buffers, one per up resnet
+    std::vector<std::vector<View>> cat(n);
+    for (int i = 0; i < n; ++i)
+        for (auto& u : ups[i]) {
+            View v = new_tensor(u.H, u.H, u.C1 + u.C2);
+            cat[i].push_back(v);
+        }
+    // skip k lives in the concat buffer of the up resnet that pops it
+    std::vector<View> skipv(skips.size());
+    {
+        int sk = (int)skips.size();
+        for (int i = 0; i < n; ++i)
+            for (size_t j = 0; j < ups[i].size(); ++j) {
+                --sk;
+                skipv[sk] = slice(cat[i][j], ups[i][j].C1, ups[i][j].C2);
+            }
+    }
+
+    // ---- pass 2: nodes in forward order ---------------------------------------------------------------
+    cur_group = 0;
+    cur_seg = seg_time; segs[seg_time].lo = 0;
+    node_time_embed();
+    int toff = 0, group = 1;
+    cur_seg = seg_in; cur_group = group++;
+    node_conv_in(skipv[0]);
+    int sk = 1;
+    View h = skipv[0];
+    int res = S0;
+    for (int i = 0; i < n; ++i) {
+        cur_seg = seg_down(i);
+        const std::string bp = "down_blocks." + std::to_string(i) + ".";
+        for (int j = 0; j < L; ++j) {
+            cur_group = group++;
+            View dst = skipv[sk];
+            if (cfg.down_attn[i]) {
+                View mid = new_tensor(res, res, boc[i]);
+                node_resnet(bp + "resnets." + std::to_string(j) + ".", h, mid, toff, 1.f);
+                cur_group = group++;
+                node_attention(bp + "attentions." + std::to_string(j) + ".", mid, dst, 1.f);
+            } else {
+                node_resnet(bp + "resnets." + std::to_string(j) + ".", h, dst, toff, 1.f);
+            }
+            toff += boc[i];
+            h = dst; ++sk;
+        }
+        if (i != n - 1) {
+            cur_group = group++;
+            View dst = skipv[sk];
+            node_downsample(bp + "downsamplers.0.", h, dst);
+            h = dst; ++sk; res /= 2;
+        }
+    }
+    {   // mid block
+        cur_seg = seg_mid;
+        const int C = boc[n - 1];
+        const float s = cfg.mid_block_scale_factor;
+        View m1 = new_tensor(res, res, C), m2 = new_tensor(res, res, C);
+        View dst = slice(cat[0][0], 0, ups[0][0].C1);
+        cur_group = group++;
+        node_resnet("mid_block.resnets.0.", h, m1, toff, s); toff += C;
+        cur_group = group++;
+        node_attention("mid_block.attentions.0.", m1, m2, s);
+        cur_group = group++;
+        node_resnet("mid_block.resnets.1.", m2, dst, toff, s); toff += C;
+    }
+    View last;
+    for (int i = 0; i < n; ++i) {
+        cur_seg = seg_up(i);
+        const std::string bp = "up_blocks." + std::to_string(i) + ".";
+        const int nl = (int)ups[i].size();
+        for (int j = 0; j < nl; ++j) {
+            const UpRes& u = ups[i][j];
+            // destination of this layer's output: next concat's h-slice, or a standalone tensor before upsample / out
+            View dst;
+            const bool last_layer = j == nl - 1;
+            if (!last_layer) dst = slice(cat[i][j + 1], 0, ups[i][j + 1].C1);
+            else dst = new_tensor(u.H, u.H, u.Cout);
+            cur_group = group++;
+            if (cfg.up_attn[i]) {
+                View mid = new_tensor(u.H, u.H, u.Cout);
+                node_resnet(bp + "resnets." + std::to_string(j) + ".", cat[i][j], mid, toff, 1.f);
+                cur_group = group++;
+                node_attention(bp + "attentions." + std::to_string(j) + ".", mid, dst, 1.f);
+            } else {
+                node_resnet(bp + "resnets." + std::to_string(j) + ".", cat[i][j], dst, toff, 1.f);
+            }
+            toff += u.Cout;
+            last = dst;
+        }
+        if (i != n - 1) {
+            cur_group = group++;
+            View dst = slice(cat[i + 1][0], 0, ups[i + 1][0].C1);
+            node_upsample(bp + "upsamplers.0.", last, dst);
+        }
+    }
+    cur_seg = seg_out; cur_group = group++;
+    node_conv_out(last);
+    (void)seg_out;
+    nparams = (nparams + 3) / 4 * 4;
+}
+
+void bd_unet::layout(int B, int training) {
+    if (lay_B == B && lay_train == training) return;
+    auto al = [](int64_t x) { return (x + 63) / 64 * 64; };
+    int64_t v = 0, g = 0;
+    for (auto& b : bufs) if (b.region == R_VALUE) { b.off = v; v += al(b.per_sample * B + b.fixed); }
+    value_floats = v;
+    for (auto& b : bufs) if (b.region == R_GRAD) { b.off = v + g; g += al(b.per_sample * B + b.fixed); }
+    grad_floats = training ? g : 0;
+    const int64_t base = value_floats + grad_floats;
+    int64_t smax = 0;
+    {
+        int cur = -1; int64_t s = 0;
+        for (auto& b : bufs) if (b.region == R_SCRATCH) {
+            if (b.group != cur) { cur = b.group; s = 0; }
+            b.off = base + s; s += al(b.per_sample * B + b.fixed);
+            if (s > smax) smax = s;
+        }
+    }
+    scratch_floats = training ? smax : 0;
+    // op workspace: dry-run every step
+    Ctx c;
+    c.dry = true; c.B = B; c.ws = nullptr; c.ginit.assign(bufs.size(), 0);
+    c.opws_bytes = (size_t)1 << 62;
+    for (auto& f : fwd) f(c);
+    if (training) for (auto it = bwd.rbegin(); it != bwd.rend(); ++it) it->fn(c);
+    opws_bytes = align_up(c.opws_need, 256);
+    lay_B = B; lay_train = training;
+}
+
+// ----------------------------------------------------------------------------------------------------
+extern "C" int bd_unet_create(const bd_unet_config* cfg, bd_unet** out) {
+    BD_CHECK(cfg && out, BD_ERR_INVALID, "bd_unet_create: null argument");
+    const int n = cfg->num_blocks;
+    BD_CHECK(n >= 1 && n <= 8, BD_ERR_INVALID, "bd_unet_create: num_blocks %d out of range", n);
+    BD_CHECK(cfg->layers_per_block >= 1, BD_ERR_INVALID, "bd_unet_create: layers_per_block");
+    BD_CHECK(cfg->sample_size > 0 && (cfg->sample_size % (1 << (n - 1))) == 0, BD_ERR_INVALID,
+             "bd_unet_create: sample_size %d not divisible by 2^%d", cfg->sample_size, n - 1);
+    BD_CHECK(cfg->in_channels > 0 && cfg->out_channels > 0, BD_ERR_INVALID, "bd_unet_create: channels");
+    BD_CHECK(cfg->norm_num_groups > 0, BD_ERR_INVALID, "bd_unet_create: norm_num_groups");
+    for (int i = 0; i < n; ++i) {
+        const int C = cfg->block_out_channels[i];
+        BD_CHECK(C > 0 && C % cfg->norm_num_groups == 0 && C % 4 == 0, BD_ERR_UNSUPPORTED,
+                 "bd_unet_create: block_out_channels[%d]=%d must be a multiple of norm_num_groups and of 4", i, C);
+        if (cfg->attention_head_dim > 0 && (cfg->down_attn[i] || cfg->up_attn[n - 1 - i]))
+            BD_CHECK(C % cfg->attention_head_dim == 0 && cfg->attention_head_dim % 4 == 0, BD_ERR_UNSUPPORTED,
+                     "bd_unet_create: attention_head_dim %d must divide %d and be a multiple of 4", cfg->attention_head_dim, C);
+    }
+    BD_CHECK(cfg->mid_block_scale_factor != 0.f, BD_ERR_INVALID, "bd_unet_create: mid_block_scale_factor == 0");
+    bd_unet* u = new (std::nothrow) bd_unet();
+    BD_CHECK(u, BD_ERR_INVALID, "bd_unet_create: out of host memory");
+    u->cfg = *cfg;
+    u->build();
+    *out = u;
+    return BD_OK;
+}
+extern "C" void bd_unet_destroy(bd_unet* u) { delete u; }
+extern "C" int64_t bd_unet_num_params(const bd_unet* u) { return u ? u->nparams : 0; }
+extern "C" int bd_unet_num_tensors(const bd_unet* u) { return u ? (int)u->params.size() : 0; }
+extern "C" int bd_unet_param_info(const bd_unet* u, int i, const char** name, int64_t* offset, int* rank, int64_t shape[4],
+                                  int* layout) {
+    BD_CHECK(u && i >= 0 && i < (int)u->params.size(), BD_ERR_INVALID, "bd_unet_param_info: index out of range");
+    const Param& p = u->params[i];
+    if (name) *name = p.name.c_str();
+    if (offset) *offset = p.off;
+    if (rank) *rank = p.rank;
+    if (shape) for (int k = 0; k < 4; ++k) shape[k] = p.shape[k];
+    if (layout) *layout = p.layout;
+    return BD_OK;
+}
+extern "C" size_t bd_unet_workspace_bytes(bd_unet* u, int B, int training) {
+    if (!u || B <= 0) return 0;
+    u->layout(B, training);
+    return (size_t)(u->value_floats + u->grad_floats + u->scratch_floats) * sizeof(float) + u->opws_bytes + 256;
+}
+
+static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, size_t workspace_bytes) {
+    BD_CHECK(u, BD_ERR_INVALID, "bd_unet: null plan");
+    BD_CHECK(B > 0, BD_ERR_INVALID, "bd_unet: B must be > 0");
+    const size_t need = bd_unet_workspace_bytes(u, B, training);
+    BD_CHECK(workspace && workspace_bytes >= need, BD_ERR_WORKSPACE, "bd_unet: workspace %zu < %zu bytes", workspace_bytes, need);
+    BD_CHECK(aligned16(workspace), BD_ERR_INVALID, "bd_unet: workspace must be 16-byte aligned");
+    c.B = B;
+    c.ws = reinterpret_cast<float*>(workspace);
+    const size_t fl = (size_t)(u->value_floats + u->grad_floats + u->scratch_floats) * sizeof(float);
+    c.opws = reinterpret_cast<char*>(workspace) + align_up(fl, 256);
+    c.opws_bytes = u->opws_bytes;
+    c.ginit.assign(u->bufs.size(), 0);
+    return BD_OK;
+}
+
+extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* params, const float* x, int64_t ldx,
+                               const int64_t* t, int t_stride, float* out, int64_t ldo, void* workspace, size_t workspace_bytes,
+                               bd_stream_t stream) {
+    Ctx c;
+    BD_TRY(unet_ctx(u, c, B, training, workspace, workspace_bytes));
+    BD_CHECK(params && x && t && out, BD_ERR_INVALID, "bd_unet_forward: null pointer");
+    BD_CHECK(ldx >= u->cfg.in_channels && ldo >= u->cfg.out_channels, BD_ERR_INVALID, "bd_unet_forward: ld < channels");
+    BD_CHECK(aligned16(params), BD_ERR_INVALID, "bd_unet_forward: params must be 16-byte aligned");
+    c.params = params; c.x = x; c.ldx = ldx; c.t = t; c.t_stride = t_stride; c.out = out; c.ldo = ldo; c.st = S(stream);
+    for (auto& f : u->fwd) BD_TRY(f(c));
+    return BD_OK;
+}
+
+extern "C" int bd_unet_num_segments(const bd_unet* u) { return u ? (int)u->segs.size() : 0; }
+
+extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float* params, const float* x, int64_t ldx,
+                                        const float* dout, int64_t lddo, float* grads, void* workspace, size_t workspace_bytes,
+                                        bd_stream_t stream, int64_t* ready_lo, int64_t* ready_hi) {
+    Ctx c;
+    BD_TRY(unet_ctx(u, c, B, 1, workspace, workspace_bytes));
+    BD_CHECK(params && x && dout && grads, BD_ERR_INVALID, "bd_unet_backward: null pointer");
+    BD_CHECK(aligned16(params) && aligned16(grads), BD_ERR_INVALID, "bd_unet_backward: params/grads must be 16-byte aligned");
+    BD_CHECK(seg >= -1 && seg < (int)u->segs.size(), BD_ERR_INVALID, "bd_unet_backward: segment %d out of range", seg);
+    c.params = params; c.grads = grads; c.dout = dout; c.lddo = lddo; c.st = S(stream);
+    c.x = x; c.ldx = ldx;   // conv_in wgrad re-reads the forward input
+    // grad-init flags must reflect everything executed before this segment: replay them (host-only)
+    for (auto it = u->bwd.rbegin(); it != u->bwd.rend(); ++it) {
+        if (seg >= 0 && it->seg > seg) break;
+        const bool run = seg < 0 || it->seg == seg;
+        const bool keep = c.dry;
+        c.dry = !run;           // earlier segments: flags only
+        int s = it->fn(c);
+        c.dry = keep;
+        if (s != BD_OK) return s;
+    }
+    if (seg >= 0) {
+        if (ready_lo) *ready_lo = u->segs[seg].lo;
+        if (ready_hi) *ready_hi = u->segs[seg].hi;
+    }
+    return BD_OK;
+}
+
+extern "C" int bd_unet_backward(bd_unet* u, int B, const float* params, const float* x, int64_t ldx, const float* dout,
+                                int64_t lddo, float* grads, void* workspace, size_t workspace_bytes, bd_stream_t stream) {
+    return bd_unet_backward_segment(u, -1, B, params, x, ldx, dout, lddo, grads, workspace, workspace_bytes, stream, nullptr,
+                                    nullptr);
+}

@@ -1,0 +1,359 @@
+"""Thin Python wrappers over the C ABI (include/bd_hip.h): torch tensors in, torch tensors out.
+
+Tensors are only carriers of device memory here (allocation, streams); every FLOP on the hot path
+happens in libbd_hip.so.  All wrappers enqueue on torch's current stream and never synchronise.
+Activations are NHWC: a [B,H,W,C] contiguous tensor, or any 2-D [rows, C] view with row stride `ld`.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+_ws_cache = {}
+
+
+def _need_cuda(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError("baddiffusion_amd.ops: tensors must live on the GPU (no CPU fallback on the hot path)")
+
+
+def workspace(nbytes, device, tag="default"):
+    """A cached scratch buffer of at least nbytes (per device / tag)."""
+    key = (str(device), tag)
+    buf = _ws_cache.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+        _ws_cache[key] = buf
+    return buf
+
+
+def _ld(t):
+    """leading dimension (elements between rows) of a [..., C] tensor whose last dim is contiguous."""
+    assert t.stride(-1) == 1
+    return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
+
+
+# ------------------------------------------------------------------------------------------------ a-1/a-2
+def poison_qsample(images, is_poison, trigger, target_img, noise, timesteps, alphas, alphas_cumprod,
+                   vmin=-1.0, want_batch=False, want_mask=False):
+    """Fused blend + q_sample.  images: float [B,C,H,W] (normalised) or uint8 [B,H,W,C].
+    Returns (x_noisy NHWC [B,H,W,C], target NHWC [B,H,W,C][, R NCHW, x0 NCHW][, mask int64 [C,H,W]])."""
+    lib = L.load()
+    _need_cuda(images, is_poison, trigger, target_img, noise, timesteps, alphas, alphas_cumprod)
+    u8 = images.dtype == torch.uint8
+    if u8:
+        B, H, W, Cc = images.shape
+    else:
+        B, Cc, H, W = images.shape
+    dev = images.device
+    images = images.contiguous(); noise = noise.contiguous()
+    is_poison = is_poison.to(torch.uint8).contiguous()
+    trigger = trigger.contiguous().float(); target_img = target_img.contiguous().float()
+    timesteps = timesteps.to(torch.int64).contiguous()
+    xn = torch.empty(B, H, W, Cc, device=dev); tg = torch.empty(B, H, W, Cc, device=dev)
+    R = torch.empty(B, Cc, H, W, device=dev) if want_batch else None
+    x0 = torch.empty(B, Cc, H, W, device=dev) if want_batch else None
+    mask = torch.empty(Cc, H, W, dtype=torch.int64, device=dev) if want_mask else None
+    d = L.PoisonQsampleDesc(B=B, C=Cc, H=H, W=W, images_f32=None if u8 else L.ptr(images),
+                            images_u8=L.ptr(images) if u8 else None, is_poison=L.ptr(is_poison),
+                            trigger=L.ptr(trigger), target_img=L.ptr(target_img), noise=L.ptr(noise),
+                            timesteps=L.ptr(timesteps), alphas=L.ptr(alphas), alphas_cumprod=L.ptr(alphas_cumprod),
+                            vmin=vmin, x_noisy=L.ptr(xn), ld_noisy=Cc, target=L.ptr(tg), ld_target=Cc,
+                            R_out=L.ptr(R), x0_out=L.ptr(x0), mask_out=L.ptr(mask))
+    L.check(lib.bd_poison_qsample(C.byref(d), L.stream()), "bd_poison_qsample")
+    out = [xn, tg]
+    if want_batch:
+        out += [R, x0]
+    if want_mask:
+        out += [mask]
+    return tuple(out)
+
+
+def qsample(x0, R, noise, timesteps, alphas, alphas_cumprod):
+    """loss.py:257-285 on NCHW inputs -> (x_noisy, target) NHWC [B,H,W,C]."""
+    lib = L.load()
+    _need_cuda(x0, R, noise, timesteps, alphas, alphas_cumprod)
+    B, Cc, H, W = x0.shape
+    x0 = x0.contiguous().float(); R = R.contiguous().float(); noise = noise.contiguous().float()
+    timesteps = timesteps.to(torch.int64).contiguous()
+    xn = torch.empty(B, H, W, Cc, device=x0.device); tg = torch.empty(B, H, W, Cc, device=x0.device)
+    d = L.QsampleDesc(B=B, C=Cc, H=H, W=W, x0=L.ptr(x0), R=L.ptr(R), noise=L.ptr(noise), timesteps=L.ptr(timesteps),
+                      alphas=L.ptr(alphas), alphas_cumprod=L.ptr(alphas_cumprod), x_noisy=L.ptr(xn), ld_noisy=Cc,
+                      target=L.ptr(tg), ld_target=Cc)
+    L.check(lib.bd_qsample(C.byref(d), L.stream()), "bd_qsample")
+    return xn, tg
+
+
+def nchw_to_nhwc(x):
+    lib = L.load(); _need_cuda(x)
+    B, Cc, H, W = x.shape
+    x = x.contiguous().float()
+    y = torch.empty(B, H, W, Cc, device=x.device)
+    L.check(lib.bd_nchw_to_nhwc(L.ptr(x), L.ptr(y), B, Cc, H, W, Cc, L.stream()), "bd_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw(x):
+    lib = L.load(); _need_cuda(x)
+    B, H, W, Cc = x.shape
+    x = x.contiguous()
+    y = torch.empty(B, Cc, H, W, device=x.device)
+    L.check(lib.bd_nhwc_to_nchw(L.ptr(x), Cc, L.ptr(y), B, Cc, H, W, L.stream()), "bd_nhwc_to_nchw")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------ a-5/a-6/a-7
+def ddpm_step(model_output, sample, noise, alphas_cumprod, t, prev_t, variance_type="fixed_small", clip_sample=True,
+              clip_sample_range=1.0, clip_defense=False, clip_defense_range=1.0, out=None, want_x0=False):
+    lib = L.load(); _need_cuda(model_output, sample, noise, alphas_cumprod)
+    vt = {"fixed_small": 0, "fixed_large": 1}.get(variance_type)
+    if vt is None:
+        raise NotImplementedError(f"variance_type {variance_type} is not supported by the HIP DDPM step "
+                                  "(BadDiffusion uses fixed_small / fixed_large)")
+    assert model_output.is_contiguous() and sample.is_contiguous()
+    prev = torch.empty_like(sample) if out is None else out
+    x0 = torch.empty_like(sample) if want_x0 else None
+    d = L.DdpmStepDesc(n=sample.numel(), model_output=L.ptr(model_output), sample=L.ptr(sample),
+                       noise=L.ptr(noise.contiguous()) if noise is not None else None, prev_sample=L.ptr(prev),
+                       pred_original=L.ptr(x0), alphas_cumprod=L.ptr(alphas_cumprod), t=int(t), prev_t=int(prev_t),
+                       variance_type=vt, clip_sample=int(bool(clip_sample)), clip_sample_range=clip_sample_range,
+                       clip_defense=int(bool(clip_defense)), clip_defense_range=clip_defense_range)
+    L.check(lib.bd_ddpm_step(C.byref(d), L.stream()), "bd_ddpm_step")
+    return (prev, x0) if want_x0 else prev
+
+
+def ddim_step(model_output, sample, alphas_cumprod, t, prev_t, eta=0.0, noise=None, clip_sample=True,
+              clip_sample_range=1.0, final_alpha_cumprod=1.0, out=None, want_x0=False):
+    lib = L.load(); _need_cuda(model_output, sample, noise, alphas_cumprod)
+    assert model_output.is_contiguous() and sample.is_contiguous()
+    prev = torch.empty_like(sample) if out is None else out
+    x0 = torch.empty_like(sample) if want_x0 else None
+    d = L.DdimStepDesc(n=sample.numel(), model_output=L.ptr(model_output), sample=L.ptr(sample),
+                       noise=L.ptr(noise.contiguous()) if noise is not None else None, prev_sample=L.ptr(prev),
+                       pred_original=L.ptr(x0), alphas_cumprod=L.ptr(alphas_cumprod), t=int(t), prev_t=int(prev_t),
+                       final_alpha_cumprod=final_alpha_cumprod, eta=eta, clip_sample=int(bool(clip_sample)),
+                       clip_sample_range=clip_sample_range)
+    L.check(lib.bd_ddim_step(C.byref(d), L.stream()), "bd_ddim_step")
+    return (prev, x0) if want_x0 else prev
+
+
+def to_image(x, nhwc, shape_bchw, want_u8=False):
+    """(x/2+0.5).clamp(0,1) -> NHWC float32 [B,H,W,C] (and uint8 round(255 x))."""
+    lib = L.load(); _need_cuda(x)
+    B, Cc, H, W = shape_bchw
+    x = x.contiguous()
+    of = torch.empty(B, H, W, Cc, device=x.device)
+    ou = torch.empty(B, H, W, Cc, dtype=torch.uint8, device=x.device) if want_u8 else None
+    L.check(lib.bd_to_image(L.ptr(x), int(nhwc), Cc, B, Cc, H, W, L.ptr(of), L.ptr(ou), L.stream()), "bd_to_image")
+    return (of, ou) if want_u8 else of
+
+
+def timestep_embedding(t, dim, flip_sin_to_cos, freq_shift):
+    lib = L.load(); _need_cuda(t)
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty(t.numel(), dim, device=t.device)
+    L.check(lib.bd_timestep_embedding(L.ptr(t), 1, t.numel(), dim, int(flip_sin_to_cos), float(freq_shift), L.ptr(out),
+                                      L.stream()), "bd_timestep_embedding")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------ GroupNorm
+def gn_fwd(x, gamma, beta, G, eps, silu):
+    """x [B,HW,C] (last dim contiguous, row stride = ld).  Returns (y [B,HW,C], mean [B,G], rstd [B,G])."""
+    lib = L.load(); _need_cuda(x, gamma, beta)
+    B, HW, Cc = x.shape
+    y = torch.empty(B, HW, Cc, device=x.device)
+    stats = torch.empty(2, B, G, device=x.device)
+    ws = workspace(lib.bd_gn_workspace_bytes(B, Cc), x.device)
+    d = L.GnFwdDesc(B=B, HW=HW, C=Cc, G=G, eps=eps, silu=int(silu), x=L.ptr(x), ldx=_ld(x), gamma=L.ptr(gamma),
+                    beta=L.ptr(beta), y=L.ptr(y), ldy=Cc, mean=L.ptr(stats[0]), rstd=L.ptr(stats[1]),
+                    workspace=L.ptr(ws), workspace_bytes=ws.numel())
+    L.check(lib.bd_gn_fwd(C.byref(d), L.stream()), "bd_gn_fwd")
+    return y, stats[0], stats[1]
+
+
+def gn_bwd(x, gamma, beta, mean, rstd, dy, G, silu, dx=None, accumulate=False):
+    lib = L.load(); _need_cuda(x, gamma, beta, mean, rstd, dy)
+    B, HW, Cc = x.shape
+    if dx is None:
+        dx = torch.empty(B, HW, Cc, device=x.device)
+    dg = torch.empty(Cc, device=x.device); db = torch.empty(Cc, device=x.device)
+    ws = workspace(lib.bd_gn_workspace_bytes(B, Cc), x.device)
+    d = L.GnBwdDesc(B=B, HW=HW, C=Cc, G=G, silu=int(silu), x=L.ptr(x), ldx=_ld(x), gamma=L.ptr(gamma), beta=L.ptr(beta),
+                    mean=L.ptr(mean), rstd=L.ptr(rstd), dy=L.ptr(dy), lddy=_ld(dy), dx=L.ptr(dx), lddx=_ld(dx),
+                    accumulate_dx=int(accumulate), dgamma=L.ptr(dg), dbeta=L.ptr(db), workspace=L.ptr(ws),
+                    workspace_bytes=ws.numel())
+    L.check(lib.bd_gn_bwd(C.byref(d), L.stream()), "bd_gn_bwd")
+    return dx, dg, db
+
+
+# ------------------------------------------------------------------------------------------------ igemm family
+def _conv_out_hw(Hs, Ws, stride, pad_t, pad_l, ups, pad_b=None, pad_r=None):
+    Hi, Wi = Hs << ups, Ws << ups
+    pad_b = pad_t if pad_b is None else pad_b
+    pad_r = pad_l if pad_r is None else pad_r
+    return (Hi + pad_t + pad_b - 3) // stride + 1, (Wi + pad_l + pad_r - 3) // stride + 1
+
+
+def conv3x3_fwd(x, w, bias=None, stride=1, pad=1, ups=0, asym=False, rowbias=None, residual=None, out_scale=1.0):
+    """x [B,Hs,Ws,Cin] NHWC ; w [Cout,3,3,Cin].  asym => F.pad(0,1,0,1) + stride-2 conv with padding 0."""
+    lib = L.load(); _need_cuda(x, w, bias, rowbias, residual)
+    B, Hs, Ws, Cin = x.shape
+    Cout = w.shape[0]
+    pt = pl = 0 if asym else pad
+    Ho, Wo = _conv_out_hw(Hs, Ws, stride, pt, pl, ups, 1 if asym else None, 1 if asym else None)
+    y = torch.empty(B, Ho, Wo, Cout, device=x.device)
+    ws = workspace(lib.bd_conv3x3_workspace_bytes(B, Ho, Wo, Hs, Ws, Cin, Cout, ups), x.device)
+    d = L.ConvFwdDesc(B=B, Hs=Hs, Ws=Ws, Cin=Cin, Cout=Cout, stride=stride, pad_t=pt, pad_l=pl, ups=ups, Ho=Ho, Wo=Wo,
+                      x=L.ptr(x), ldx=_ld(x), w=L.ptr(w), bias=L.ptr(bias), rowbias=L.ptr(rowbias),
+                      ld_rowbias=rowbias.stride(0) if rowbias is not None else 0, residual=L.ptr(residual),
+                      ldr=_ld(residual) if residual is not None else 0, out_scale=out_scale, y=L.ptr(y), ldy=Cout,
+                      workspace=L.ptr(ws), workspace_bytes=ws.numel())
+    L.check(lib.bd_conv3x3_fwd(C.byref(d), L.stream()), "bd_conv3x3_fwd")
+    return y
+
+
+def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False):
+    """Returns dx over the conv's own input grid [B, Hs<<ups, Ws<<ups, Cin]."""
+    lib = L.load(); _need_cuda(dy, w)
+    B, Hs, Ws, Cin = x_shape
+    Cout = w.shape[0]
+    pt = pl = 0 if asym else pad
+    Ho, Wo = dy.shape[1], dy.shape[2]
+    dx = torch.empty(B, Hs << ups, Ws << ups, Cin, device=dy.device)
+    ws = workspace(lib.bd_conv3x3_workspace_bytes(B, Ho, Wo, Hs, Ws, Cin, Cout, ups), dy.device)
+    d = L.ConvDgradDesc(B=B, Hs=Hs, Ws=Ws, Cin=Cin, Cout=Cout, stride=stride, pad_t=pt, pad_l=pl, ups=ups, Ho=Ho, Wo=Wo,
+                        dy=L.ptr(dy), lddy=_ld(dy), w=L.ptr(w), dx=L.ptr(dx), lddx=Cin, accumulate=0,
+                        workspace=L.ptr(ws), workspace_bytes=ws.numel())
+    L.check(lib.bd_conv3x3_dgrad(C.byref(d), L.stream()), "bd_conv3x3_dgrad")
+    return dx
+
+
+def conv3x3_wgrad(x, dy, stride=1, pad=1, ups=0, asym=False):
+    lib = L.load(); _need_cuda(x, dy)
+    B, Hs, Ws, Cin = x.shape
+    Cout = dy.shape[-1]
+    pt = pl = 0 if asym else pad
+    Ho, Wo = dy.shape[1], dy.shape[2]
+    dw = torch.empty(Cout, 3, 3, Cin, device=x.device)
+    ws = workspace(lib.bd_conv3x3_workspace_bytes(B, Ho, Wo, Hs, Ws, Cin, Cout, ups), x.device)
+    d = L.ConvWgradDesc(B=B, Hs=Hs, Ws=Ws, Cin=Cin, Cout=Cout, stride=stride, pad_t=pt, pad_l=pl, ups=ups, Ho=Ho, Wo=Wo,
+                        x=L.ptr(x), ldx=_ld(x), dy=L.ptr(dy), lddy=_ld(dy), dw=L.ptr(dw), workspace=L.ptr(ws),
+                        workspace_bytes=ws.numel())
+    L.check(lib.bd_conv3x3_wgrad(C.byref(d), L.stream()), "bd_conv3x3_wgrad")
+    return dw
+
+
+def gemm(a, b, trans_a=False, trans_b=True, bias=None, alpha=1.0, tile=0, ksplit=0):
+    """C = alpha * op(a) @ op(b)^T-style product on the igemm engine.
+    a: [M,K] (trans_a False) or [K,M] (trans_a True); b: [N,K] (trans_b True, 'weights') or [K,N] (False).
+    Batched when a/b are 3-D (same leading batch)."""
+    lib = L.load(); _need_cuda(a, b, bias)
+    batched = a.dim() == 3
+    if not batched:
+        a, b = a[None], b[None]
+    nb = a.shape[0]
+    M, K = (a.shape[2], a.shape[1]) if trans_a else (a.shape[1], a.shape[2])
+    N = b.shape[1] if trans_b else b.shape[2]
+    a = a.contiguous(); b = b.contiguous()
+    c = torch.empty(nb, M, N, device=a.device)
+    d = L.IgemmDesc()
+    d.A.kind = 0; d.A.kc = 0 if trans_a else 1; d.A.p = L.ptr(a); d.A.ld = a.shape[2]; d.A.bs_outer = a.stride(0)
+    d.B.kind = 0; d.B.kc = 1 if trans_b else 0; d.B.p = L.ptr(b); d.B.ld = b.shape[2]; d.B.bs_outer = b.stride(0)
+    d.M, d.N, d.K = M, N, K
+    d.batch_outer, d.batch_inner = nb, 1
+    d.C = L.ptr(c); d.ldc = N; d.c_bs_outer = M * N
+    d.alpha = alpha; d.out_scale = 1.0; d.bias = L.ptr(bias)
+    d.tile = tile; d.ksplit = ksplit
+    need = lib.bd_igemm_workspace_bytes(C.byref(d))
+    ws = workspace(need, a.device)
+    d.workspace = L.ptr(ws); d.workspace_bytes = ws.numel()
+    L.check(lib.bd_igemm(C.byref(d), L.stream()), "bd_igemm")
+    return c if batched else c[0]
+
+
+# ------------------------------------------------------------------------------------------------ small ops
+def colsum(x, rows_per_group):
+    lib = L.load(); _need_cuda(x)
+    rows, N = x.shape
+    groups = (rows + rows_per_group - 1) // rows_per_group
+    out = torch.empty(groups, N, device=x.device)
+    L.check(lib.bd_colsum(L.ptr(x), _ld(x), rows, N, rows_per_group, L.ptr(out), N, 0, L.stream()), "bd_colsum")
+    return out
+
+
+def sum2x2(du):
+    lib = L.load(); _need_cuda(du)
+    B, H2, W2, Cc = du.shape
+    dx = torch.empty(B, H2 // 2, W2 // 2, Cc, device=du.device)
+    L.check(lib.bd_sum2x2(L.ptr(du), Cc, L.ptr(dx), Cc, B, H2 // 2, W2 // 2, Cc, 0, L.stream()), "bd_sum2x2")
+    return dx
+
+
+def softmax_fwd(s):
+    lib = L.load(); _need_cuda(s)
+    s = s.contiguous()
+    p = torch.empty_like(s)
+    L.check(lib.bd_softmax_fwd(L.ptr(s), L.ptr(p), s.numel() // s.shape[-1], s.shape[-1], L.stream()), "bd_softmax_fwd")
+    return p
+
+
+def softmax_bwd(p, dp):
+    lib = L.load(); _need_cuda(p, dp)
+    ds = torch.empty_like(p)
+    L.check(lib.bd_softmax_bwd(L.ptr(p.contiguous()), L.ptr(dp.contiguous()), L.ptr(ds), p.numel() // p.shape[-1],
+                               p.shape[-1], L.stream()), "bd_softmax_bwd")
+    return ds
+
+
+def silu_fwd(x):
+    lib = L.load(); _need_cuda(x)
+    y = torch.empty_like(x)
+    L.check(lib.bd_silu_fwd(L.ptr(x.contiguous()), L.ptr(y), x.numel(), L.stream()), "bd_silu_fwd")
+    return y
+
+
+def silu_bwd(x, dy):
+    lib = L.load(); _need_cuda(x, dy)
+    dx = torch.empty_like(x)
+    L.check(lib.bd_silu_bwd(L.ptr(x.contiguous()), L.ptr(dy.contiguous()), L.ptr(dx), x.numel(), 0, L.stream()), "bd_silu_bwd")
+    return dx
+
+
+LOSS_TYPES = {"l2": 0, "l1": 1, "huber": 2}
+
+
+def loss_fwd_bwd(pred, target, loss_type="l2", grad_scale=1.0, want_grad=True):
+    """pred / target: [..., C] views with the same logical shape (last dim contiguous, uniform row stride).
+    Returns (loss 0-dim tensor, dpred contiguous [rows, C] or None)."""
+    lib = L.load(); _need_cuda(pred, target)
+    if loss_type not in LOSS_TYPES:
+        raise NotImplementedError()
+    Cc = pred.shape[-1]
+    rows = pred.numel() // Cc
+    p2 = pred.reshape(rows, Cc) if pred.is_contiguous() else pred
+    t2 = target.reshape(rows, Cc) if target.is_contiguous() else target
+    loss = torch.empty((), device=pred.device)
+    dp = torch.empty(rows, Cc, device=pred.device) if want_grad else None
+    ws = workspace(lib.bd_reduce_workspace_bytes(), pred.device, "reduce")
+    L.check(lib.bd_loss_fwd_bwd(L.ptr(p2), _ld(p2), L.ptr(t2), _ld(t2), rows, Cc, LOSS_TYPES[loss_type], grad_scale,
+                                L.ptr(loss), L.ptr(dp), Cc, L.ptr(ws), L.stream()), "bd_loss_fwd_bwd")
+    return loss, dp
+
+
+def sumsq(g, out=None):
+    lib = L.load(); _need_cuda(g)
+    if out is None:
+        out = torch.empty((), dtype=torch.float64, device=g.device)
+    ws = workspace(lib.bd_reduce_workspace_bytes(), g.device, "reduce")
+    L.check(lib.bd_sumsq(L.ptr(g), g.numel(), L.ptr(out), L.ptr(ws), L.stream()), "bd_sumsq")
+    return out
+
+
+def adam_clip(p, g, m, v, sumsq_t, step, lr, max_norm=1.0, betas=(0.9, 0.999), eps=1e-8, grad_norm_out=None):
+    lib = L.load(); _need_cuda(p, g, m, v, sumsq_t)
+    L.check(lib.bd_adam_clip(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(sumsq_t), float(max_norm), float(lr),
+                             float(betas[0]), float(betas[1]), float(eps), int(step), L.ptr(grad_norm_out), L.stream()),
+            "bd_adam_clip")

@@ -1,0 +1,308 @@
+/*
+ * bd_hip.h -- C ABI of libbd_hip.so, the MI355X (gfx950) kernels behind the BadDiffusion hot path.
+ *
+ * The reference (IBM/BadDiffusion) has no FFI for this path: the seam is the Python API that
+ * baddiffusion.py calls.  Each entry point below names the reference code it replaces
+ * (paths relative to the reference root).  Conventions:
+ *   - every pointer is a DEVICE pointer owned by the caller (PyTorch's allocator on the Python side);
+ *     the library never allocates, frees or retains device memory;
+ *   - activations are NHWC ("pixels x channels", fp32) with an explicit leading dimension `ld`
+ *     (elements between consecutive pixels), so a channel slice of a wider buffer is a valid tensor
+ *     and the reference's torch.cat on the channel axis needs no copy;
+ *   - conv weights are [Cout][kh][kw][Cin] (the physical layout of a channels_last OIHW tensor);
+ *   - all work is enqueued on `stream` (a hipStream_t); no hidden synchronisation, no default-stream
+ *     use => capturable in a hipGraph;
+ *   - return 0 on success, a negative bd_status otherwise; bd_last_error() gives the message
+ *     (thread-local).  No C++ exception crosses this boundary.
+ */
+#ifndef BD_HIP_H
+#define BD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* bd_stream_t; /* hipStream_t */
+
+enum bd_status {
+    BD_OK = 0,
+    BD_ERR_INVALID = -1,     /* bad shape / null pointer / misaligned */
+    BD_ERR_UNSUPPORTED = -2, /* configuration the reference supports but this path does not */
+    BD_ERR_LAUNCH = -3,      /* hipGetLastError() after a launch */
+    BD_ERR_WORKSPACE = -4    /* workspace too small */
+};
+
+const char* bd_last_error(void);
+int bd_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * a-1 + a-2: poisoned-sample blend + BadDiffusion forward process, one fused kernel.
+ * Replaces dataset.py:275-276 (get_mask), :288-315 (clean/backdoor transforms: R = m*x + (1-m)*g,
+ * x0 = y | R = 0, x0 = x), util.py:83-111 (normalize, eps 1e-5) when the images are uint8, and
+ * loss.py:257-285 (q_sample_diffuser) + schedulers/scheduling_ddpm.py:422-443 (add_noise):
+ *     x_noisy = sqrt(ac_t) x0 + sqrt(1-ac_t) eps + (1 - sqrt(ac_t)) R,  target = rho_t R + eps.
+ * Layout: NCHW in (what the reference's DataLoader yields), NHWC out with leading dim ld_out.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, C, H, W;
+    const float* images_f32;      /* [B,C,H,W] normalised images, or NULL                     */
+    const uint8_t* images_u8;     /* [B,H,W,C] raw uint8 (normalised in-kernel), or NULL      */
+    const uint8_t* is_poison;     /* [B] 0 = clean row, 1 = backdoor row                      */
+    const float* trigger;         /* [C,H,W]  g                                               */
+    const float* target_img;      /* [C,H,W]  y                                               */
+    const float* noise;           /* [B,C,H,W] eps (NCHW, as torch.randn produced it)         */
+    const int64_t* timesteps;     /* [B]                                                      */
+    const float* alphas;          /* [T]                                                      */
+    const float* alphas_cumprod;  /* [T]                                                      */
+    float vmin;                   /* mask threshold: m = (g > vmin) ? 0 : 1                   */
+    float* x_noisy; int64_t ld_noisy;   /* NHWC [B*H*W, ld]                                   */
+    float* target;  int64_t ld_target;  /* NHWC [B*H*W, ld]                                   */
+    float* R_out;                 /* optional NCHW [B,C,H,W] (pixel_values), may be NULL      */
+    float* x0_out;                /* optional NCHW [B,C,H,W] (target), may be NULL            */
+    int64_t* mask_out;            /* optional [C,H,W] int64 mask (bit-exact check), may be NULL */
+} bd_poison_qsample_desc;
+int bd_poison_qsample(const bd_poison_qsample_desc* d, bd_stream_t stream);
+
+/* Plain q_sample_diffuser on already-collated (x0, R) NCHW batches (loss.py:257-285). */
+typedef struct {
+    int B, C, H, W;
+    const float* x0; const float* R; const float* noise;   /* NCHW */
+    const int64_t* timesteps; const float* alphas; const float* alphas_cumprod;
+    float* x_noisy; int64_t ld_noisy;   /* NHWC */
+    float* target;  int64_t ld_target;  /* NHWC */
+} bd_qsample_desc;
+int bd_qsample(const bd_qsample_desc* d, bd_stream_t stream);
+
+/* NCHW <-> NHWC(ld) conversion for the 3-channel boundary tensors. */
+int bd_nchw_to_nhwc(const float* src, float* dst, int B, int C, int H, int W, int64_t ld, bd_stream_t stream);
+int bd_nhwc_to_nchw(const float* src, int64_t ld, float* dst, int B, int C, int H, int W, bd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a-5 / a-6 / a-7: scheduler steps and image conversion (all NCHW-agnostic: elementwise over
+ * [B, n] with per-launch scalar coefficients read from a DEVICE table indexed by t).
+ * Replaces scheduling_ddpm.py:324-420, scheduling_ddim.py:261-381, pipeline_ddpm.py:115-116.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int64_t n;                    /* total elements                                            */
+    const float* model_output; const float* sample; const float* noise;  /* noise may be NULL iff t == 0 */
+    float* prev_sample; float* pred_original; /* pred_original may be NULL                     */
+    const float* alphas_cumprod;  /* [T] device                                                */
+    int t, prev_t;                /* prev_t < 0 => alpha_prod_prev = 1                         */
+    int variance_type;            /* 0 fixed_small, 1 fixed_large                              */
+    int clip_sample; float clip_sample_range;
+    int clip_defense; float clip_defense_range;
+} bd_ddpm_step_desc;
+int bd_ddpm_step(const bd_ddpm_step_desc* d, bd_stream_t stream);
+
+typedef struct {
+    int64_t n;
+    const float* model_output; const float* sample; const float* noise; /* noise NULL iff eta == 0 */
+    float* prev_sample; float* pred_original;
+    const float* alphas_cumprod;
+    int t, prev_t; float final_alpha_cumprod; float eta;
+    int clip_sample; float clip_sample_range;
+} bd_ddim_step_desc;
+int bd_ddim_step(const bd_ddim_step_desc* d, bd_stream_t stream);
+
+/* (x/2+0.5).clamp(0,1): NCHW or NHWC(ld) in -> NHWC float [B,H,W,C] and/or uint8 round(255 x). */
+int bd_to_image(const float* x, int src_is_nhwc, int64_t ld, int B, int C, int H, int W,
+                float* out_f32, uint8_t* out_u8, bd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a-4a: sinusoidal timestep embedding (models/embeddings.py:22-62).  t is int64 [B] (or one value
+ * broadcast when t_stride == 0).
+ * ------------------------------------------------------------------------------------------------ */
+int bd_timestep_embedding(const int64_t* t, int t_stride, int B, int dim, int flip_sin_to_cos,
+                          float freq_shift, float* out, bd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU) over NHWC(ld).  Replaces nn.GroupNorm + F.silu at resnet.py:559,591,
+ * attention.py:125, unet_2d.py:312-313 and their autograd backward.
+ * Workspace: bd_gn_workspace_bytes(B, C).  mean/rstd are [B, G] fp32 outputs saved for backward.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, HW, C, G; float eps; int silu;
+    const float* x; int64_t ldx;
+    const float* gamma; const float* beta;
+    float* y; int64_t ldy;
+    float* mean; float* rstd;       /* [B,G] */
+    void* workspace; size_t workspace_bytes;
+} bd_gn_fwd_desc;
+size_t bd_gn_workspace_bytes(int B, int C);
+int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream);
+
+typedef struct {
+    int B, HW, C, G; int silu;
+    const float* x; int64_t ldx;            /* GN input saved from forward                     */
+    const float* gamma; const float* beta;
+    const float* mean; const float* rstd;
+    const float* dy; int64_t lddy;          /* grad wrt the (activated) output                 */
+    float* dx; int64_t lddx; int accumulate_dx;  /* dx (+)= ...                                */
+    float* dgamma; float* dbeta;            /* [C], written (not accumulated)                  */
+    void* workspace; size_t workspace_bytes;
+} bd_gn_bwd_desc;
+int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Implicit-GEMM engine on f32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products/accumulate).
+ *     C[m,n] = out_scale * (alpha * sum_k A(m,k) B(n,k) + bias[n] + rowbias[m / rows_per_group, n]
+ *                           + residual[m,n])   (+ C[m,n] if accumulate)
+ * Operand kinds select how (row, k) maps to memory; see DESIGN.md "igemm".
+ * Replaces aten::convolution / convolution_backward / addmm / mm / bmm / baddbmm of SURVEY 2.3.
+ * ------------------------------------------------------------------------------------------------ */
+enum bd_operand_kind {
+    BD_OPK_DENSE = 0, /* KC: p[row*ld + k]            RC: p[k*ld + row]                          */
+    BD_OPK_CONV = 1,  /* 3x3 gather of an NHWC tensor: KC rows = output pixels, k = tap*C + c;
+                         RC rows = tap*C + c, k = output pixels (wgrad)                          */
+    BD_OPK_TCONV = 2, /* KC only: rows = input pixels, k = tap*C + c over dY (dgrad, any stride) */
+    BD_OPK_WGT = 3    /* RC only: rows = ci, k = tap*C + co over W[co][tap][ci]   (dgrad)        */
+};
+typedef struct {
+    int kind;              /* bd_operand_kind                                                   */
+    int kc;                /* 1: k-contiguous in memory (KC)  0: row-contiguous (RC)            */
+    const float* p; int64_t ld;
+    int64_t bs_outer, bs_inner;   /* batch strides (elements)                                   */
+    int C, Hs, Ws, Ho, Wo, stride, pad_t, pad_l, ups;   /* conv geometry (CONV/TCONV/WGT)       */
+} bd_operand;
+typedef struct {
+    bd_operand A, B;
+    int M, N, K;
+    int batch_outer, batch_inner;            /* >= 1                                            */
+    float* C; int64_t ldc; int64_t c_bs_outer, c_bs_inner;
+    float alpha; float out_scale;
+    const float* bias;
+    const float* rowbias; int64_t ld_rowbias; int rows_per_group;
+    const float* residual; int64_t ldr;      /* same batch strides as C                         */
+    int accumulate;
+    int ksplit;                              /* 0 = choose; >1 needs workspace                  */
+    void* workspace; size_t workspace_bytes;
+    int tile;                                /* 0 = choose, 128 or 64                           */
+} bd_igemm_desc;
+size_t bd_igemm_workspace_bytes(const bd_igemm_desc* d);
+int bd_igemm(const bd_igemm_desc* d, bd_stream_t stream);
+
+/* Convenience wrappers over bd_igemm (all NHWC(ld), weights [Cout][3][3][Cin]).
+ * conv fwd:   y[B,Ho,Wo,Cout] = conv3x3(x[B,Hs,Ws,Cin] (nearest-upsampled x2 if ups), stride, pads)
+ *             (+bias) (+rowbias per sample) (+residual) ; resnet.py:493,514,118,185,201-203
+ * dgrad:      dx[B,Hs<<ups,Ws<<ups,Cin] (the conv's own input grid)
+ * wgrad:      dw[Cout][3][3][Cin] (written), db[Cout] via bd_colsum                            */
+typedef struct {
+    int B, Hs, Ws, Cin, Cout, stride, pad_t, pad_l, ups; /* Ho/Wo derived by the callee         */
+    int Ho, Wo;
+    const float* x; int64_t ldx;
+    const float* w;
+    const float* bias;
+    const float* rowbias; int64_t ld_rowbias;   /* [B, Cout] added per sample (time embedding)  */
+    const float* residual; int64_t ldr;
+    float out_scale;
+    float* y; int64_t ldy;
+    void* workspace; size_t workspace_bytes;
+} bd_conv3x3_fwd_desc;
+int bd_conv3x3_fwd(const bd_conv3x3_fwd_desc* d, bd_stream_t stream);
+
+typedef struct {
+    int B, Hs, Ws, Cin, Cout, stride, pad_t, pad_l, ups, Ho, Wo;
+    const float* dy; int64_t lddy;
+    const float* w;
+    float* dx; int64_t lddx; int accumulate;   /* dx over the (virtual, upsampled) input grid   */
+    void* workspace; size_t workspace_bytes;
+} bd_conv3x3_dgrad_desc;
+int bd_conv3x3_dgrad(const bd_conv3x3_dgrad_desc* d, bd_stream_t stream);
+
+typedef struct {
+    int B, Hs, Ws, Cin, Cout, stride, pad_t, pad_l, ups, Ho, Wo;
+    const float* x; int64_t ldx;
+    const float* dy; int64_t lddy;
+    float* dw;
+    void* workspace; size_t workspace_bytes;
+} bd_conv3x3_wgrad_desc;
+int bd_conv3x3_wgrad(const bd_conv3x3_wgrad_desc* d, bd_stream_t stream);
+size_t bd_conv3x3_workspace_bytes(int B, int Ho, int Wo, int Hs, int Ws, int Cin, int Cout, int ups);
+
+/* out[g, n] = sum over rows m in group g of x[m, n]  (rows_per_group rows each); bias / temb grads. */
+int bd_colsum(const float* x, int64_t ldx, int64_t rows, int N, int64_t rows_per_group, float* out,
+              int64_t ld_out, int accumulate, bd_stream_t stream);
+/* dx[b, y, x, c] (+)= sum of the 2x2 block of du[b, 2y.., 2x.., c]  (nearest-upsample backward). */
+int bd_sum2x2(const float* du, int64_t ldu, float* dx, int64_t lddx, int B, int H, int W, int C,
+              int accumulate, bd_stream_t stream);
+
+/* Row softmax over [rows, n] (attention.py:161) and its backward dS = P * (dP - sum(dP*P)). */
+int bd_softmax_fwd(const float* s, float* p, int64_t rows, int n, bd_stream_t stream);
+int bd_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, int n, bd_stream_t stream);
+
+/* y = x * sigmoid(x) ; dx = dy * silu'(x)  (embeddings.py:205-206, resnet.py:576) */
+int bd_silu_fwd(const float* x, float* y, int64_t n, bd_stream_t stream);
+int bd_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, int accumulate, bd_stream_t stream);
+
+/* a-3: loss = mean((pred - target)^2) and dpred = 2 (pred - target) / n  (loss.py:301).
+ * loss_type: 0 l2, 1 l1, 2 huber(beta=1).  loss is a device scalar, written (not accumulated).
+ * grad_scale multiplies dpred (1/world for DP mean).  workspace >= bd_reduce_workspace_bytes().   */
+size_t bd_reduce_workspace_bytes(void);
+int bd_loss_fwd_bwd(const float* pred, int64_t ldp, const float* target, int64_t ldt, int64_t rows, int C,
+                    int loss_type, float grad_scale, float* loss, float* dpred, int64_t lddp,
+                    void* workspace, bd_stream_t stream);
+
+/* a-8: global-norm clip + Adam over one flat fp32 buffer (baddiffusion.py:320, 611-615).
+ * bd_sumsq: sumsq (device double scalar) = sum g^2.  bd_adam_clip reads it:
+ *   coef = min(1, max_norm / (sqrt(sumsq) + 1e-6));  g *= coef;  Adam(b1,b2,eps), bias correction from
+ *   `step` (1-based, host scalar) ; lr host scalar.  grad_norm_out (device float, optional) = sqrt(sumsq). */
+int bd_sumsq(const float* g, int64_t n, double* sumsq, void* workspace, bd_stream_t stream);
+int bd_adam_clip(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
+                 double max_norm, double lr, double b1, double b2, double eps, int step, float* grad_norm_out,
+                 bd_stream_t stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * a-4: the whole UNet2DModel (models/unet_2d.py:82-326) as a static plan: forward (inference or
+ * training, saving what backward needs in the caller's workspace) and backward (writes the flat
+ * gradient buffer; every parameter gets exactly one contribution, so no zeroing is needed).
+ * Parameters live in ONE flat fp32 buffer; bd_unet_param_* describe where each state_dict key is.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int sample_size, in_channels, out_channels;
+    int num_blocks;                 /* <= 8                                                     */
+    int block_out_channels[8];
+    int down_attn[8];               /* 1 = AttnDownBlock2D, 0 = DownBlock2D                     */
+    int up_attn[8];                 /* 1 = AttnUpBlock2D,   0 = UpBlock2D                       */
+    int layers_per_block;
+    int downsample_padding;         /* 0 => asymmetric (0,1,0,1) pad, 1 => symmetric            */
+    int flip_sin_to_cos; float freq_shift;
+    float norm_eps; int norm_num_groups;
+    int attention_head_dim;         /* 0 => single head                                         */
+    float mid_block_scale_factor;
+} bd_unet_config;
+
+typedef struct bd_unet bd_unet;     /* host-only plan object (no device memory)                  */
+int bd_unet_create(const bd_unet_config* cfg, bd_unet** out);
+void bd_unet_destroy(bd_unet* u);
+int64_t bd_unet_num_params(const bd_unet* u);
+int bd_unet_num_tensors(const bd_unet* u);
+/* i-th parameter tensor: state_dict key, offset (elements) in the flat buffer, logical shape
+ * (rank <= 4, OIHW for convs) and layout: 0 = as-is (contiguous logical shape),
+ * 1 = conv weight stored [O][kh][kw][I]. */
+int bd_unet_param_info(const bd_unet* u, int i, const char** name, int64_t* offset, int* rank,
+                       int64_t shape[4], int* layout);
+/* workspace bytes for batch B; training != 0 keeps every tensor backward needs */
+size_t bd_unet_workspace_bytes(bd_unet* u, int B, int training);
+/* x: NHWC [B*S*S, ldx] ; t: int64 [B] (t_stride 0 => broadcast t[0]) ; out NHWC [B*S*S, ldo] */
+int bd_unet_forward(bd_unet* u, int B, int training, const float* params, const float* x, int64_t ldx,
+                    const int64_t* t, int t_stride, float* out, int64_t ldo,
+                    void* workspace, size_t workspace_bytes, bd_stream_t stream);
+/* after a training forward with the same workspace and the same x: dout NHWC -> grads (flat, same offsets) */
+int bd_unet_backward(bd_unet* u, int B, const float* params, const float* x, int64_t ldx,
+                     const float* dout, int64_t lddo, float* grads, void* workspace, size_t workspace_bytes,
+                     bd_stream_t stream);
+/* backward split in `bd_unet_num_segments` contiguous-in-time segments so the caller can overlap a
+ * gradient all-reduce with the rest of backward: after segment s, grads in
+ * [seg_lo[s], seg_hi[s]) (elements) are final. */
+int bd_unet_num_segments(const bd_unet* u);
+int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float* params, const float* x, int64_t ldx,
+                             const float* dout, int64_t lddo, float* grads, void* workspace, size_t workspace_bytes,
+                             bd_stream_t stream, int64_t* ready_lo, int64_t* ready_hi);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BD_HIP_H */

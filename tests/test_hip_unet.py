@@ -1,0 +1,144 @@
+"""GPU parity: the whole UNet2DModel plan (forward, backward, clip + Adam) against the CPU oracle and the
+golden vectors captured from the reference (tests/golden/unet_small.npz, unet_cifar.npz).
+Tolerance: 1e-3 relative fp32 (BASELINE.json north_star); observed errors are ~1e-5."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import loss_ref, sched_ref, train_ref
+from oracle import unet_ref as U
+from tests.golden import cases as C
+
+
+@pytest.fixture(scope="module")
+def bd():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    import baddiffusion_amd.unet as unet
+    import baddiffusion_amd.ops as ops
+    return unet, ops
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double(); b = torch.as_tensor(np.asarray(b)).double() if not torch.is_tensor(b) else b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def make_model(unet, cfg, seed):
+    m = unet.unet_from_config(cfg).cuda()
+    m.load_state_dict(U.gen_params(cfg, seed))
+    return m
+
+
+def test_state_dict_roundtrip(bd):
+    unet, _ = bd
+    cfg = C.SMALL_CFGS["small"]
+    P = U.gen_params(cfg, 3)
+    m = make_model(unet, cfg, 3)
+    sd = m.state_dict()
+    assert list(sd.keys()) != [] and set(sd.keys()) == set(P.keys())
+    for k, v in P.items():
+        assert sd[k].shape == v.shape and torch.equal(sd[k].cpu(), v), k
+
+
+@pytest.mark.parametrize("tag", ["small", "small_default"])
+def test_unet_forward_vs_oracle(bd, tag):
+    unet, _ = bd
+    cfg = C.SMALL_CFGS[tag]
+    m = make_model(unet, cfg, 7)
+    P = U.gen_params(cfg, 7)
+    x = torch.randn(3, 3, 16, 16, generator=torch.Generator().manual_seed(5))
+    for t in (torch.tensor([3, 500, 999]), torch.tensor(17), 998):
+        with torch.no_grad():
+            ref = U.unet_forward(cfg, P, x, t)
+            out = m(x.cuda(), t.cuda() if torch.is_tensor(t) else t).sample
+        assert out.shape == ref.shape
+        assert relerr(out, ref) < 1e-4, relerr(out, ref)
+    # chunked inference == unchunked (samples are independent)
+    m.max_chunk = 2
+    with torch.no_grad():
+        out2 = m(x.cuda(), torch.tensor([3, 500, 999]).cuda(), return_dict=False)[0]
+        ref = U.unet_forward(cfg, P, x, torch.tensor([3, 500, 999]))
+    assert relerr(out2, ref) < 1e-4
+
+
+def _train_step(bd, cfg, seed, B, tag, g, lr=2e-4):
+    unet, ops = bd
+    _, a, ac = sched_ref.make_tables()
+    m = make_model(unet, cfg, seed)
+    x0, R, t, eps = C.train_inputs(cfg, B)
+    xn, tg = ops.qsample(x0.cuda(), R.cuda(), eps.cuda(), t.cuda(), a.cuda(), ac.cuda())
+    # forward (inference mode) vs golden prediction
+    with torch.no_grad():
+        pred = m(xn.permute(0, 3, 1, 2), t.cuda()).sample
+    assert relerr(pred, g[f"{tag}_pred"]) < 1e-4
+    # training step through autograd: loss + grads
+    pred = m(xn.permute(0, 3, 1, 2), t.cuda(), return_dict=False)[0]
+    loss, dp = ops.loss_fwd_bwd(pred.permute(0, 2, 3, 1), tg, "l2")
+    pred.backward(dp.reshape(pred.permute(0, 2, 3, 1).shape).permute(0, 3, 1, 2))
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-4 * abs(float(g[f"{tag}_loss"]))
+    names = [str(s) for s in g[f"{tag}_names"]]
+    grads = m.logical_grads()
+    gn = np.array([float(grads[k].double().norm()) for k in names])
+    ref = g[f"{tag}_gradnorms"]
+    bad = [(k, a_, b_) for k, a_, b_ in zip(names, gn, ref) if abs(a_ - b_) > 1e-3 * max(b_, 1e-6 * ref.max())]
+    assert not bad, bad[:10]
+    g8 = np.stack([np.pad(grads[k].contiguous().flatten()[:8].cpu().numpy(), (0, max(0, 8 - grads[k].numel()))) for k in names])
+    np.testing.assert_allclose(g8, g[f"{tag}_grad8"], rtol=2e-3, atol=2e-3 * float(np.abs(g[f"{tag}_grad8"]).max()))
+    # full-tensor gradient check against the oracle's autograd
+    _, G = train_ref.loss_and_grads(cfg, U.gen_params(cfg, seed), a, ac, x0, R, t, eps)
+    worst = max((relerr(grads[k], G[k]), k) for k in names)
+    assert worst[0] < 1e-3, worst
+    # clip + Adam on the flat buffers
+    flat = m.flat.data; gflat = m.flat.grad
+    mom = torch.zeros_like(flat); var = torch.zeros_like(flat)
+    ss = ops.sumsq(gflat)
+    norm = torch.empty((), device="cuda")
+    ops.adam_clip(flat, gflat, mom, var, ss, 1, lr, grad_norm_out=norm)
+    assert abs(float(norm) - float(g[f"{tag}_total_norm"])) < 1e-3 * float(g[f"{tag}_total_norm"])
+    sd = m.state_dict()
+    p8 = np.stack([np.pad(sd[k].flatten()[:8].cpu().numpy(), (0, max(0, 8 - sd[k].numel()))) for k in names])
+    np.testing.assert_allclose(p8, g[f"{tag}_p8_after"], rtol=1e-3, atol=1e-5)
+
+
+@pytest.mark.parametrize("tag", ["small", "small_default"])
+def test_small_unet_train_step(bd, golden, tag):
+    _train_step(bd, C.SMALL_CFGS[tag], 7, 2, tag, golden("unet_small"))
+
+
+def test_cifar_unet_train_step(bd, golden):
+    torch.set_num_threads(max(1, torch.get_num_threads()))
+    _train_step(bd, U.CIFAR10_32, 0, 2, "cifar", golden("unet_cifar"))
+
+
+def test_backward_segments_equal_whole(bd):
+    """bd_unet_backward_segment over all segments == bd_unet_backward (the DP overlap path)."""
+    unet, ops = bd
+    import ctypes
+    from baddiffusion_amd import _lib as L
+    cfg = C.SMALL_CFGS["small"]
+    m = make_model(unet, cfg, 7)
+    x = torch.randn(2, 16, 16, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    t = torch.tensor([10, 900]).cuda()
+    dout = torch.randn(2, 16, 16, 3, generator=torch.Generator().manual_seed(2)).cuda()
+    out, ws = m._run_forward(m.flat.data, x, t, True)
+    g1 = m._run_backward(m.flat.data, x, dout, ws)
+    out, ws2 = m._run_forward(m.flat.data, x, t, True)
+    g2 = torch.zeros_like(g1)
+    lib = L.load()
+    nseg = lib.bd_unet_num_segments(m._plan)
+    covered = torch.zeros(m.num_flat, dtype=torch.bool)
+    for s in range(nseg):
+        lo = ctypes.c_int64(); hi = ctypes.c_int64()
+        L.check(lib.bd_unet_backward_segment(m._plan, s, 2, m.flat.data_ptr(), x.data_ptr(), 3, dout.data_ptr(), 3, g2.data_ptr(),
+                                             ws2.data_ptr(), ws2.numel(), L.stream(), ctypes.byref(lo), ctypes.byref(hi)))
+        assert 0 <= lo.value < hi.value <= m.num_flat
+        assert not covered[lo.value:hi.value].any()
+        # the range reported ready must already be final
+        torch.cuda.synchronize()
+        assert torch.equal(g2[lo.value:hi.value], g1[lo.value:hi.value]), s
+        covered[lo.value:hi.value] = True
+    assert torch.equal(g1, g2)
+    assert int((~covered).sum()) < 64      # only alignment padding is uncovered
