@@ -19,7 +19,7 @@ class PoisonQsampleDesc(C.Structure):
                 ("images_f32", vp), ("images_u8", vp), ("is_poison", vp), ("trigger", vp), ("target_img", vp),
                 ("noise", vp), ("timesteps", vp), ("alphas", vp), ("alphas_cumprod", vp), ("vmin", f32),
                 ("x_noisy", vp), ("ld_noisy", i64), ("target", vp), ("ld_target", i64),
-                ("R_out", vp), ("x0_out", vp), ("mask_out", vp)]
+                ("R_out", vp), ("x0_out", vp), ("mask_out", vp), ("image_out", vp)]
 
 
 class QsampleDesc(C.Structure):
@@ -131,6 +131,12 @@ SIGNATURES = {
     "bd_loss_fwd_bwd": (i32, [vp, i64, vp, i64, i64, i32, i32, f32, vp, vp, i64, vp, vp]),
     "bd_sumsq": (i32, [vp, i64, vp, vp, vp]),
     "bd_adam_clip": (i32, [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, i32, vp, vp]),
+    "bd_prof_enable": (i32, [i32]),
+    "bd_prof_reset": (i32, []),
+    "bd_prof_num_classes": (i32, []),
+    "bd_prof_get": (i32, [i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]),
+    "bd_axpy": (i32, [vp, vp, i64, f32, i32, vp]),
+    "bd_adam_clip_dev": (i32, [vp, vp, vp, vp, i64, vp, f64, vp, f64, f64, f64, vp, vp]),
     "bd_unet_create": (i32, [C.POINTER(UnetConfig), C.POINTER(vp)]),
     "bd_unet_destroy": (None, [vp]),
     "bd_unet_num_params": (i64, [vp]),

@@ -22,6 +22,7 @@ SOURCES = [  # (file, extra flags)
     ("igemm.hip", []),
     ("conv.cpp", ["-x", "hip"]),
     ("unet_plan.cpp", ["-x", "hip"]),
+    ("prof.cpp", ["-x", "hip"]),
 ]
 HEADERS = [os.path.join(CSRC, "common.h"), os.path.join(os.path.dirname(HERE), "include", "bd_hip.h")]
 

@@ -65,6 +65,9 @@ __device__ __forceinline__ float silu_grad_f(float z) {
 // ---- internal (non-ABI) launchers shared between files -------------------------------------------
 int igemm_launch(const bd_igemm_desc& d, hipStream_t stream);
 size_t igemm_workspace_bytes(const bd_igemm_desc& d);
+bool prof_on();
+int prof_begin(const char* name, double flops, double bytes, hipStream_t st);
+void prof_end(int rec, hipStream_t st);
 int add_launch(const float* src, int64_t lds, float* dst, int64_t ldd, int64_t rows, int C, float scale, int acc,
                hipStream_t st);
 

@@ -67,6 +67,7 @@ __global__ __launch_bounds__(TPB) void poison_qsample_kernel(bd_poison_qsample_d
         if (d.R_out) d.R_out[(int64_t)b * d.C * hw + chw] = R;
         if (d.x0_out) d.x0_out[(int64_t)b * d.C * hw + chw] = x0;
         if (d.mask_out && b == 0) d.mask_out[chw] = g > d.vmin ? 0 : 1;
+        if (d.image_out) d.image_out[(int64_t)b * d.C * hw + chw] = x;
     }
 }
 
@@ -367,7 +368,9 @@ __global__ void sumsq_final_kernel(const double* part, int nb, double* out) {
 // clip_grad_norm_(max_norm) + torch.optim.Adam (single-tensor formulas), flat buffers
 __global__ __launch_bounds__(TPB) void adam_clip_kernel(float* p, const float* g, float* m, float* v, int64_t n,
                                                       const double* sumsq, float max_norm, float step_size, float omb1,
-                                                      float b2, float omb2, float eps, float bc2_sqrt, float* gn_out) {
+                                                      float b2, float omb2, float eps, float bc2_sqrt, float* gn_out,
+                                                      const float* hyper) {
+    if (hyper) { step_size = hyper[0]; bc2_sqrt = hyper[1]; }
     const float norm = (float)sqrt(*sumsq);
     float coef = max_norm / (norm + 1e-6f);
     coef = fminf(coef, 1.0f);
@@ -550,7 +553,29 @@ extern "C" int bd_adam_clip(float* p, const float* g, float* m, float* v, int64_
     const double bc1 = 1.0 - pow(b1, step), bc2 = 1.0 - pow(b2, step);
     const float step_size = (float)(lr / bc1), bc2_sqrt = (float)sqrt(bc2);
     hipLaunchKernelGGL(adam_clip_kernel, dim3(nblocks(n, TPB, 8192)), dim3(TPB), 0, S(stream), p, g, m, v, n, sumsq, (float)max_norm,
-                       step_size, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, bc2_sqrt, grad_norm_out);
+                       step_size, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, bc2_sqrt, grad_norm_out,
+                       (const float*)nullptr);
     BD_LAUNCH_CHECK("adam_clip");
+    return BD_OK;
+}
+extern "C" int bd_adam_clip_dev(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq, double max_norm,
+                                const float* hyper, double b1, double b2, double eps, float* grad_norm_out, bd_stream_t stream) {
+    BD_CHECK(p && g && m && v && sumsq && hyper && n > 0, BD_ERR_INVALID, "bd_adam_clip_dev: bad args");
+    hipLaunchKernelGGL(adam_clip_kernel, dim3(nblocks(n, TPB, 8192)), dim3(TPB), 0, S(stream), p, g, m, v, n, sumsq, (float)max_norm,
+                       0.f, (float)(1.0 - b1), (float)b2, (float)(1.0 - b2), (float)eps, 1.f, grad_norm_out, hyper);
+    BD_LAUNCH_CHECK("adam_clip_dev");
+    return BD_OK;
+}
+__global__ __launch_bounds__(256) void axpy_kernel(const float* src, float* dst, int64_t n, float scale, int acc) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        float v = src[i] * scale;
+        if (acc) v += dst[i];
+        dst[i] = v;
+    }
+}
+extern "C" int bd_axpy(const float* src, float* dst, int64_t n, float scale, int accumulate, bd_stream_t stream) {
+    BD_CHECK(src && dst && n > 0, BD_ERR_INVALID, "bd_axpy: bad args");
+    hipLaunchKernelGGL(axpy_kernel, dim3(nblocks(n, TPB, 8192)), dim3(TPB), 0, S(stream), src, dst, n, scale, accumulate);
+    BD_LAUNCH_CHECK("axpy");
     return BD_OK;
 }

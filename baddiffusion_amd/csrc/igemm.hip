@@ -491,6 +491,20 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
     }
     dim3 grid(p.tiles_m * p.tiles_n, 1, nb * c.ksplit);
     BD_CHECK(grid.z <= 65535, BD_ERR_UNSUPPORTED, "igemm: batch*ksplit %u too large", grid.z);
+    int rec = -1;
+    if (prof_on()) {
+        auto op_bytes = [&](const bd_operand& o, int rows) -> double {
+            if (o.kind == BD_OPK_CONV || o.kind == BD_OPK_TCONV) {
+                const double pixels = o.kc ? (double)d.M / ((double)o.Ho * o.Wo) : (double)d.K / ((double)o.Ho * o.Wo);
+                return pixels * o.Hs * o.Ws * o.C * 4.0;
+            }
+            return (double)rows * d.K * 4.0;
+        };
+        char name[64];
+        snprintf(name, sizeof(name), "igemm_%d_%s_%s", c.tile, d.A.kc ? "kc" : "rc", d.B.kc ? "kc" : "rc");
+        rec = prof_begin(name, 2.0 * d.M * d.N * (double)d.K * nb,
+                         (op_bytes(d.A, d.M) + op_bytes(d.B, d.N) + (double)d.M * d.N * 4.0) * nb, stream);
+    }
     if (c.tile == 128) launch_tile<128>(p, d.A.kc != 0, d.B.kc != 0, grid, stream);
     else launch_tile<64>(p, d.A.kc != 0, d.B.kc != 0, grid, stream);
     BD_LAUNCH_CHECK("igemm");
@@ -499,6 +513,7 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
         hipLaunchKernelGGL(igemm_splitk_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, p, nb);
         BD_LAUNCH_CHECK("igemm_splitk_reduce");
     }
+    prof_end(rec, stream);
     return BD_OK;
 }
 

@@ -37,7 +37,7 @@ def _ld(t):
 
 # ------------------------------------------------------------------------------------------------ a-1/a-2
 def poison_qsample(images, is_poison, trigger, target_img, noise, timesteps, alphas, alphas_cumprod,
-                   vmin=-1.0, want_batch=False, want_mask=False):
+                   vmin=-1.0, want_batch=False, want_mask=False, want_image=False):
     """Fused blend + q_sample.  images: float [B,C,H,W] (normalised) or uint8 [B,H,W,C].
     Returns (x_noisy NHWC [B,H,W,C], target NHWC [B,H,W,C][, R NCHW, x0 NCHW][, mask int64 [C,H,W]])."""
     lib = L.load()
@@ -56,18 +56,21 @@ def poison_qsample(images, is_poison, trigger, target_img, noise, timesteps, alp
     R = torch.empty(B, Cc, H, W, device=dev) if want_batch else None
     x0 = torch.empty(B, Cc, H, W, device=dev) if want_batch else None
     mask = torch.empty(Cc, H, W, dtype=torch.int64, device=dev) if want_mask else None
+    image = torch.empty(B, Cc, H, W, device=dev) if want_image else None
     d = L.PoisonQsampleDesc(B=B, C=Cc, H=H, W=W, images_f32=None if u8 else L.ptr(images),
                             images_u8=L.ptr(images) if u8 else None, is_poison=L.ptr(is_poison),
                             trigger=L.ptr(trigger), target_img=L.ptr(target_img), noise=L.ptr(noise),
                             timesteps=L.ptr(timesteps), alphas=L.ptr(alphas), alphas_cumprod=L.ptr(alphas_cumprod),
                             vmin=vmin, x_noisy=L.ptr(xn), ld_noisy=Cc, target=L.ptr(tg), ld_target=Cc,
-                            R_out=L.ptr(R), x0_out=L.ptr(x0), mask_out=L.ptr(mask))
+                            R_out=L.ptr(R), x0_out=L.ptr(x0), mask_out=L.ptr(mask), image_out=L.ptr(image))
     L.check(lib.bd_poison_qsample(C.byref(d), L.stream()), "bd_poison_qsample")
     out = [xn, tg]
     if want_batch:
         out += [R, x0]
     if want_mask:
         out += [mask]
+    if want_image:
+        out += [image]
     return tuple(out)
 
 

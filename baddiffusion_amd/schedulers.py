@@ -1,0 +1,253 @@
+"""DDPMScheduler / DDIMScheduler -- drop-in for the two diffusers schedulers BadDiffusion uses
+(/root/reference/diffusers/src/diffusers/schedulers/scheduling_ddpm.py:76-481,
+ scheduling_ddim.py:79-429), with `step` / `add_noise` running as HIP kernels.
+
+Kept surface: `.betas .alphas .alphas_cumprod .timesteps .config.{num_train_timesteps,
+clip_sample (assignable), variance_type, ...} .init_noise_sigma .set_timesteps() .step(...).prev_sample
+.add_noise() .previous_timestep() ._get_variance() __len__`.
+Tables are built on the host exactly as the reference does (fp32 linspace + fp32 cumprod) and mirrored
+once to the device; `step` reads its coefficients from that device table (no per-step host scalar math,
+no host<->device sync; scheduling_ddpm.py:350-365 does ~7 host scalar extractions per step).
+Only what BadDiffusion exercises is supported: epsilon prediction, linear betas, fixed_small /
+fixed_large variance; anything else raises like the reference does for unknown options.
+"""
+import numpy as np
+import torch
+
+from . import ops
+from .unet import FrozenConfig
+
+
+class SchedulerOutput:
+    def __init__(self, prev_sample, pred_original_sample=None):
+        self.prev_sample = prev_sample
+        self.pred_original_sample = pred_original_sample
+
+
+def randn_tensor(shape, generator=None, device=None, dtype=torch.float32):
+    """utils/torch_utils.py:29-70: with a CPU generator the noise is drawn on the CPU (seed parity with
+    the reference) and copied to the device."""
+    device = torch.device(device) if device is not None else torch.device("cpu")
+    if generator is not None and generator.device.type == "cpu" and device.type != "cpu":
+        return torch.randn(shape, generator=generator, device="cpu", dtype=dtype).to(device)
+    return torch.randn(shape, generator=generator, device=device, dtype=dtype)
+
+
+class _Base:
+    order = 1
+
+    def _make_tables(self, num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas):
+        if trained_betas is not None:
+            self.betas = torch.tensor(trained_betas, dtype=torch.float32)
+        elif beta_schedule == "linear":
+            self.betas = torch.linspace(beta_start, beta_end, num_train_timesteps, dtype=torch.float32)
+        elif beta_schedule == "scaled_linear":
+            self.betas = torch.linspace(beta_start ** 0.5, beta_end ** 0.5, num_train_timesteps, dtype=torch.float32) ** 2
+        else:
+            raise NotImplementedError(f"{beta_schedule} does is not implemented for {self.__class__}")
+        self.alphas = 1.0 - self.betas
+        self.alphas_cumprod = torch.cumprod(self.alphas, dim=0)
+        self.one = torch.tensor(1.0)
+        self.init_noise_sigma = 1.0
+        self._dev = {}
+
+    def device_tables(self, device):
+        """(alphas, alphas_cumprod) on `device`, uploaded once."""
+        key = str(device)
+        if key not in self._dev:
+            self._dev[key] = (self.alphas.to(device), self.alphas_cumprod.to(device))
+        return self._dev[key]
+
+    def scale_model_input(self, sample, timestep=None):
+        return sample
+
+    def __len__(self):
+        return self.config.num_train_timesteps
+
+    def add_noise(self, original_samples, noise, timesteps):
+        # scheduling_ddpm.py:422-443  (q_sample with R = 0)
+        a, ac = self.device_tables(original_samples.device)
+        xn, _ = ops.qsample(original_samples, torch.zeros_like(original_samples), noise, timesteps, a, ac)
+        return xn.permute(0, 3, 1, 2)
+
+    @staticmethod
+    def _flat(x):
+        """dense storage view of a (possibly channels_last) tensor: the step kernels are elementwise, so any
+        layout works as long as model_output / sample / noise share it."""
+        if x.is_contiguous():
+            return x, None
+        p = x.permute(0, 2, 3, 1)
+        if p.is_contiguous():
+            return p, "nhwc"
+        return x.contiguous(), None
+
+    def _align(self, *ts):
+        """bring all tensors to one common dense layout; returns (tensors, restore_fn)."""
+        first, tag = self._flat(ts[0])
+        outs = [first]
+        for t in ts[1:]:
+            if t is None:
+                outs.append(None)
+            elif tag == "nhwc":
+                q = t.permute(0, 2, 3, 1)
+                outs.append(q if q.is_contiguous() else q.contiguous())
+            else:
+                outs.append(t.contiguous())
+        restore = (lambda y: y.permute(0, 3, 1, 2)) if tag == "nhwc" else (lambda y: y)
+        return outs, restore
+
+
+class DDPMScheduler(_Base):
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 trained_betas=None, variance_type="fixed_small", clip_sample=True, prediction_type="epsilon",
+                 thresholding=False, dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0,
+                 clip_defense=False, clip_defense_range=1.0, **unused):
+        self.config = FrozenConfig(
+            num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end, beta_schedule=beta_schedule,
+            trained_betas=trained_betas, variance_type=variance_type, clip_sample=clip_sample,
+            prediction_type=prediction_type, thresholding=thresholding,
+            dynamic_thresholding_ratio=dynamic_thresholding_ratio, clip_sample_range=clip_sample_range,
+            sample_max_value=sample_max_value, clip_defense=clip_defense, clip_defense_range=clip_defense_range)
+        self._make_tables(num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas)
+        self.custom_timesteps = False
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy())
+        self.variance_type = variance_type
+
+    def set_timesteps(self, num_inference_steps=None, device=None, timesteps=None):
+        # scheduling_ddpm.py:197-248
+        if num_inference_steps is not None and timesteps is not None:
+            raise ValueError("Can only pass one of `num_inference_steps` or `custom_timesteps`.")
+        if timesteps is not None:
+            for i in range(1, len(timesteps)):
+                if timesteps[i] >= timesteps[i - 1]:
+                    raise ValueError("`custom_timesteps` must be in descending order.")
+            if timesteps[0] >= self.config.num_train_timesteps:
+                raise ValueError(f"`timesteps` must start before `self.config.train_timesteps`: {self.config.num_train_timesteps}.")
+            timesteps = np.array(timesteps, dtype=np.int64)
+            self.custom_timesteps = True
+        else:
+            if num_inference_steps > self.config.num_train_timesteps:
+                raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than "
+                                 f"`self.config.train_timesteps`: {self.config.num_train_timesteps}")
+            self.num_inference_steps = num_inference_steps
+            step_ratio = self.config.num_train_timesteps // self.num_inference_steps
+            timesteps = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
+            self.custom_timesteps = False
+        self.timesteps = torch.from_numpy(timesteps).to(device)
+
+    def previous_timestep(self, timestep):
+        # scheduling_ddpm.py:468-481
+        if self.custom_timesteps:
+            index = (self.timesteps == timestep).nonzero(as_tuple=True)[0][0]
+            return torch.tensor(-1) if index == self.timesteps.shape[0] - 1 else self.timesteps[index + 1]
+        n = self.num_inference_steps if self.num_inference_steps else self.config.num_train_timesteps
+        return timestep - self.config.num_train_timesteps // n
+
+    def _get_variance(self, t, predicted_variance=None, variance_type=None):
+        # scheduling_ddpm.py:250-288 (host scalar; kept for API parity and the reference's KATs)
+        prev_t = self.previous_timestep(t)
+        a_t = self.alphas_cumprod[t]
+        a_prev = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.one
+        cur_beta = 1 - a_t / a_prev
+        variance = torch.clamp((1 - a_prev) / (1 - a_t) * cur_beta, min=1e-20)
+        variance_type = variance_type or self.config.variance_type
+        if variance_type == "fixed_small":
+            return variance
+        if variance_type == "fixed_large":
+            return cur_beta
+        raise NotImplementedError(f"variance_type {variance_type}: only fixed_small / fixed_large are on the BadDiffusion path")
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True, noise=None):
+        # scheduling_ddpm.py:324-420
+        if self.config.prediction_type != "epsilon":
+            raise ValueError(f"prediction_type given as {self.config.prediction_type} must be `epsilon` on the HIP path")
+        if self.config.thresholding:
+            raise NotImplementedError("dynamic thresholding is not on the BadDiffusion path")
+        if not model_output.is_cuda:
+            raise RuntimeError("DDPMScheduler.step runs on the GPU only")
+        t = int(timestep)
+        prev_t = int(self.previous_timestep(t))
+        if t > 0 and noise is None:
+            noise = randn_tensor(tuple(model_output.shape), generator=generator, device=model_output.device,
+                                 dtype=model_output.dtype)
+        (mo, sm, nz), restore = self._align(model_output, sample, noise if t > 0 else None)
+        _, ac = self.device_tables(model_output.device)
+        prev, x0 = ops.ddpm_step(mo, sm, nz, ac, t, prev_t, self.variance_type, self.config.clip_sample,
+                                 self.config.clip_sample_range, self.config.clip_defense, self.config.clip_defense_range,
+                                 want_x0=True)
+        prev, x0 = restore(prev), restore(x0)
+        if not return_dict:
+            return (prev,)
+        return SchedulerOutput(prev_sample=prev, pred_original_sample=x0)
+
+
+class DDIMScheduler(_Base):
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
+                 trained_betas=None, clip_sample=True, set_alpha_to_one=True, steps_offset=0, prediction_type="epsilon",
+                 thresholding=False, dynamic_thresholding_ratio=0.995, clip_sample_range=1.0, sample_max_value=1.0, **unused):
+        self.config = FrozenConfig(
+            num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end, beta_schedule=beta_schedule,
+            trained_betas=trained_betas, clip_sample=clip_sample, set_alpha_to_one=set_alpha_to_one,
+            steps_offset=steps_offset, prediction_type=prediction_type, thresholding=thresholding,
+            dynamic_thresholding_ratio=dynamic_thresholding_ratio, clip_sample_range=clip_sample_range,
+            sample_max_value=sample_max_value)
+        self._make_tables(num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.num_inference_steps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+
+    @classmethod
+    def from_config(cls, config):
+        """pipeline_ddim.py:39-42 re-creates a DDIM scheduler from any scheduler's config."""
+        keys = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "trained_betas", "clip_sample",
+                "set_alpha_to_one", "steps_offset", "prediction_type", "thresholding", "dynamic_thresholding_ratio",
+                "clip_sample_range", "sample_max_value")
+        return cls(**{k: config[k] for k in keys if k in config})
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        # scheduling_ddim.py:237-259
+        if num_inference_steps > self.config.num_train_timesteps:
+            raise ValueError(f"`num_inference_steps`: {num_inference_steps} cannot be larger than "
+                             f"`self.config.train_timesteps`: {self.config.num_train_timesteps}")
+        self.num_inference_steps = num_inference_steps
+        step_ratio = self.config.num_train_timesteps // self.num_inference_steps
+        timesteps = (np.arange(0, num_inference_steps) * step_ratio).round()[::-1].copy().astype(np.int64)
+        self.timesteps = torch.from_numpy(timesteps).to(device)
+        self.timesteps += self.config.steps_offset
+
+    def _get_variance(self, timestep, prev_timestep):
+        a_t = self.alphas_cumprod[timestep]
+        a_prev = self.alphas_cumprod[prev_timestep] if prev_timestep >= 0 else self.final_alpha_cumprod
+        return ((1 - a_prev) / (1 - a_t)) * (1 - a_t / a_prev)
+
+    def step(self, model_output, timestep, sample, eta=0.0, use_clipped_model_output=False, generator=None,
+             variance_noise=None, return_dict=True):
+        # scheduling_ddim.py:261-381
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if self.config.prediction_type != "epsilon":
+            raise ValueError(f"prediction_type given as {self.config.prediction_type} must be `epsilon` on the HIP path")
+        if self.config.thresholding:
+            raise NotImplementedError("dynamic thresholding is not on the BadDiffusion path")
+        if use_clipped_model_output:
+            raise NotImplementedError("use_clipped_model_output is not on the BadDiffusion path")
+        if not model_output.is_cuda:
+            raise RuntimeError("DDIMScheduler.step runs on the GPU only")
+        t = int(timestep)
+        prev_t = t - self.config.num_train_timesteps // self.num_inference_steps
+        if eta > 0:
+            if variance_noise is not None and generator is not None:
+                raise ValueError("Cannot pass both generator and variance_noise.")
+            if variance_noise is None:
+                variance_noise = randn_tensor(tuple(model_output.shape), generator=generator, device=model_output.device,
+                                              dtype=model_output.dtype)
+        (mo, sm, nz), restore = self._align(model_output, sample, variance_noise if eta > 0 else None)
+        _, ac = self.device_tables(model_output.device)
+        prev, x0 = ops.ddim_step(mo, sm, ac, t, prev_t, eta=float(eta), noise=nz, clip_sample=self.config.clip_sample,
+                                 clip_sample_range=self.config.clip_sample_range,
+                                 final_alpha_cumprod=float(self.final_alpha_cumprod), want_x0=True)
+        prev, x0 = restore(prev), restore(x0)
+        if not return_dict:
+            return (prev,)
+        return SchedulerOutput(prev_sample=prev, pred_original_sample=x0)

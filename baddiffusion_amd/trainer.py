@@ -1,0 +1,120 @@
+"""Fused BadDiffusion train step (e): the loop body of /root/reference/baddiffusion.py:590-615
+as one launch sequence on the GPU, data-parallel over one process per GPU.
+
+    poison-blend + q_sample  ->  UNet forward  ->  MSE + dL/dpred  ->  UNet backward (segment by segment,
+    each finished gradient range all-reduced over RCCL while the next segment computes)  ->
+    global-norm clip + Adam on the flat parameter buffer.
+
+No host synchronisation inside a step (the loss stays a device scalar; call .item() when you log).
+Replaces: torch.optim.Adam (:320), clip_grad_norm_ (:612), get_cosine_schedule_with_warmup
+(diffusers/optimization.py:109-140), nn.DataParallel (:325) -> RCCL all-reduce of the flat gradient.
+"""
+import ctypes
+import math
+
+import torch
+import torch.distributed as dist
+
+from . import _lib as L
+from . import ops
+
+
+def cosine_schedule_with_warmup(step, num_warmup_steps, num_training_steps, num_cycles=0.5):
+    """LR multiplier of diffusers/optimization.py:134-138."""
+    if step < num_warmup_steps:
+        return float(step) / float(max(1, num_warmup_steps))
+    progress = float(step - num_warmup_steps) / float(max(1, num_training_steps - num_warmup_steps))
+    return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
+
+
+class TrainEngine:
+    def __init__(self, model, noise_sched, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
+                 lr_warmup_steps=500, num_training_steps=None, loss_type="l2", process_group=None,
+                 grad_accum_steps=1):
+        if not model.flat.is_cuda:
+            raise RuntimeError("TrainEngine needs the model on a GPU")
+        self.model, self.sched = model, noise_sched
+        self.lr, self.betas, self.eps, self.max_grad_norm = lr, betas, eps, max_grad_norm
+        self.warmup, self.total_steps = lr_warmup_steps, num_training_steps
+        self.loss_type = loss_type
+        self.pg = process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.accum = int(grad_accum_steps)
+        dev = model.flat.device
+        n = model.num_flat
+        self.grads = torch.zeros(n, device=dev)          # written by backward (padding stays 0)
+        self.acc = torch.zeros(n, device=dev) if self.accum > 1 else None
+        self.m = torch.zeros(n, device=dev)
+        self.v = torch.zeros(n, device=dev)
+        self.sumsq = torch.zeros((), dtype=torch.float64, device=dev)
+        self.grad_norm = torch.zeros((), device=dev)
+        self.opt_step = 0      # optimizer steps taken
+        self.micro = 0
+        self._lib = L.load()
+        self._nseg = self._lib.bd_unet_num_segments(model._plan)
+        self.alphas, self.alphas_cumprod = noise_sched.device_tables(dev)
+
+    # ---- LR schedule (host scalar; baddiffusion.py:327-331) ------------------------------------------
+    def current_lr(self):
+        if self.total_steps is None:
+            return self.lr
+        return self.lr * cosine_schedule_with_warmup(self.opt_step, self.warmup, self.total_steps)
+
+    # ---- pieces ---------------------------------------------------------------------------------------
+    def forward_backward(self, xn, tg, t):
+        """xn / tg NHWC [B,H,W,C] ; fills self.grads (already all-reduced when world > 1); returns loss."""
+        model = self.model
+        flat = model.flat.data
+        pred, ws = model._run_forward(flat, xn, t, training=True)
+        loss, dpred = ops.loss_fwd_bwd(pred, tg, self.loss_type, grad_scale=1.0 / (self.world * self.accum))
+        B = xn.shape[0]
+        works = []
+        lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        for s in range(self._nseg):
+            L.check(self._lib.bd_unet_backward_segment(
+                model._plan, s, B, flat.data_ptr(), xn.data_ptr(), xn.shape[-1], dpred.data_ptr(), dpred.shape[-1],
+                self.grads.data_ptr(), ws.data_ptr(), ws.numel(), L.stream(), ctypes.byref(lo), ctypes.byref(hi)),
+                "bd_unet_backward_segment")
+            if self.world > 1 and hi.value > lo.value:
+                # the collective waits (on its own stream) for the kernels enqueued so far, then overlaps
+                # with the next segments; 143 MB total per step for the CIFAR UNet
+                works.append(dist.all_reduce(self.grads[lo.value: hi.value], group=self.pg, async_op=True))
+        for w in works:
+            w.wait()
+        model._release_ws(ws)
+        return loss
+
+    def optimizer_step(self, grads):
+        self.opt_step += 1
+        lr = self.current_lr() if self.total_steps is None else \
+            self.lr * cosine_schedule_with_warmup(self.opt_step - 1, self.warmup, self.total_steps)
+        ops.sumsq(grads, out=self.sumsq)
+        ops.adam_clip(self.model.flat.data, grads, self.m, self.v, self.sumsq, self.opt_step, lr, self.max_grad_norm,
+                      self.betas, self.eps, grad_norm_out=self.grad_norm)
+
+    # ---- the train step -----------------------------------------------------------------------------------
+    def train_step(self, images, is_poison, trigger, target_img, noise, timesteps):
+        """images: uint8 [B,H,W,C] or float [B,C,H,W] on the GPU; is_poison bool [B]; trigger/target [C,H,W];
+        noise [B,C,H,W]; timesteps int64 [B].  Returns the (local) loss as a device scalar."""
+        xn, tg = ops.poison_qsample(images, is_poison, trigger, target_img, noise, timesteps, self.alphas,
+                                    self.alphas_cumprod)
+        return self.step_from_noisy(xn, tg, timesteps)
+
+    def train_step_batch(self, x_start, R, noise, timesteps):
+        """The reference's calling convention (baddiffusion.py:593-607): collated x_start / R batches."""
+        xn, tg = ops.qsample(x_start, R, noise, timesteps, self.alphas, self.alphas_cumprod)
+        return self.step_from_noisy(xn, tg, timesteps)
+
+    def step_from_noisy(self, xn, tg, timesteps):
+        t = timesteps.to(torch.int64).contiguous()
+        loss = self.forward_backward(xn, tg, t)
+        self.micro += 1
+        if self.accum > 1:
+            lib = self._lib
+            L.check(lib.bd_axpy(self.grads.data_ptr(), self.acc.data_ptr(), self.grads.numel(), 1.0,
+                                int(self.micro % self.accum != 1), L.stream()), "bd_axpy")
+            if self.micro % self.accum == 0:
+                self.optimizer_step(self.acc)
+        else:
+            self.optimizer_step(self.grads)
+        return loss

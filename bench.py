@@ -1,0 +1,187 @@
+"""bench.py -- headline benchmark of the BadDiffusion hot path on MI355X.
+
+metric (BASELINE.json): train images/sec of the 32x32 UNet (DDPM-CIFAR10-32 topology), batch 128 per GPU,
+poison_rate 0.1, BOX_14 trigger, fp32, synthetic data.  One "step" = poison-blend + q_sample -> UNet forward
+-> MSE -> UNet backward (+ RCCL all-reduce of the 143 MB flat gradient when N > 1) -> clip + Adam.
+
+    python bench.py --gpus 1 --steps 20 --warmup 5
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  Inputs (uint8 images, noise, timesteps) are resident in HBM before the timed
+region.  `roofline` is measured live with hipEvent pairs around every igemm launch (bd_prof_*), `cpu_baseline`
+is the CPU oracle (pure PyTorch fp32 restatement of the reference path) timed on this box's host cores.
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+TRAIN_GFLOP_PER_IMG = 37.324          # SURVEY 8d (fwd+bwd, 2*MAC of conv/GEMM/BMM), CIFAR-32 UNet
+FP32_MFMA_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+HBM_PEAK_GBS = 8000.0
+
+
+def cpu_baseline(seconds_budget=25.0):
+    """The reference CPU path = the oracle's fp32 restatement (oracle/), config 1: batch 16, poison 0.0."""
+    from oracle import sched_ref, train_ref
+    from oracle import unet_ref as U
+    cfg = U.CIFAR10_32
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    P = U.gen_params(cfg, 0)
+    _, a, ac = sched_ref.make_tables()
+    B = 16
+    g = torch.Generator().manual_seed(0)
+    x0 = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    R = torch.zeros_like(x0)
+    eps = torch.randn(B, 3, 32, 32, generator=g)
+    t = torch.randint(0, 1000, (B,), generator=g)
+    state = {}
+    times = []
+    t_start = time.time()
+    step = 0
+    while True:
+        t0 = time.time()
+        loss, G = train_ref.loss_and_grads(cfg, P, a, ac, x0, R, t, eps)
+        P, state, _ = train_ref.clip_and_adam(P, G, state, 2e-4, step + 1)
+        dt = time.time() - t0
+        step += 1
+        if step > 2:
+            times.append(dt)
+        if (time.time() - t_start > seconds_budget and len(times) >= 3) or len(times) >= 10:
+            break
+    times.sort()
+    med = times[len(times) // 2]
+    return {"value": B / med, "unit": "images/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{len(times)} timed train steps (after 2 warm-up) of the CIFAR-32 UNet, batch {B}, poison_rate 0.0, "
+                      f"fp32, oracle/train_ref.py (median {med:.3f} s/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-prof", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    else:
+        torch.cuda.set_device(0)
+    dev = torch.device("cuda", local_rank if world > 1 else 0)
+    assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+
+    from baddiffusion_amd import _lib as L
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    from baddiffusion_amd.unet import UNet2DModel
+
+    # DDPM-CIFAR10-32 topology, torch default init with seed 0 (no hub weights offline)
+    torch.manual_seed(0)
+    model = UNet2DModel(sample_size=32, in_channels=3, out_channels=3, block_out_channels=(128, 256, 256, 256),
+                        down_block_types=("DownBlock2D", "AttnDownBlock2D", "DownBlock2D", "DownBlock2D"),
+                        up_block_types=("UpBlock2D", "UpBlock2D", "AttnUpBlock2D", "UpBlock2D"), layers_per_block=2,
+                        downsample_padding=0, flip_sin_to_cos=False, freq_shift=1, norm_eps=1e-6,
+                        attention_head_dim=None).to(dev)
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    B = args.batch
+    eng = TrainEngine(model, sched, lr=2e-4, lr_warmup_steps=500, num_training_steps=469 * 50)
+
+    # synthetic CIFAR-like data, resident in HBM: uint8 images, BOX_14 trigger, CORNER target (HAT stand-in:
+    # static/fedora-hat.png is a reference asset and does not travel), poison flags i % 10 == 0
+    from baddiffusion_amd.dataset import Backdoor
+    bd = Backdoor(root=None)
+    trigger = bd.get_trigger("BOX_14", 3, 32).to(dev)
+    target = bd.get_target("CORNER", trigger.cpu()).to(dev)
+    NIMG = 8192
+    g = torch.Generator().manual_seed(1000 + rank)
+    images = torch.randint(0, 256, (NIMG, 32, 32, 3), generator=g, dtype=torch.uint8).to(dev)
+    flags = (torch.arange(NIMG) % 10 == 0).to(dev)
+    NPOOL = 8
+    noise = torch.randn(NPOOL, B, 3, 32, 32, generator=g).to(dev)
+    ts = torch.randint(0, 1000, (NPOOL, B), generator=g).to(dev)
+
+    def step(i):
+        s = (i * B) % (NIMG - B + 1)
+        return eng.train_step(images[s:s + B], flags[s:s + B], trigger, target, noise[i % NPOOL], ts[i % NPOOL])
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    lib = L.load()
+    for i in range(args.warmup):
+        loss = step(i)
+    barrier()
+    if not args.no_prof:
+        lib.bd_prof_reset(); lib.bd_prof_enable(1)
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        loss = step(args.warmup + i)
+    barrier()
+    dt = time.perf_counter() - t0
+    lib.bd_prof_enable(0)
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    final_loss = float(loss)
+
+    if rank == 0:
+        ms = dt / args.steps * 1e3
+        value = world * B * args.steps / dt
+        out = {"metric": "train images/sec (32x32 UNet, DDPM-CIFAR10-32 topology, bs128/GPU, poison_rate 0.1)",
+               "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "data": "synthetic (uint8 32x32x3 images resident in HBM, seeded default-init weights)",
+               "config": {"workload": "BASELINE configs[1]: CIFAR10 DDPM-CIFAR10-32 train step, batch 128/GPU, poison_rate 0.1, "
+                                      "BOX_14 trigger, CORNER target (HAT stand-in), clip 1.0 + Adam, fp32",
+                          "global_batch": world * B, "parallelism": f"dp{world}", "params": 35746307},
+               "final_loss": final_loss,
+               "step_tflops": TRAIN_GFLOP_PER_IMG * B * world / (ms * 1e-3) / 1e3,
+               "step_frac_of_fp32_mfma_peak": TRAIN_GFLOP_PER_IMG * B / (ms * 1e-3) / 1e3 / FP32_MFMA_PEAK_TFLOPS}
+        if not args.no_prof:
+            classes = []
+            for c in range(lib.bd_prof_num_classes()):
+                name = ctypes.c_char_p(); n = ctypes.c_int64(); tms = ctypes.c_double(); fl = ctypes.c_double(); by = ctypes.c_double()
+                lib.bd_prof_get(c, ctypes.byref(name), ctypes.byref(n), ctypes.byref(tms), ctypes.byref(fl), ctypes.byref(by))
+                classes.append({"kernel": name.value.decode(), "launches": n.value, "ms": tms.value, "flops": fl.value, "bytes": by.value})
+            classes.sort(key=lambda c: -c["ms"])
+            if classes:
+                d = classes[0]
+                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+                out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
+                                   "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                                   "launches_per_step": d["launches"] / args.steps,
+                                   "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+                                   "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                                   "alg_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
+                                   "share_of_step": d["ms"] / (dt * 1e3)}
+                out["kernel_classes"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in classes]
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -63,6 +63,7 @@ typedef struct {
     float* R_out;                 /* optional NCHW [B,C,H,W] (pixel_values), may be NULL      */
     float* x0_out;                /* optional NCHW [B,C,H,W] (target), may be NULL            */
     int64_t* mask_out;            /* optional [C,H,W] int64 mask (bit-exact check), may be NULL */
+    float* image_out;             /* optional NCHW [B,C,H,W] normalised image x, may be NULL  */
 } bd_poison_qsample_desc;
 int bd_poison_qsample(const bd_poison_qsample_desc* d, bd_stream_t stream);
 
@@ -301,6 +302,25 @@ int bd_unet_num_segments(const bd_unet* u);
 int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float* params, const float* x, int64_t ldx,
                              const float* dout, int64_t lddo, float* grads, void* workspace, size_t workspace_bytes,
                              bd_stream_t stream, int64_t* ready_lo, int64_t* ready_hi);
+
+/* ------------------------------------------------------------------------------------------------
+ * Measurement hooks (bench.py `roofline`): when enabled, every igemm launch is bracketed by a
+ * hipEvent pair on its own stream; totals are kept per kernel class ("igemm_<tile>_<A>_<B>").
+ * flops = 2*M*N*K algorithmic ; bytes = unique operand + output bytes (algorithmic, fp32).
+ * ------------------------------------------------------------------------------------------------ */
+int bd_prof_enable(int on);
+int bd_prof_reset(void);
+int bd_prof_num_classes(void);
+int bd_prof_get(int cls, const char** name, int64_t* launches, double* total_ms, double* flops, double* bytes);
+
+/* dst[i] (+)= scale * src[i] over a flat fp32 range (gradient accumulation across micro-batches). */
+int bd_axpy(const float* src, float* dst, int64_t n, float scale, int accumulate, bd_stream_t stream);
+
+/* bd_adam_clip with the step-dependent scalars read from DEVICE memory (hipGraph replay):
+ * hyper = { lr / (1 - b1^step), sqrt(1 - b2^step) } */
+int bd_adam_clip_dev(float* p, const float* g, float* m, float* v, int64_t n, const double* sumsq,
+                     double max_norm, const float* hyper, double b1, double b2, double eps,
+                     float* grad_norm_out, bd_stream_t stream);
 
 #ifdef __cplusplus
 }

@@ -55,7 +55,11 @@ def test_poison_qsample(ops, S, trig, tgt, golden):
             assert np.array_equal(mask.cpu().numpy(), golden("backdoor")[f"mask_{trig}_32"])
         close(Rg, Rr, 0, 1e-6); close(x0g, x0, 0, 1e-6)
         close(xn.permute(0, 3, 1, 2), xn_ref, 1e-6, 1e-6)
-        close(tg.permute(0, 3, 1, 2), tg_ref, 1e-6, 1e-6)
+        # rho_t = (1 - sqrt(alpha_t)) * s / (1 - alpha_t) (loss.py:270) cancels catastrophically, so its last
+        # ~2 decimal digits depend on how the HOST's torch build rounds pow(x, 0.5) (observed: 7e-6 relative
+        # between two x86 hosts).  The kernel evaluates it with correctly-rounded IEEE sqrt/div (bit-equal to the
+        # golden vectors, test_qsample_golden / test_rho_ieee); against a live CPU oracle allow 1e-5.
+        close(tg.permute(0, 3, 1, 2), tg_ref, 1e-5, 1e-5)
 
 
 def test_qsample_golden(ops, golden):
@@ -65,6 +69,18 @@ def test_qsample_golden(ops, golden):
     xn, tg = ops.qsample(dev(x0), dev(Rr), dev(eps), dev(t), dev(a), dev(ac))
     close(xn.permute(0, 3, 1, 2), g["x_noisy"], 1e-6, 1e-7)
     close(tg.permute(0, 3, 1, 2), g["target"], 1e-6, 1e-7)
+
+
+def test_rho_ieee(ops):
+    # target = rho_t * 1 + 0 for every t: bit-equal to the correctly-rounded fp32 evaluation of loss.py:268-270
+    _, a, ac = sched_ref.make_tables()
+    t = torch.arange(1000)
+    one = torch.ones(1000, 1, 1, 1); zero = torch.zeros(1000, 1, 1, 1)
+    xn, tg = ops.qsample(dev(zero), dev(one), dev(zero), dev(t), dev(a), dev(ac))
+    an, acn, f = a.numpy(), ac.numpy(), np.float32
+    rho = (f(1) - np.sqrt(an)) * np.sqrt(f(1) - acn) / (f(1) - an)
+    assert np.array_equal(tg.flatten().cpu().numpy(), rho)
+    assert np.array_equal(xn.flatten().cpu().numpy(), f(1) - np.sqrt(acn))
 
 
 def test_layout_roundtrip(ops):
@@ -123,10 +139,11 @@ def test_to_image(ops):
 def test_timestep_embedding(ops, golden):
     g = golden("temb")
     t = torch.tensor(C.TEMB_TS)
-    close(ops.timestep_embedding(dev(t), 128, False, 1), g["cifar"], 2e-5, 2e-5)
-    close(ops.timestep_embedding(dev(t), 128, True, 0), g["default"], 2e-5, 2e-5)
+    # sin/cos arguments reach t*f ~ 1e3, where ONE ulp of expf() in f moves the argument by 6e-5: atol 2e-4
+    close(ops.timestep_embedding(dev(t), 128, False, 1), g["cifar"], 0, 2e-4)
+    close(ops.timestep_embedding(dev(t), 128, True, 0), g["default"], 0, 2e-4)
     t = torch.arange(1000)
-    close(ops.timestep_embedding(dev(t), 128, False, 1), U.timestep_embedding(t, 128, False, 1), 5e-5, 5e-5)
+    close(ops.timestep_embedding(dev(t), 128, False, 1), U.timestep_embedding(t, 128, False, 1), 0, 2e-4)
 
 
 # ------------------------------------------------------------------------------------------ GroupNorm

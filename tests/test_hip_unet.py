@@ -89,7 +89,13 @@ def _train_step(bd, cfg, seed, B, tag, g, lr=2e-4):
     np.testing.assert_allclose(g8, g[f"{tag}_grad8"], rtol=2e-3, atol=2e-3 * float(np.abs(g[f"{tag}_grad8"]).max()))
     # full-tensor gradient check against the oracle's autograd
     _, G = train_ref.loss_and_grads(cfg, U.gen_params(cfg, seed), a, ac, x0, R, t, eps)
-    worst = max((relerr(grads[k], G[k]), k) for k in names)
+    # (key.bias gradients are mathematically zero -- softmax is shift-invariant -- so they are pure rounding
+    #  noise on both sides: judge every tensor against 1e-3 of its own norm OR 1e-6 of the global grad norm)
+    total = float(torch.sqrt(sum((v.double() ** 2).sum() for v in G.values())))
+    def err(k):
+        d = float((grads[k].detach().cpu().double() - G[k].double()).norm())
+        return d / max(float(G[k].double().norm()), 1e-3 * total)
+    worst = max((err(k), k) for k in names)
     assert worst[0] < 1e-3, worst
     # clip + Adam on the flat buffers
     flat = m.flat.data; gflat = m.flat.grad
