@@ -424,15 +424,16 @@ static Choice choose(const bd_igemm_desc& d) {
     Choice c;
     const int nb = d.batch_outer * d.batch_inner;
     auto tiles = [&](int t) { return cdiv(d.M, t) * cdiv(d.N, t) * nb; };
-    c.tile = d.tile ? d.tile : ((d.M >= 128 && d.N >= 128 && tiles(128) >= 192) ? 128 : 64);
+    // 128x128 tiles (32 flop per staged byte) whenever both dims allow; split K to put >= ~1.5 workgroups on each CU
+    c.tile = d.tile ? d.tile : ((d.M >= 128 && d.N >= 128) ? 128 : 64);
     const int nchunks = (int)cdiv(d.K, BK);
     int ks = d.ksplit;
     if (ks <= 0) {
         long long t = tiles(c.tile);
         ks = 1;
         if (t < 256) {
-            ks = (int)cdiv(512, t);
-            int maxks = nchunks / 4;
+            ks = (int)cdiv(384, t);
+            int maxks = nchunks / 8;
             if (maxks < 1) maxks = 1;
             if (ks > maxks) ks = maxks;
             if (ks > 128) ks = 128;
