@@ -170,43 +170,45 @@ __global__ void gn_bwd_stats_kernel(const float* __restrict__ x, long long ldx, 
             a += sh[(pr * C + c) * 2 + 0];
             e += sh[(pr * C + c) * 2 + 1];
         }
-        float* o = part + (((long long)b * S + s) * C + c) * 2;
-        o[0] = a;
-        o[1] = e;
+        float* o = part + ((long long)b * S + s) * 2 * C + c;
+        o[0] = e;   // plane 0: sum dz * xhat  -> dgamma
+        o[C] = a;   // plane 1: sum dz         -> dbeta
     }
 }
 
-// ---- backward finalize: role A (blocks [0, nbc)): dgamma/dbeta per channel; role B: (b,g) sums -------
-__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, int B, int S, int C, int G,
-                                                            const float* __restrict__ gamma, int nbc,
-                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                                            float* __restrict__ ds /* [B][G][2] */) {
-    if ((int)blockIdx.x < nbc) {
-        const int c = blockIdx.x * 256 + threadIdx.x;
-        if (c >= C) return;
-        double a = 0.0, e = 0.0;
-        for (int bs = 0; bs < B * S; ++bs) {
-            const float* p = part + ((long long)bs * C + c) * 2;
-            a += (double)p[0];
-            e += (double)p[1];
-        }
-        dbeta[c] = (float)a;
-        dgamma[c] = (float)e;
-    } else {
-        const int i = (blockIdx.x - nbc) * 256 + threadIdx.x;
-        if (i >= B * G) return;
-        const int b = i / G, g = i - b * G;
-        const int cpg = C / G;
-        double a = 0.0, e = 0.0;
-        for (int s = 0; s < S; ++s)
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-                const float* p = part + (((long long)b * S + s) * C + c) * 2;
-                a += (double)p[0] * gamma[c];
-                e += (double)p[1] * gamma[c];
-            }
-        ds[i * 2 + 0] = (float)a;
-        ds[i * 2 + 1] = (float)e;
+// ---- backward finalize -----------------------------------------------------------------------------
+// (a) dgamma/dbeta[c] = sum over the B*S partial rows: 64 columns x 4 row phases per block, fixed order
+__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ part, int rows, int C,
+                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double red[4][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + tx;   // column in [0, 2C): plane 0 = dgamma, plane 1 = dbeta
+    double s = 0.0;
+    if (n < 2 * C)
+        for (int r = ty; r < rows; r += 4) s += (double)part[(long long)r * 2 * C + n];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < 2 * C) {
+        const float v = (float)((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
+        if (n < C) dgamma[n] = v; else dbeta[n - C] = v;
     }
+}
+// (b) per (b, g): s1 = sum gamma*dz, s2 = sum gamma*dz*xhat
+__global__ __launch_bounds__(256) void gn_bwd_group_kernel(const float* __restrict__ part, int B, int S, int C, int G,
+                                                         const float* __restrict__ gamma, float* __restrict__ ds) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= B * G) return;
+    const int b = i / G, g = i - b * G;
+    const int cpg = C / G;
+    double a = 0.0, e = 0.0;
+    for (int s = 0; s < S; ++s)
+        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+            const float* p = part + ((long long)b * S + s) * 2 * C + c;
+            e += (double)p[0] * gamma[c];
+            a += (double)p[C] * gamma[c];
+        }
+    ds[i * 2 + 0] = (float)a;
+    ds[i * 2 + 1] = (float)e;
 }
 
 // ---- backward apply: dx (+)= rstd * (dz*gamma - (s1 + xhat*s2)/n) -----------------------------------
@@ -315,10 +317,12 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
                        (long long)d->ldx, d->dy, (long long)d->lddy, d->HW, d->C, d->G, r, S_, d->gamma, d->beta, d->mean,
                        d->rstd, d->silu, part);
     BD_LAUNCH_CHECK("gn_bwd_stats");
-    const int nbc = (int)cdiv(d->C, 256), nbg = (int)cdiv(d->B * d->G, 256);
-    hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(nbc + nbg), dim3(256), 0, S(stream), part, d->B, S_, d->C, d->G, d->gamma,
-                       nbc, d->dgamma, d->dbeta, ds);
-    BD_LAUNCH_CHECK("gn_bwd_finalize");
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(256), 0, S(stream), part, d->B * S_, d->C,
+                       d->dgamma, d->dbeta);
+    BD_LAUNCH_CHECK("gn_bwd_param");
+    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((unsigned)cdiv(d->B * d->G, 256)), dim3(256), 0, S(stream), part, d->B, S_, d->C,
+                       d->G, d->gamma, ds);
+    BD_LAUNCH_CHECK("gn_bwd_group");
     const long long total4 = (long long)d->B * d->HW * (d->C / 4);
     long long nb = cdiv(total4, 256);
     if (nb > 16384) nb = 16384;

@@ -30,16 +30,28 @@ FP32_MFMA_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_
 HBM_PEAK_GBS = 8000.0
 
 
+def _host_cores():
+    """Usable host cores: affinity mask capped by the cgroup CPU quota (the GPU boxes expose 256 hardware
+    threads but a 16-CPU quota; running 256 OpenMP threads there is ~50x slower than running 16)."""
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    try:
+        q, p = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            cores = min(cores, max(1, int(int(q) / int(p))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(cores, int(os.environ.get("BD_CPU_THREADS", cores))))
+
+
 def _cpu_baseline_worker():
     """Child process: time oracle train steps (config 1: batch 16, poison 0.0) and print one JSON line per step."""
     from oracle import sched_ref, train_ref
     from oracle import unet_ref as U
     cfg = U.CIFAR10_32
-    try:
-        cores = len(os.sched_getaffinity(0))
-    except AttributeError:
-        cores = os.cpu_count() or 1
-    cores = max(1, min(cores, int(os.environ.get("BD_CPU_THREADS", cores))))
+    cores = _host_cores()
     torch.set_num_threads(cores)
     P = U.gen_params(cfg, 0)
     _, a, ac = sched_ref.make_tables()
