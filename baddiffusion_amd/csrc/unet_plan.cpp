@@ -865,6 +865,12 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
 }
 
 extern "C" int bd_unet_num_segments(const bd_unet* u) { return u ? (int)u->segs.size() : 0; }
+extern "C" int bd_unet_segment_range(const bd_unet* u, int seg, int64_t* lo, int64_t* hi) {
+    BD_CHECK(u && seg >= 0 && seg < (int)u->segs.size(), BD_ERR_INVALID, "bd_unet_segment_range: segment out of range");
+    if (lo) *lo = u->segs[seg].lo;
+    if (hi) *hi = u->segs[seg].hi;
+    return BD_OK;
+}
 
 extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float* params, const float* x, int64_t ldx,
                                         const float* dout, int64_t lddo, float* grads, void* workspace, size_t workspace_bytes,

@@ -1,0 +1,265 @@
+"""DiffuserModelSched + batch sampling helpers -- drop-in for /root/reference/model.py:466-729.
+
+`get_pretrained / get_trained / get_model_sched` return `(model, noise_sched, get_pipeline)` like the
+reference; checkpoints are read from a LOCAL diffusers-layout directory (no network here):
+    <dir>/model_index.json, <dir>/unet/config.json, <dir>/unet/diffusion_pytorch_model.{bin,safetensors},
+    <dir>/scheduler/scheduler_config.json            (utils/constants.py:22-26, scheduling_utils.py:25)
+Hub ids ("google/ddpm-cifar10-32") are resolved against $BD_CKPT_ROOT / $HF_HOME-style local folders; when the
+weights are not available the documented topology is built with default init and `model.pretrained = False`.
+"""
+import json
+import os
+from typing import Union
+
+import numpy as np
+import torch
+
+from .pipelines import DDIMPipeline, DDPMPipeline
+from .schedulers import DDIMScheduler, DDPMScheduler
+from .unet import UNet2DModel
+
+WEIGHTS_NAME = "diffusion_pytorch_model.bin"
+SAFETENSORS_WEIGHTS_NAME = "diffusion_pytorch_model.safetensors"
+CONFIG_NAME = "config.json"
+SCHEDULER_CONFIG_NAME = "scheduler_config.json"
+
+# architecture kwargs of the hub checkpoints the reference uses (validated by parameter counts)
+KNOWN_TOPOLOGIES = {
+    "google/ddpm-cifar10-32": dict(
+        sample_size=32, in_channels=3, out_channels=3, block_out_channels=(128, 256, 256, 256),
+        down_block_types=("DownBlock2D", "AttnDownBlock2D", "DownBlock2D", "DownBlock2D"),
+        up_block_types=("UpBlock2D", "UpBlock2D", "AttnUpBlock2D", "UpBlock2D"), layers_per_block=2,
+        downsample_padding=0, flip_sin_to_cos=False, freq_shift=1, norm_eps=1e-6, attention_head_dim=None),
+    "google/ddpm-ema-celebahq-256": dict(
+        sample_size=256, in_channels=3, out_channels=3, block_out_channels=(128, 128, 256, 256, 512, 512),
+        down_block_types=("DownBlock2D",) * 4 + ("AttnDownBlock2D", "DownBlock2D"),
+        up_block_types=("UpBlock2D", "AttnUpBlock2D") + ("UpBlock2D",) * 4, layers_per_block=2,
+        downsample_padding=0, flip_sin_to_cos=False, freq_shift=1, norm_eps=1e-6, attention_head_dim=None),
+}
+KNOWN_TOPOLOGIES["google/ddpm-ema-church-256"] = KNOWN_TOPOLOGIES["google/ddpm-ema-celebahq-256"]
+KNOWN_TOPOLOGIES["google/ddpm-ema-bedroom-256"] = KNOWN_TOPOLOGIES["google/ddpm-ema-celebahq-256"]
+KNOWN_SCHEDULERS = {   # hub scheduler configs (verify when assets are available)
+    "google/ddpm-cifar10-32": dict(variance_type="fixed_large", clip_sample=True),
+    "google/ddpm-ema-celebahq-256": dict(variance_type="fixed_small", clip_sample=True),
+}
+
+
+# ------------------------------------------------------------------------------------------------ I/O (f-2)
+def save_unet(unet, directory):
+    os.makedirs(directory, exist_ok=True)
+    cfg = {k: (list(v) if isinstance(v, tuple) else v) for k, v in unet.config_dict().items()}
+    with open(os.path.join(directory, CONFIG_NAME), "w") as f:
+        json.dump(cfg, f, indent=2, sort_keys=True)
+    sd = {k: v.cpu() for k, v in unet.state_dict().items()}
+    torch.save(sd, os.path.join(directory, WEIGHTS_NAME))
+
+
+def load_unet(directory, device=None):
+    with open(os.path.join(directory, CONFIG_NAME)) as f:
+        cfg = json.load(f)
+    cfg = {k: v for k, v in cfg.items() if not k.startswith("_")}
+    unet = UNet2DModel(**cfg)
+    st = os.path.join(directory, SAFETENSORS_WEIGHTS_NAME)
+    if os.path.exists(st):
+        from safetensors.torch import load_file
+        sd = load_file(st)
+    else:
+        sd = torch.load(os.path.join(directory, WEIGHTS_NAME), map_location="cpu")
+    unet.load_state_dict(sd)
+    unet.pretrained = True
+    return unet.to(device) if device is not None else unet
+
+
+def save_scheduler(sched, directory):
+    os.makedirs(directory, exist_ok=True)
+    cfg = dict(sched.config)
+    cfg["_class_name"] = type(sched).__name__
+    cfg["_diffusers_version"] = "0.16.0.dev0"
+    with open(os.path.join(directory, SCHEDULER_CONFIG_NAME), "w") as f:
+        json.dump(cfg, f, indent=2, sort_keys=True)
+
+
+def load_scheduler(directory):
+    with open(os.path.join(directory, SCHEDULER_CONFIG_NAME)) as f:
+        cfg = json.load(f)
+    cls = {"DDPMScheduler": DDPMScheduler, "DDIMScheduler": DDIMScheduler}.get(cfg.get("_class_name", "DDPMScheduler"))
+    if cls is None:
+        raise NotImplementedError(f"scheduler {cfg.get('_class_name')} is not on the BadDiffusion hot path")
+    return cls(**{k: v for k, v in cfg.items() if not k.startswith("_")})
+
+
+def _resolve_local(ckpt_id):
+    """A diffusers-layout directory for `ckpt_id`, or None."""
+    cands = [ckpt_id]
+    for root in (os.environ.get("BD_CKPT_ROOT"), "checkpoints", os.path.expanduser("~/.cache/baddiffusion")):
+        if root:
+            cands += [os.path.join(root, ckpt_id), os.path.join(root, ckpt_id.replace("/", "--"))]
+    for c in cands:
+        if c and os.path.isdir(c) and os.path.exists(os.path.join(c, "unet", CONFIG_NAME)):
+            return c
+    return None
+
+
+# ------------------------------------------------------------------------------------------------ sampling helpers
+def batch_sampling(sample_n: int, pipeline, init: torch.Tensor = None, max_batch_n: int = 256, rng: torch.Generator = None):
+    # model.py:469-490
+    if init is None:
+        if sample_n > max_batch_n:
+            replica, residual = sample_n // max_batch_n, sample_n % max_batch_n
+            batch_sizes = [max_batch_n] * replica + ([residual] if residual > 0 else [])
+        else:
+            batch_sizes = [sample_n]
+        inits = [None] * len(batch_sizes)
+    else:
+        inits = torch.split(init, max_batch_n)
+        batch_sizes = [len(x) for x in inits]
+    out = []
+    for i, bs in enumerate(batch_sizes):
+        out.append(pipeline(batch_size=bs, generator=rng, init=inits[i], output_type=None).images)
+    return np.concatenate(out)
+
+
+def save_imgs(imgs: np.ndarray, file_dir: Union[str, os.PathLike], file_name: Union[str, os.PathLike] = "", start_cnt: int = 0) -> None:
+    # model.py:496-502 : PNG = round(255 x) uint8
+    from PIL import Image
+    os.makedirs(file_dir, exist_ok=True)
+    arr = np.squeeze((imgs * 255).round().astype("uint8"))
+    if arr.ndim == 3 and imgs.shape[0] == 1:
+        arr = arr[None]
+    for i, image in enumerate(arr):
+        Image.fromarray(image).save(os.path.join(file_dir, f"{file_name}{start_cnt + i}.png"))
+
+
+def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], init: torch.Tensor = None, max_batch_n: int = 256,
+                        rng: torch.Generator = None, rank: int = 0, world: int = 1):
+    """model.py:504-529.  With world > 1 the rows of `init` are split contiguously over ranks and every rank writes
+    its own PNG index range (sampling chains are independent, no collective)."""
+    if init is None:
+        if sample_n > max_batch_n:
+            replica, residual = sample_n // max_batch_n, sample_n % max_batch_n
+            batch_sizes = [max_batch_n] * replica + ([residual] if residual > 0 else [])
+        else:
+            batch_sizes = [sample_n]
+        inits = [None] * len(batch_sizes)
+        if world > 1:
+            raise ValueError("sharded sampling needs an explicit `init` (one generator stream cannot be split)")
+        offset = 0
+    else:
+        n = len(init)
+        per = (n + world - 1) // world
+        offset = rank * per
+        init = init[offset: offset + per]
+        inits = torch.split(init, max_batch_n)
+        batch_sizes = [len(x) for x in inits]
+    cnt = offset
+    for i, bs in enumerate(batch_sizes):
+        res = pipeline(batch_size=bs, generator=rng, init=inits[i], output_type=None)
+        save_imgs(imgs=res.images, file_dir=path, file_name="", start_cnt=cnt)
+        cnt += bs
+        del res
+    return None
+
+
+class DiffuserModelSched:
+    CLIP_SAMPLE_DEFAULT = False
+    MODEL_DEFAULT = "DEFAULT"
+    DDPM_CIFAR10_DEFAULT = "DDPM-CIFAR10-DEFAULT"
+    DDPM_CELEBA_HQ_DEFAULT = "DDPM-CELEBA-HQ-DEFAULT"
+    DDPM_CHURCH_DEFAULT = "DDPM-CHURCH-DEFAULT"
+    DDPM_BEDROOM_DEFAULT = "DDPM-BEDROOM-DEFAULT"
+    LDM_CELEBA_HQ_DEFAULT = "LDM-CELEBA-HQ-DEFAULT"
+    DDPM_CIFAR10_32 = "DDPM-CIFAR10-32"
+    DDPM_CELEBA_HQ_256 = "DDPM-CELEBA-HQ-256"
+    DDPM_CHURCH_256 = "DDPM-CHURCH-256"
+    DDPM_BEDROOM_256 = "DDPM-BEDROOM-256"
+    LDM_CELEBA_HQ_256 = "LDM-CELEBA-HQ-256"
+    DDPM_SCHED = "DDPM-SCHED"
+    DDIM_SCHED = "DDIM-SCHED"
+    _OTHER_SCHEDS = ("DPM_SOLVER_PP_O1-SCHED", "DPM_SOLVER_O1-SCHED", "DPM_SOLVER_PP_O2-SCHED", "DPM_SOLVER_O2-SCHED",
+                     "DPM_SOLVER_PP_O3-SCHED", "DPM_SOLVER_O3-SCHED", "UNIPC-SCHED", "PNDM-SCHED", "DEIS-SCHED", "HEUN-SCHED",
+                     "LMSD-SCHED", "LDM-SCHED", "SCORE-SDE-VE-SCHED", "EDM-VE-SCHED", "EDM-VE-ODE-SCHED", "EDM-VE-SDE-SCHED")
+    _HUB = {DDPM_CIFAR10_32: "google/ddpm-cifar10-32", DDPM_CELEBA_HQ_256: "google/ddpm-ema-celebahq-256",
+            DDPM_CHURCH_256: "google/ddpm-ema-church-256", DDPM_BEDROOM_256: "google/ddpm-ema-bedroom-256",
+            LDM_CELEBA_HQ_256: "CompVis/ldm-celebahq-256"}
+
+    @staticmethod
+    def get_sample_clip(clip_sample: bool, clip_sample_default: bool):
+        return clip_sample if clip_sample is not None else clip_sample_default
+
+    @staticmethod
+    def _pipeline_generator(pipeline):
+        def get_pipeline(unet, scheduler):
+            return pipeline(unet, scheduler)
+        return get_pipeline
+
+    @staticmethod
+    def _get_model_sched(ckpt_id: str, clip_sample: bool, noise_sched_type: str = None):
+        # model.py:577-643
+        clip_used = DiffuserModelSched.get_sample_clip(clip_sample, DiffuserModelSched.CLIP_SAMPLE_DEFAULT)
+        local = _resolve_local(ckpt_id)
+        if local is not None:
+            model = load_unet(os.path.join(local, "unet"))
+            ckpt_sched = load_scheduler(os.path.join(local, "scheduler")) if os.path.isdir(os.path.join(local, "scheduler")) \
+                else DDPMScheduler()
+        elif ckpt_id in KNOWN_TOPOLOGIES:
+            print(f"[baddiffusion_amd] weights for '{ckpt_id}' are not available locally (set BD_CKPT_ROOT): "
+                  f"building the documented topology with default initialisation")
+            model = UNet2DModel(**KNOWN_TOPOLOGIES[ckpt_id])
+            model.pretrained = False
+            ckpt_sched = DDPMScheduler(**KNOWN_SCHEDULERS.get(ckpt_id, {}))
+        else:
+            raise FileNotFoundError(f"checkpoint '{ckpt_id}' not found locally and its topology is unknown")
+        kw = dict(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02)
+        if noise_sched_type == DiffuserModelSched.DDPM_SCHED:
+            noise_sched = DDPMScheduler(clip_sample=clip_used, **kw)
+            get_pipeline = DiffuserModelSched._pipeline_generator(DDPMPipeline)
+        elif noise_sched_type == DiffuserModelSched.DDIM_SCHED:
+            noise_sched = DDIMScheduler(clip_sample=clip_used, **kw)
+            get_pipeline = DiffuserModelSched._pipeline_generator(DDIMPipeline)
+        elif noise_sched_type is None:
+            noise_sched = ckpt_sched
+            get_pipeline = DiffuserModelSched._pipeline_generator(DDPMPipeline)
+        elif noise_sched_type in DiffuserModelSched._OTHER_SCHEDS:
+            raise NotImplementedError(f"{noise_sched_type}: only DDPM-SCHED / DDIM-SCHED are on the BadDiffusion hot path "
+                                      "(SURVEY f-4; `--sched` is inert in the reference at this commit, Appendix D-3)")
+        else:
+            raise NotImplementedError()
+        if clip_used is not None:
+            noise_sched.config.clip_sample = clip_used
+            print(f"noise_sched.config.clip_sample = {noise_sched.config.clip_sample}")
+        return model, noise_sched, get_pipeline
+
+    @staticmethod
+    def get_model_sched(image_size: int, channels: int, model_type: str = MODEL_DEFAULT, noise_sched_type: str = None,
+                        clip_sample: bool = None, **kwargs):
+        # model.py:645-698
+        if model_type == DiffuserModelSched.MODEL_DEFAULT:
+            clip_used = DiffuserModelSched.get_sample_clip(clip_sample, False)
+            noise_sched = DDPMScheduler(num_train_timesteps=1000, clip_sample=clip_used)
+            model = UNet2DModel(
+                sample_size=image_size, in_channels=channels, out_channels=channels, layers_per_block=2,
+                block_out_channels=(128, 128, 256, 256, 512, 512),
+                down_block_types=("DownBlock2D", "DownBlock2D", "DownBlock2D", "DownBlock2D", "AttnDownBlock2D", "DownBlock2D"),
+                up_block_types=("UpBlock2D", "AttnUpBlock2D", "UpBlock2D", "UpBlock2D", "UpBlock2D", "UpBlock2D"))
+            get_pipeline = DiffuserModelSched._pipeline_generator(DDPMPipeline)
+            return model, noise_sched, get_pipeline
+        table = {DiffuserModelSched.DDPM_CIFAR10_DEFAULT: DiffuserModelSched.DDPM_CIFAR10_32,
+                 DiffuserModelSched.DDPM_CELEBA_HQ_DEFAULT: DiffuserModelSched.DDPM_CELEBA_HQ_256,
+                 DiffuserModelSched.DDPM_CHURCH_DEFAULT: DiffuserModelSched.DDPM_CHURCH_256,
+                 DiffuserModelSched.DDPM_BEDROOM_DEFAULT: DiffuserModelSched.DDPM_BEDROOM_256,
+                 DiffuserModelSched.LDM_CELEBA_HQ_DEFAULT: DiffuserModelSched.LDM_CELEBA_HQ_256}
+        if model_type not in table:
+            raise NotImplementedError()
+        model, noise_sched, get_pipeline = DiffuserModelSched.get_pretrained(ckpt=table[model_type], noise_sched_type=noise_sched_type,
+                                                                             clip_sample=clip_sample)
+        model.reset_parameters()      # model.apply(weight_reset), model.py:647-652
+        return model, noise_sched, get_pipeline
+
+    @staticmethod
+    def get_pretrained(ckpt: str, clip_sample: bool = None, noise_sched_type: str = None):
+        ckpt = DiffuserModelSched._HUB.get(ckpt, ckpt)
+        return DiffuserModelSched._get_model_sched(ckpt_id=ckpt, clip_sample=clip_sample, noise_sched_type=noise_sched_type)
+
+    @staticmethod
+    def get_trained(ckpt: str, clip_sample: bool = None, noise_sched_type: str = None):
+        return DiffuserModelSched._get_model_sched(ckpt_id=ckpt, clip_sample=clip_sample, noise_sched_type=noise_sched_type)

@@ -1,0 +1,151 @@
+"""DDPMPipeline / DDIMPipeline -- drop-in for the two (locally modified) pipelines BadDiffusion samples with
+(/root/reference/diffusers/src/diffusers/pipelines/ddpm/pipeline_ddpm.py:46-125,
+ pipelines/ddim/pipeline_ddim.py:50-142), including the repo's additions `init=`, `save_every_step=`,
+`start_from=` and the `.movie` output.
+
+Loop body = one UNet forward (bd_unet_forward) + one fused scheduler step kernel; the image never leaves the
+GPU until the final (x/2+0.5).clamp(0,1) -> NHWC conversion (bd_to_image).  With a CPU `generator` the
+per-step noise is drawn on the CPU in the reference's order (seed parity, scheduling_ddpm.py:400-404);
+with a CUDA generator or `generator=None` it is drawn on the device (throughput mode).
+"""
+import json
+import os
+
+import numpy as np
+import torch
+
+from . import ops
+from .schedulers import DDIMScheduler, DDPMScheduler, randn_tensor
+
+
+class ImagePipelineOutput:
+    def __init__(self, images, movie=None):
+        self.images = images
+        self.movie = movie if movie is not None else []
+
+
+class _PipelineBase:
+    def __init__(self, unet, scheduler):
+        self.unet = unet
+        self.scheduler = scheduler
+        self._progress = {}
+
+    @property
+    def device(self):
+        return self.unet.device
+
+    def to(self, device):
+        self.unet.to(device)
+        return self
+
+    def set_progress_bar_config(self, **kw):
+        self._progress = kw
+
+    def progress_bar(self, it):
+        if self._progress.get("disable", True):
+            return it
+        try:
+            from tqdm.auto import tqdm
+            return tqdm(it, **{k: v for k, v in self._progress.items() if k != "disable"})
+        except ImportError:
+            return it
+
+    @staticmethod
+    def numpy_to_pil(images):
+        from PIL import Image
+        if images.ndim == 3:
+            images = images[None, ...]
+        images = (images * 255).round().astype("uint8")
+        if images.shape[-1] == 1:
+            return [Image.fromarray(image.squeeze(), mode="L") for image in images]
+        return [Image.fromarray(image) for image in images]
+
+    def _image_shape(self, batch_size):
+        s = self.unet.config.sample_size
+        return (batch_size, self.unet.config.in_channels, s, s)
+
+    def _to_numpy(self, image_nhwc_storage, shape):
+        """image: NHWC storage [B,H,W,C] -> float32 numpy [B,H,W,C] in [0,1] (pipeline_ddpm.py:115-116)."""
+        return ops.to_image(image_nhwc_storage, True, shape).cpu().numpy()
+
+    def _start(self, batch_size, generator, init):
+        shape = self._image_shape(batch_size)
+        if init is None:
+            image = randn_tensor(shape, generator=generator, device=self.device)
+        else:
+            image = init.detach().clone().to(self.device)
+            shape = tuple(image.shape)
+        # keep the running sample in NHWC storage (what the UNet consumes and produces)
+        return ops.nchw_to_nhwc(image.float()), shape
+
+    # ---- diffusers-layout save (SURVEY f-2) ------------------------------------------------------------------
+    def save_pretrained(self, save_directory):
+        from .model import save_unet, save_scheduler
+        os.makedirs(save_directory, exist_ok=True)
+        with open(os.path.join(save_directory, "model_index.json"), "w") as f:
+            json.dump({"_class_name": type(self).__name__, "_diffusers_version": "0.16.0.dev0",
+                       "scheduler": ["diffusers", type(self.scheduler).__name__], "unet": ["diffusers", "UNet2DModel"]}, f, indent=2)
+        save_unet(self.unet, os.path.join(save_directory, "unet"))
+        save_scheduler(self.scheduler, os.path.join(save_directory, "scheduler"))
+
+
+class DDPMPipeline(_PipelineBase):
+    @torch.no_grad()
+    def __call__(self, batch_size=1, generator=None, num_inference_steps=1000, start_from=0, output_type="pil", init=None,
+                 save_every_step=False, return_dict=True, **kwargs):
+        image, shape = self._start(batch_size, generator, init)
+        self.scheduler.set_timesteps(num_inference_steps)
+        mov = [self._to_numpy(image, shape)] if save_every_step else []
+        for t in self.progress_bar(self.scheduler.timesteps[start_from:]):
+            t = int(t)
+            eps = self.unet(image.permute(0, 3, 1, 2), t).sample.permute(0, 2, 3, 1)        # NHWC storage
+            noise = None
+            if t > 0:   # same draw order / shape as randn_tensor(model_output.shape) in the reference
+                noise = randn_tensor(shape, generator=generator, device=self.device)
+                noise = ops.nchw_to_nhwc(noise)
+            image = self.scheduler.step(eps.permute(0, 3, 1, 2), t, image.permute(0, 3, 1, 2),
+                                        noise=noise.permute(0, 3, 1, 2) if noise is not None else None
+                                        ).prev_sample.permute(0, 2, 3, 1)
+            if save_every_step:
+                mov.append(self._to_numpy(image, shape))
+        images = self._to_numpy(image, shape)
+        if output_type == "pil":
+            images = self.numpy_to_pil(images)
+            if save_every_step:
+                mov = list(map(self.numpy_to_pil, mov))
+        if not return_dict:
+            return (images,)
+        return ImagePipelineOutput(images=images, movie=mov)
+
+
+class DDIMPipeline(_PipelineBase):
+    def __init__(self, unet, scheduler):
+        # pipeline_ddim.py:39-42: make sure the scheduler can always be converted to DDIM
+        scheduler = DDIMScheduler.from_config(scheduler.config)
+        super().__init__(unet, scheduler)
+
+    @torch.no_grad()
+    def __call__(self, batch_size=1, generator=None, eta=0.0, num_inference_steps=50, use_clipped_model_output=None,
+                 output_type="pil", init=None, save_every_step=False, return_dict=True, **kwargs):
+        if isinstance(generator, list) and len(generator) != batch_size:
+            raise ValueError(f"You have passed a list of generators of length {len(generator)}, but requested an effective "
+                             f"batch size of {batch_size}.")
+        image, shape = self._start(batch_size, generator, init)
+        self.scheduler.set_timesteps(num_inference_steps)
+        mov = [self._to_numpy(image, shape)] if save_every_step else []
+        for t in self.progress_bar(self.scheduler.timesteps):
+            t = int(t)
+            eps = self.unet(image.permute(0, 3, 1, 2), t).sample
+            image = self.scheduler.step(eps, t, image.permute(0, 3, 1, 2), eta=eta,
+                                        use_clipped_model_output=bool(use_clipped_model_output),
+                                        generator=generator).prev_sample.permute(0, 2, 3, 1)
+            if save_every_step:
+                mov.append(self._to_numpy(image, shape))
+        images = self._to_numpy(image, shape)
+        if output_type == "pil":
+            images = self.numpy_to_pil(images)
+            if save_every_step:
+                mov = list(map(self.numpy_to_pil, mov))
+        if not return_dict:
+            return (images,)
+        return ImagePipelineOutput(images=images, movie=mov)

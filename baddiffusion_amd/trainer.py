@@ -27,6 +27,37 @@ def cosine_schedule_with_warmup(step, num_warmup_steps, num_training_steps, num_
     return max(0.0, 0.5 * (1.0 + math.cos(math.pi * float(num_cycles) * 2.0 * progress)))
 
 
+class DPReducer:
+    """Sum-all-reduce of finished ranges of one flat gradient buffer, issued asynchronously as backward
+    produces them (RCCL over xGMI on the GPUs; gloo on CPU tensors in the tests).  The loss gradient is
+    pre-scaled by 1/world, so the sum is the global-batch mean gradient."""
+
+    def __init__(self, flat, process_group=None):
+        self.flat, self.pg = flat, process_group
+        self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.works = []
+
+    def reduce_range(self, lo, hi):
+        if self.world > 1 and hi > lo:
+            self.works.append(dist.all_reduce(self.flat[lo:hi], group=self.pg, async_op=True))
+
+    def finish(self):
+        for w in self.works:
+            w.wait()
+        self.works = []
+
+
+def plan_segments(model):
+    """[(lo, hi)] ranges of the flat gradient in the order backward finalises them."""
+    lib = L.load()
+    out = []
+    lo, hi = ctypes.c_int64(), ctypes.c_int64()
+    for s in range(lib.bd_unet_num_segments(model._plan)):
+        L.check(lib.bd_unet_segment_range(model._plan, s, ctypes.byref(lo), ctypes.byref(hi)), "bd_unet_segment_range")
+        out.append((lo.value, hi.value))
+    return out
+
+
 class TrainEngine:
     def __init__(self, model, noise_sched, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  lr_warmup_steps=500, num_training_steps=None, loss_type="l2", process_group=None,
@@ -68,19 +99,17 @@ class TrainEngine:
         pred, ws = model._run_forward(flat, xn, t, training=True)
         loss, dpred = ops.loss_fwd_bwd(pred, tg, self.loss_type, grad_scale=1.0 / (self.world * self.accum))
         B = xn.shape[0]
-        works = []
+        red = DPReducer(self.grads, self.pg)
         lo, hi = ctypes.c_int64(), ctypes.c_int64()
         for s in range(self._nseg):
             L.check(self._lib.bd_unet_backward_segment(
                 model._plan, s, B, flat.data_ptr(), xn.data_ptr(), xn.shape[-1], dpred.data_ptr(), dpred.shape[-1],
                 self.grads.data_ptr(), ws.data_ptr(), ws.numel(), L.stream(), ctypes.byref(lo), ctypes.byref(hi)),
                 "bd_unet_backward_segment")
-            if self.world > 1 and hi.value > lo.value:
-                # the collective waits (on its own stream) for the kernels enqueued so far, then overlaps
-                # with the next segments; 143 MB total per step for the CIFAR UNet
-                works.append(dist.all_reduce(self.grads[lo.value: hi.value], group=self.pg, async_op=True))
-        for w in works:
-            w.wait()
+            # the collective waits (on RCCL's stream) for the kernels enqueued so far, then overlaps with the
+            # next segments' kernels; 143 MB in total per step for the CIFAR UNet
+            red.reduce_range(lo.value, hi.value)
+        red.finish()
         model._release_ws(ws)
         return loss
 

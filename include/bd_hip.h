@@ -299,6 +299,7 @@ int bd_unet_backward(bd_unet* u, int B, const float* params, const float* x, int
  * gradient all-reduce with the rest of backward: after segment s, grads in
  * [seg_lo[s], seg_hi[s]) (elements) are final. */
 int bd_unet_num_segments(const bd_unet* u);
+int bd_unet_segment_range(const bd_unet* u, int seg, int64_t* lo, int64_t* hi);   /* host-only query */
 int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float* params, const float* x, int64_t ldx,
                              const float* dout, int64_t lddo, float* grads, void* workspace, size_t workspace_bytes,
                              bd_stream_t stream, int64_t* ready_lo, int64_t* ready_hi);

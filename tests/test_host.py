@@ -1,0 +1,135 @@
+"""CPU: host-side logic of the drop-in surface (no GPU work): parameter table / state_dict contract, schedulers'
+host parts against the reference KATs, Backdoor constructors against golden vectors, CLI rules, checkpoint I/O."""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oracle import train_ref
+from oracle import unet_ref as U
+from tests.golden import cases as C
+
+
+def test_param_table_matches_reference_state_dict_contract():
+    from baddiffusion_amd.unet import unet_from_config
+    for cfg, n in ((U.CIFAR10_32, 35746307), (U.CELEBA_HQ_256, 113673219), (C.SMALL_CFGS["small_default"], None)):
+        m = unet_from_config(cfg)
+        shapes = U.param_shapes(cfg)
+        sd = m.state_dict()
+        assert set(sd) == set(shapes)
+        assert all(tuple(sd[k].shape) == tuple(v) for k, v in shapes.items())
+        if n:
+            assert sum(v.numel() for v in sd.values()) == n
+        P = U.gen_params(cfg, 1)
+        m.load_state_dict(P)
+        sd = m.state_dict()
+        assert all(torch.equal(sd[k], P[k]) for k in P)
+        with pytest.raises(RuntimeError):
+            m.load_state_dict({k: v for k, v in list(P.items())[:-1]})
+        if cfg is U.CELEBA_HQ_256:
+            break
+
+
+def test_unsupported_configs_fail_loudly():
+    from baddiffusion_amd.unet import UNet2DModel
+    kw = dict(sample_size=16, block_out_channels=(128, 256), layers_per_block=1)
+    with pytest.raises(NotImplementedError):
+        UNet2DModel(down_block_types=("DownBlock2D", "CrossAttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"), **kw)
+    with pytest.raises(NotImplementedError):
+        UNet2DModel(down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"),
+                    resnet_time_scale_shift="scale_shift", **kw)
+    with pytest.raises(ValueError):
+        UNet2DModel(down_block_types=("DownBlock2D",), up_block_types=("AttnUpBlock2D", "UpBlock2D"), **kw)
+    with pytest.raises(RuntimeError):   # C plan: channels must be multiples of the group count
+        UNet2DModel(down_block_types=("DownBlock2D", "AttnDownBlock2D"), up_block_types=("AttnUpBlock2D", "UpBlock2D"),
+                    sample_size=16, block_out_channels=(100, 256), layers_per_block=1)
+
+
+def test_scheduler_host_side(golden):
+    from baddiffusion_amd.schedulers import DDIMScheduler, DDPMScheduler
+    g = golden("sched")
+    s = DDPMScheduler()
+    assert np.array_equal(s.betas.numpy(), g["betas"]) and np.array_equal(s.alphas_cumprod.numpy(), g["alphas_cumprod"])
+    # diffusers/tests/schedulers/test_scheduler_ddpm.py:62-69
+    assert abs(float(s._get_variance(0)) - 0.0) < 1e-5 and abs(float(s._get_variance(487)) - 0.00979) < 1e-5
+    assert abs(float(s._get_variance(999)) - 0.02) < 1e-5
+    s.set_timesteps(50)
+    assert np.array_equal(s.timesteps.numpy(), g["ddpm_ts50"]) and int(s.previous_timestep(980)) == 960
+    with pytest.raises(ValueError):
+        s.set_timesteps(timesteps=[100, 100, 50])                       # test_scheduler_ddpm.py:160-170
+    with pytest.raises(ValueError):
+        s.set_timesteps(num_inference_steps=10, timesteps=[100, 50])
+    d = DDIMScheduler(steps_offset=1); d.set_timesteps(5)
+    assert list(d.timesteps.numpy()) == [801, 601, 401, 201, 1]          # test_scheduler_ddim.py:46-54
+    d = DDIMScheduler.from_config(DDPMScheduler(clip_sample=False).config); d.set_timesteps(50)
+    assert d.config.clip_sample is False and np.array_equal(d.timesteps.numpy(), g["ddim_ts50"])
+    assert abs(float(d._get_variance(420, 400)) - 0.14771) < 1e-5        # test_scheduler_ddim.py:94-104
+    s.config.clip_sample = True                                          # assignable (model.py:639-641)
+    assert s.config["clip_sample"] is True
+    with pytest.raises(RuntimeError):
+        s.step(torch.zeros(1, 3, 4, 4), 5, torch.zeros(1, 3, 4, 4))      # CPU tensors are rejected
+
+
+def test_backdoor_product_vs_golden(golden):
+    from baddiffusion_amd.dataset import Backdoor, DatasetLoader
+    g = golden("backdoor")
+    bd = Backdoor(root=None)
+    for S in (32, 256):
+        for trig in ("BOX_4", "BOX_8", "BOX_11", "BOX_14", "BOX_18", "SM_BOX", "NONE"):
+            t = bd.get_trigger(trig, 3, S)
+            assert np.array_equal(t.numpy(), g[f"trig_{trig}_{S}"])
+            if S == 32 or trig == "BOX_14":
+                for tg in ("CORNER", "TRIGGER", "SHIFT"):
+                    assert np.array_equal(bd.get_target(tg, t).numpy(), g[f"tgt_{tg}_{trig}_{S}"])
+    with pytest.raises(ValueError):
+        bd.get_trigger("NOPE", 3, 32)
+    with pytest.raises(FileNotFoundError):
+        bd.get_target("HAT", bd.get_trigger("BOX_14", 3, 32))            # static/ assets are not redistributed
+    dsl = DatasetLoader(root=None, name="CIFAR10", batch_size=128, num_images=1000, device="cpu")
+    dsl.set_poison("BOX_14", "CORNER", clean_rate=1.0, poison_rate=0.1).prepare_dataset("FIXED")
+    assert int(dsl._is_poison.sum()) == 100 and dsl.num_batch == 8 and dsl.image_size == 32 and dsl.channel == 3
+    assert torch.equal(dsl.get_mask(dsl.trigger), torch.from_numpy(g["mask_BOX_14_32"]))
+    assert dsl.source == "synthetic"
+
+
+def test_lr_schedule_and_cli_rules(tmp_path, monkeypatch):
+    from baddiffusion_amd.trainer import cosine_schedule_with_warmup
+    for s in (0, 1, 499, 500, 7777, 23449, 23450):
+        assert cosine_schedule_with_warmup(s, 500, 23450) == train_ref.cosine_lr_lambda(s, 500, 23450)
+    import baddiffusion as cli
+    monkeypatch.chdir(tmp_path)
+    cfg = cli.setup(["--project", "default", "--mode", "train", "--dataset", "CIFAR10", "--batch", "64", "--epoch", "50",
+                     "--poison_rate", "0.1", "--trigger", "BOX_14", "--target", "HAT", "--ckpt", "DDPM-CIFAR10-32", "--fclip", "o", "-o"])
+    assert cfg.gradient_accumulation_steps == 2 and cfg.learning_rate == 2e-4 and cfg.clip is False
+    assert os.path.basename(cfg.output_dir) == "res_DDPM-CIFAR10-32_CIFAR10_ep50_c1.0_p0.1_BOX_14-HAT"
+    assert json.load(open(os.path.join(cfg.output_dir, "args.json")))["poison_rate"] == 0.1
+    with pytest.raises(ValueError):      # batch must divide 128 (baddiffusion.py:213-217)
+        cli.setup(["--mode", "train", "--dataset", "CIFAR10", "--batch", "48", "-o"], write=False)
+    with pytest.raises(NotImplementedError):   # per-mode whitelist (baddiffusion.py:163-175)
+        cli.setup(["--mode", "sampling", "--ckpt", cfg.output_dir, "--epoch", "3"], write=False)
+    with pytest.raises(NotImplementedError):
+        cli.setup(["--mode", "train", "--dataset", "CIFAR10", "--batch", "128", "--sample_ep", "3", "-o"], write=False)
+    c2 = cli.setup(["--mode", "sampling", "--ckpt", cfg.output_dir, "--fclip", "w", "--eval_max_batch", "2048", "--sched", "DDIM-SCHED"])
+    assert c2.clip is True and c2.dataset == "CIFAR10" and c2.sched == "DDIM-SCHED" and c2.eval_max_batch == 2048
+    c3 = cli.setup(["--mode", "train", "--dataset", "CELEBA-HQ", "--batch", "4", "-o"], write=False)
+    assert c3.gradient_accumulation_steps == 16 and c3.learning_rate == 2e-5
+
+
+def test_checkpoint_layout_roundtrip(tmp_path):
+    from baddiffusion_amd.model import DiffuserModelSched, load_scheduler, load_unet
+    model, sched, get_pipeline = DiffuserModelSched.get_pretrained("DDPM-CIFAR10-32", clip_sample=False, noise_sched_type="DDPM-SCHED")
+    d = str(tmp_path / "run")
+    get_pipeline(model, sched).save_pretrained(d)
+    assert sorted(os.listdir(d)) == ["model_index.json", "scheduler", "unet"]
+    assert sorted(os.listdir(os.path.join(d, "unet"))) == ["config.json", "diffusion_pytorch_model.bin"]
+    sd = torch.load(os.path.join(d, "unet", "diffusion_pytorch_model.bin"))
+    assert tuple(sd["conv_in.weight"].shape) == (128, 3, 3, 3) and sd["conv_in.weight"].is_contiguous()
+    m2 = load_unet(os.path.join(d, "unet"))
+    assert torch.equal(m2.flat, model.flat)
+    m3, s3, _ = DiffuserModelSched.get_trained(d, clip_sample=None)
+    assert torch.equal(m3.flat, model.flat) and s3.config.clip_sample is False and m3.pretrained
+    with pytest.raises(NotImplementedError):
+        DiffuserModelSched.get_pretrained("DDPM-CIFAR10-32", noise_sched_type="UNIPC-SCHED")
