@@ -9,12 +9,15 @@
 // The f32 MFMA takes ONE float per lane per operand (lane l: row l&31, k-slot l>>5), so any
 // (row,k) -> memory map works without a transpose pass; the K order inside a chunk is permuted
 // identically for A and B (k(g,j,h) = 8g + 4h + j) which leaves the dot product unchanged.
-// Results are bit-identical to a k-ordered fmaf chain per (m,n) within one K chunk order
-// (cdna_hip_programming.md section 3), i.e. fp32 everywhere: no reduced-precision inputs.
+// Products and accumulation are exact fp32 (cdna_hip_programming.md section 3): no reduced-precision inputs.
 //
 // Operand kinds (bd_hip.h): DENSE, CONV (3x3 gather, fwd and wgrad), TCONV (dgrad gather), WGT
-// (weights seen from the dgrad side).  Replaces aten::convolution(_backward), addmm/mm/bmm/baddbmm
-// in the reference's UNet.
+// (weights seen from the dgrad side).  Each kind has a FAST loader (float4 only, no integer division
+// in the K loop: the (tap, channel) cursor of a conv operand advances incrementally and is wave-uniform)
+// used when the shape is aligned (C % 32 == 0, ld % 4 == 0, ...), and every shape falls back to the
+// GENERIC loaders (per-element address computation, scalar loads) otherwise -- conv_in (Cin = 3),
+// conv_out (Cout = 3), odd GEMM sizes.  Replaces aten::convolution(_backward), addmm/mm/bmm/baddbmm
+// of the reference's UNet.
 #include "common.h"
 
 namespace bd {
@@ -29,7 +32,8 @@ struct Opnd {
     long long ld;
     int kind, vec;
     int C, Hs, Ws, Ho, Wo, stride, pad_t, pad_l, ups;
-    int rows;  // number of valid rows (M for A, N for B)
+    int rows;      // number of valid rows (M for A, N for B)
+    int lw, lhw;   // log2(Wo), log2(Ho*Wo) when both are powers of two, else -1
 };
 
 struct IGemmParams {
@@ -52,118 +56,346 @@ struct IGemmParams {
 };
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
+__device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
-// ------------------------------------------------------------------------------------------------
-// KC loader: tile [R rows][32 k]; thread t owns float4 column k4 = (t&7)*4 of rows (t>>3) + 32*i.
-// ------------------------------------------------------------------------------------------------
+// pixel index -> (b, y, x) over an (Ho, Wo) grid
+__device__ __forceinline__ void decode_pixel(const Opnd& o, int pix, int& b, int& y, int& x) {
+    if (o.lw >= 0) {
+        x = pix & (o.Wo - 1);
+        y = (pix >> o.lw) & (o.Ho - 1);
+        b = pix >> o.lhw;
+    } else {
+        const int hw = o.Ho * o.Wo;
+        b = pix / hw;
+        const int rem = pix - b * hw;
+        y = rem / o.Wo;
+        x = rem - y * o.Wo;
+    }
+}
+
+// =================================================================================================
+// FAST loaders.  Interface: init(opnd, row0, tid, kbase0, K) ; load(v) for the current chunk ; advance().
+// KC: tile [R rows][32 k]; thread t owns float4 column k4 = (t&7)*4 of rows (t>>3) + 32*i.
+// RC: tile [32 k][R rows]; thread t owns float4 at rows r4 = (t % (R/4))*4, k = t/(R/4) + KS*i.
+// =================================================================================================
 template <int R>
-struct LoaderKC {
+struct KCStore {
     static constexpr int NI = R / 32;
-    long long base[NI];  // DENSE: row*ld ; CONV/TCONV: image offset b*Hs*Ws*ld
-    int yb[NI], xb[NI];  // CONV: y*stride - pad_t ; TCONV: yi + pad_t   (invalid row: very negative)
-    int k4;
+    __device__ __forceinline__ static void store(float* s, int tid, const float4 (&v)[NI]) {
+        const int k4 = (tid & 7) * 4;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * i) * LDK + k4) = v[i];
+    }
+};
+template <int R>
+struct RCStore {
+    static constexpr int NI = R / 32;
+    static constexpr int KS = 1024 / R;
+    __device__ __forceinline__ static void store(float* s, int tid, const float4 (&v)[NI]) {
+        const int r4 = (tid % (R / 4)) * 4, k0 = tid / (R / 4);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + (k0 + KS * i) * (R + 4) + r4) = v[i];
+    }
+};
 
-    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid) {
-        k4 = (tid & 7) * 4;
+template <int R>
+struct DenseKC : KCStore<R> {
+    static constexpr int NI = R / 32;
+    static constexpr bool kKC = true;
+    const float* ptr[NI];
+    bool ok[NI];
+    int krem;  // K - (kbase + k4): > 0 while this thread's float4 is inside K
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int K) {
+        const int k4 = (tid & 7) * 4;
+        krem = K - kbase - k4;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            int r = row0 + (tid >> 3) + 32 * i;
-            bool ok = r < o.rows;
+            const int r = row0 + (tid >> 3) + 32 * i;
+            ok[i] = r < o.rows;
+            ptr[i] = o.p + (long long)r * o.ld + kbase + k4;
+        }
+    }
+    __device__ __forceinline__ void load(const Opnd&, float4 (&v)[NI]) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[i] = (ok[i] && krem > 0) ? ld4(ptr[i]) : zero4();
+    }
+    __device__ __forceinline__ void advance(const Opnd&) {
+        krem -= BK;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) ptr[i] += BK;
+    }
+};
+
+// conv gather, forward direction: rows = output pixels, k = tap*C + c, C % 32 == 0 (tap uniform per chunk)
+template <int R>
+struct ConvKC : KCStore<R> {
+    static constexpr int NI = R / 32;
+    static constexpr bool kKC = true;
+    const float* base[NI];  // image base + k4
+    int y0[NI], x0[NI];
+    int kh, kw, c0;         // wave-uniform cursor
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
+        const int k4 = (tid & 7) * 4;
+        const int tap = kbase / o.C;
+        c0 = kbase - tap * o.C;
+        kh = tap / 3;
+        kw = tap - kh * 3;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = row0 + (tid >> 3) + 32 * i;
+            int b, y, x;
+            decode_pixel(o, r, b, y, x);
+            base[i] = o.p + (long long)b * o.Hs * o.Ws * o.ld + k4;
+            y0[i] = r < o.rows ? y * o.stride - o.pad_t : -(1 << 28);
+            x0[i] = x * o.stride - o.pad_l;
+        }
+    }
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
+        const int He = o.Hs << o.ups, We = o.Ws << o.ups;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int ys = y0[i] + kh, xs = x0[i] + kw;
+            const bool okk = (unsigned)ys < (unsigned)He && (unsigned)xs < (unsigned)We && kh < 3;
+            const int off = ((ys >> o.ups) * o.Ws + (xs >> o.ups)) * (int)o.ld + c0;
+            v[i] = okk ? ld4(base[i] + off) : zero4();
+        }
+    }
+    __device__ __forceinline__ void advance(const Opnd& o) {
+        c0 += BK;
+        if (c0 >= o.C) {
+            c0 = 0;
+            if (++kw == 3) { kw = 0; ++kh; }
+        }
+    }
+};
+
+// conv gather, data-gradient direction: rows = input pixels, k = tap*C + c over dY (C = Cout, C % 32 == 0)
+template <int R>
+struct TConvKC : KCStore<R> {
+    static constexpr int NI = R / 32;
+    static constexpr bool kKC = true;
+    const float* base[NI];
+    int y0[NI], x0[NI];
+    int kh, kw, c0;
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
+        const int k4 = (tid & 7) * 4;
+        const int tap = kbase / o.C;
+        c0 = kbase - tap * o.C;
+        kh = tap / 3;
+        kw = tap - kh * 3;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = row0 + (tid >> 3) + 32 * i;
+            int b, y, x;
+            decode_pixel(o, r, b, y, x);
+            base[i] = o.p + (long long)b * o.Hs * o.Ws * o.ld + k4;
+            y0[i] = r < o.rows ? y + o.pad_t : -(1 << 28);
+            x0[i] = x + o.pad_l;
+        }
+    }
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
+        const int sh = o.stride - 1;  // 0 or 1
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int yn = y0[i] - kh, xn = x0[i] - kw;
+            const int ys = yn >> sh, xs = xn >> sh;
+            const bool okk = yn >= 0 && xn >= 0 && ((yn | xn) & sh) == 0 && ys < o.Hs && xs < o.Ws && kh < 3;
+            const int off = (ys * o.Ws + xs) * (int)o.ld + c0;
+            v[i] = okk ? ld4(base[i] + off) : zero4();
+        }
+    }
+    __device__ __forceinline__ void advance(const Opnd& o) {
+        c0 += BK;
+        if (c0 >= o.C) {
+            c0 = 0;
+            if (++kw == 3) { kw = 0; ++kh; }
+        }
+    }
+};
+
+template <int R>
+struct DenseRC : RCStore<R> {
+    static constexpr int NI = R / 32;
+    static constexpr int KS = 1024 / R;
+    static constexpr bool kKC = false;
+    const float* ptr;  // p + row + (kbase + k0)*ld
+    long long step;    // KS * ld
+    int krem;          // K - (kbase + k0)
+    bool ok;
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int K) {
+        const int r4 = (tid % (R / 4)) * 4, k0 = tid / (R / 4);
+        ok = row0 + r4 < o.rows;
+        ptr = o.p + (row0 + r4) + (long long)(kbase + k0) * o.ld;
+        step = (long long)KS * o.ld;
+        krem = K - kbase - k0;
+    }
+    __device__ __forceinline__ void load(const Opnd&, float4 (&v)[NI]) const {
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[i] = (ok && krem > KS * i) ? ld4(ptr + step * i) : zero4();
+    }
+    __device__ __forceinline__ void advance(const Opnd& o) {
+        ptr += (long long)BK * o.ld;
+        krem -= BK;
+    }
+};
+
+// weights seen from dgrad: rows = ci, k = tap*C + co (C = Cout, C % 32 == 0): W[(co*9 + tap)*ld + ci]
+template <int R>
+struct WgtRC : RCStore<R> {
+    static constexpr int NI = R / 32;
+    static constexpr int KS = 1024 / R;
+    static constexpr bool kKC = false;
+    const float* ptr;  // p + row + k0*9*ld
+    long long step;    // KS*9*ld
+    int tap, c0;
+    bool ok;
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
+        const int r4 = (tid % (R / 4)) * 4, k0 = tid / (R / 4);
+        ok = row0 + r4 < o.rows;
+        tap = kbase / o.C;
+        c0 = kbase - tap * o.C;
+        ptr = o.p + (row0 + r4) + (long long)k0 * 9 * o.ld;
+        step = (long long)KS * 9 * o.ld;
+    }
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
+        const float* q = ptr + ((long long)c0 * 9 + tap) * o.ld;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[i] = (ok && tap < 9) ? ld4(q + step * i) : zero4();
+    }
+    __device__ __forceinline__ void advance(const Opnd& o) {
+        c0 += BK;
+        if (c0 >= o.C) { c0 = 0; ++tap; }
+    }
+};
+
+// conv gather, weight-gradient direction: rows = tap*C + ci (fixed per thread), k = output pixels
+template <int R>
+struct ConvRC : RCStore<R> {
+    static constexpr int NI = R / 32;
+    static constexpr int KS = 1024 / R;
+    static constexpr bool kKC = false;
+    int kh, kw, ci, pix, Kp;
+    bool ok;
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int K) {
+        const int r4 = (tid % (R / 4)) * 4, k0 = tid / (R / 4);
+        const int r = row0 + r4;
+        const int tap = r / o.C;
+        ci = r - tap * o.C;
+        kh = tap / 3;
+        kw = tap - kh * 3;
+        ok = r < o.rows;
+        pix = kbase + k0;
+        Kp = K;
+    }
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
+        const int He = o.Hs << o.ups, We = o.Ws << o.ups;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int p = pix + KS * i;
+            int b, y, x;
+            decode_pixel(o, p, b, y, x);
+            const int ys = y * o.stride - o.pad_t + kh, xs = x * o.stride - o.pad_l + kw;
+            const bool okk = ok && p < Kp && (unsigned)ys < (unsigned)He && (unsigned)xs < (unsigned)We;
+            const long long off = ((long long)b * o.Hs * o.Ws + (ys >> o.ups) * o.Ws + (xs >> o.ups)) * o.ld + ci;
+            v[i] = okk ? ld4(o.p + off) : zero4();
+        }
+    }
+    __device__ __forceinline__ void advance(const Opnd&) { pix += BK; }
+};
+
+// =================================================================================================
+// GENERIC loaders (any kind / alignment; per-element address math).
+// =================================================================================================
+template <int R>
+struct GenericKC : KCStore<R> {
+    static constexpr int NI = R / 32;
+    static constexpr bool kKC = true;
+    long long base[NI];
+    int yb[NI], xb[NI];
+    int k4, kbase, K;
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kb, int K_) {
+        k4 = (tid & 7) * 4; kbase = kb; K = K_;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = row0 + (tid >> 3) + 32 * i;
+            const bool ok = r < o.rows;
             if (o.kind == BD_OPK_DENSE) {
                 base[i] = (long long)r * o.ld;
                 yb[i] = ok ? 0 : -(1 << 28);
                 xb[i] = 0;
             } else {
-                int hw = o.Ho * o.Wo;
-                int b = r / hw;
-                int rem = r - b * hw;
-                int y = rem / o.Wo;
-                int x = rem - y * o.Wo;
+                int b, y, x;
+                decode_pixel(o, r, b, y, x);
                 base[i] = (long long)b * o.Hs * o.Ws * o.ld;
                 if (o.kind == BD_OPK_CONV) {
                     yb[i] = ok ? y * o.stride - o.pad_t : -(1 << 28);
                     xb[i] = x * o.stride - o.pad_l;
-                } else {  // TCONV
+                } else {
                     yb[i] = ok ? y + o.pad_t : -(1 << 28);
                     xb[i] = x + o.pad_l;
                 }
             }
         }
     }
-
-    // address (element offset) of (row slot i, absolute k) or -1 if it reads as zero
-    __device__ __forceinline__ long long addr(const Opnd& o, int i, int k, int K) const {
+    __device__ __forceinline__ long long addr(const Opnd& o, int i, int k) const {
         if (k >= K) return -1;
         if (o.kind == BD_OPK_DENSE) return yb[i] < 0 ? -1 : base[i] + k;
-        int tap = k / o.C;
-        int c = k - tap * o.C;
-        int kh = tap / 3, kw = tap - kh * 3;
+        const int tap = k / o.C;
+        const int c = k - tap * o.C;
+        const int kh = tap / 3, kw = tap - kh * 3;
         if (o.kind == BD_OPK_CONV) {
-            int ys = yb[i] + kh, xs = xb[i] + kw;
+            const int ys = yb[i] + kh, xs = xb[i] + kw;
             if (ys < 0 || xs < 0 || ys >= (o.Hs << o.ups) || xs >= (o.Ws << o.ups)) return -1;
             return base[i] + ((long long)(ys >> o.ups) * o.Ws + (xs >> o.ups)) * o.ld + c;
-        } else {
-            int yn = yb[i] - kh, xn = xb[i] - kw;
-            if (yn < 0 || xn < 0) return -1;
-            if (o.stride == 2) {
-                if ((yn | xn) & 1) return -1;
-                yn >>= 1;
-                xn >>= 1;
-            }
-            if (yn >= o.Hs || xn >= o.Ws) return -1;
-            return base[i] + ((long long)yn * o.Ws + xn) * o.ld + c;
         }
+        int yn = yb[i] - kh, xn = xb[i] - kw;
+        if (yn < 0 || xn < 0) return -1;
+        if (o.stride == 2) {
+            if ((yn | xn) & 1) return -1;
+            yn >>= 1; xn >>= 1;
+        }
+        if (yn >= o.Hs || xn >= o.Ws) return -1;
+        return base[i] + ((long long)yn * o.Ws + xn) * o.ld + c;
     }
-
-    __device__ __forceinline__ void load(const Opnd& o, int kbase, int K, float4 (&v)[NI]) const {
-        int k = kbase + k4;
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
+        const int k = kbase + k4;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             if (o.vec) {
-                long long a = addr(o, i, k, K);
-                v[i] = a >= 0 ? ld4(o.p + a) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const long long a = addr(o, i, k);
+                v[i] = a >= 0 ? ld4(o.p + a) : zero4();
             } else {
                 float e[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    long long a = addr(o, i, k + j, K);
+                    const long long a = addr(o, i, k + j);
                     e[j] = a >= 0 ? o.p[a] : 0.f;
                 }
                 v[i] = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
     }
-
-    __device__ __forceinline__ void store(float* s, int tid, const float4 (&v)[NI]) const {
-#pragma unroll
-        for (int i = 0; i < NI; ++i)
-            *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * i) * LDK + k4) = v[i];
-    }
+    __device__ __forceinline__ void advance(const Opnd&) { kbase += BK; }
 };
 
-// ------------------------------------------------------------------------------------------------
-// RC loader: tile [32 k][R rows]; thread t owns float4 at rows r4 = (t % (R/4))*4, k = t/(R/4) + KS*i.
-// ------------------------------------------------------------------------------------------------
 template <int R>
-struct LoaderRC {
+struct GenericRC : RCStore<R> {
     static constexpr int NI = R / 32;
     static constexpr int KS = 1024 / R;
-    static constexpr int LDR = R + 4;
-    int r4, k0, row;
-    // CONV: (tap, ci) of row..row+3 is fixed per thread
+    static constexpr bool kKC = false;
+    int k0, row, kbase, K;
     int kh[4], kw[4], ci[4];
     bool rok[4];
-
-    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid) {
-        r4 = (tid % (R / 4)) * 4;
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kb, int K_) {
+        const int r4 = (tid % (R / 4)) * 4;
         k0 = tid / (R / 4);
-        row = row0 + r4;
+        row = row0 + r4; kbase = kb; K = K_;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            int r = row + j;
+            const int r = row + j;
             rok[j] = r < o.rows;
             if (o.kind == BD_OPK_CONV) {
-                int tap = r / o.C;
+                const int tap = r / o.C;
                 ci[j] = r - tap * o.C;
                 kh[j] = tap / 3;
                 kw[j] = tap - kh[j] * 3;
@@ -174,58 +406,39 @@ struct LoaderRC {
             }
         }
     }
-
-    __device__ __forceinline__ long long addr(const Opnd& o, int j, int k, int K) const {
+    __device__ __forceinline__ long long addr(const Opnd& o, int j, int k) const {
         if (k >= K || !rok[j]) return -1;
         if (o.kind == BD_OPK_DENSE) return (long long)k * o.ld + ci[j];
-        if (o.kind == BD_OPK_WGT) {  // k = tap*C + co ; W[(co*9 + tap)*ld + ci]
-            int tap = k / o.C;
-            int co = k - tap * o.C;
+        if (o.kind == BD_OPK_WGT) {
+            const int tap = k / o.C;
+            const int co = k - tap * o.C;
             return ((long long)co * 9 + tap) * o.ld + ci[j];
         }
-        // CONV (wgrad): k = output pixel
-        int hw = o.Ho * o.Wo;
-        int b = k / hw;
-        int rem = k - b * hw;
-        int y = rem / o.Wo;
-        int x = rem - y * o.Wo;
-        int ys = y * o.stride - o.pad_t + kh[j], xs = x * o.stride - o.pad_l + kw[j];
+        int b, y, x;
+        decode_pixel(o, k, b, y, x);
+        const int ys = y * o.stride - o.pad_t + kh[j], xs = x * o.stride - o.pad_l + kw[j];
         if (ys < 0 || xs < 0 || ys >= (o.Hs << o.ups) || xs >= (o.Ws << o.ups)) return -1;
         return ((long long)b * o.Hs * o.Ws + (long long)(ys >> o.ups) * o.Ws + (xs >> o.ups)) * o.ld + ci[j];
     }
-
-    __device__ __forceinline__ void load(const Opnd& o, int kbase, int K, float4 (&v)[NI]) const {
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            int k = kbase + k0 + KS * i;
+            const int k = kbase + k0 + KS * i;
             if (o.vec) {
-                long long a = addr(o, 0, k, K);
-                v[i] = a >= 0 ? ld4(o.p + a) : make_float4(0.f, 0.f, 0.f, 0.f);
+                const long long a = addr(o, 0, k);
+                v[i] = a >= 0 ? ld4(o.p + a) : zero4();
             } else {
                 float e[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    long long a = addr(o, j, k, K);
+                    const long long a = addr(o, j, k);
                     e[j] = a >= 0 ? o.p[a] : 0.f;
                 }
                 v[i] = make_float4(e[0], e[1], e[2], e[3]);
             }
         }
     }
-
-    __device__ __forceinline__ void store(float* s, int tid, const float4 (&v)[NI]) const {
-#pragma unroll
-        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + (k0 + KS * i) * LDR + r4) = v[i];
-    }
-};
-
-template <int R, bool KC>
-struct LoaderSel {
-    typedef LoaderKC<R> type;
-};
-template <int R>
-struct LoaderSel<R, false> {
-    typedef LoaderRC<R> type;
+    __device__ __forceinline__ void advance(const Opnd&) { kbase += BK; }
 };
 
 template <int R, bool KC>
@@ -234,8 +447,9 @@ constexpr int lds_floats() {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, bool A_KC, bool B_KC>
+template <int BM, int BN, class LA, class LB>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
+    constexpr bool A_KC = LA::kKC, B_KC = LB::kKC;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     __shared__ __attribute__((aligned(16))) float sA[lds_floats<BM, A_KC>()];
     __shared__ __attribute__((aligned(16))) float sB[lds_floats<BN, B_KC>()];
@@ -246,7 +460,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     const int li = lane & 31, h = lane >> 5;
 
     // tile coordinates: n fastest so neighbouring workgroups share the A (activation) panel
-    int tile = blockIdx.x;
+    const int tile = blockIdx.x;
     const int tn_i = tile % p.tiles_n, tm_i = tile / p.tiles_n;
     const int m0 = tm_i * BM, n0 = tn_i * BN;
     const int bz = blockIdx.z / p.ksplit, ks = blockIdx.z - bz * p.ksplit;
@@ -256,10 +470,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     A.p += bo * p.a_bso + bi * p.a_bsi;
     B.p += bo * p.b_bso + bi * p.b_bsi;
 
-    typename LoaderSel<BM, A_KC>::type la;
-    typename LoaderSel<BN, B_KC>::type lb;
-    la.init(A, m0, tid);
-    lb.init(B, n0, tid);
+    const int nchunks_total = (p.K + BK - 1) / BK;
+    const int c_begin = ks * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > nchunks_total) c_end = nchunks_total;
+
+    LA la;
+    LB lb;
+    la.init(A, m0, tid, c_begin * BK, p.K);
+    lb.init(B, n0, tid, c_begin * BK, p.K);
 
     floatx16 acc[TM][TN];
 #pragma unroll
@@ -269,23 +488,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    const int nchunks_total = (p.K + BK - 1) / BK;
-    const int c_begin = ks * p.chunks_per_split;
-    int c_end = c_begin + p.chunks_per_split;
-    if (c_end > nchunks_total) c_end = nchunks_total;
-
     float4 ra[BM / 32], rb[BN / 32];
     if (c_begin < c_end) {
-        la.load(A, c_begin * BK, p.K, ra);
-        lb.load(B, c_begin * BK, p.K, rb);
+        la.load(A, ra);
+        lb.load(B, rb);
     }
     for (int c = c_begin; c < c_end; ++c) {
-        la.store(sA, tid, ra);
-        lb.store(sB, tid, rb);
+        LA::store(sA, tid, ra);
+        LB::store(sB, tid, rb);
         __syncthreads();
         if (c + 1 < c_end) {  // prefetch the next chunk into registers while this one is computed
-            la.load(A, (c + 1) * BK, p.K, ra);
-            lb.load(B, (c + 1) * BK, p.K, rb);
+            la.advance(A);
+            lb.advance(B);
+            la.load(A, ra);
+            lb.load(B, rb);
         }
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
@@ -294,7 +510,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
             for (int i = 0; i < TM; ++i) {
                 const int r = wm * WM + i * 32 + li;
                 if (A_KC) {
-                    float4 v = *reinterpret_cast<const float4*>(sA + r * LDK + g * 8 + 4 * h);
+                    const float4 v = *reinterpret_cast<const float4*>(sA + r * LDK + g * 8 + 4 * h);
                     fa[i][0] = v.x; fa[i][1] = v.y; fa[i][2] = v.z; fa[i][3] = v.w;
                 } else {
 #pragma unroll
@@ -305,7 +521,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
             for (int i = 0; i < TN; ++i) {
                 const int r = wn * WN + i * 32 + li;
                 if (B_KC) {
-                    float4 v = *reinterpret_cast<const float4*>(sB + r * LDK + g * 8 + 4 * h);
+                    const float4 v = *reinterpret_cast<const float4*>(sB + r * LDK + g * 8 + 4 * h);
                     fb[i][0] = v.x; fb[i][1] = v.y; fb[i][2] = v.z; fb[i][3] = v.w;
                 } else {
 #pragma unroll
@@ -331,6 +547,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         for (int q = 0; q < TN; ++q) {
             const int n = n0 + wn * WN + q * 32 + li;
             if (n >= p.N) continue;
+            const float bn = (p.ksplit == 1 && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -339,8 +556,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
                 if (p.ksplit > 1) {
                     p.partial[((long long)blockIdx.z * p.M + m) * p.N + n] = v;
                 } else {
-                    v *= p.alpha;
-                    if (p.bias) v += p.bias[n];
+                    v = v * p.alpha + bn;
                     if (p.rowbias) v += p.rowbias[(long long)(m / p.rows_per_group) * p.ld_rowbias + n];
                     if (p.residual) v += p.residual[coff + (long long)m * p.ldr + n];
                     v *= p.out_scale;
@@ -354,12 +570,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 
 // split-K second pass: fixed-order (deterministic) sum of the partial slabs + epilogue
 __global__ __launch_bounds__(256) void igemm_splitk_reduce(IGemmParams p, int nbatch) {
-    long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    long long per = (long long)p.M * p.N;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per = (long long)p.M * p.N;
     if (idx >= per * nbatch) return;
-    int bz = (int)(idx / per);
-    long long mn = idx - (long long)bz * per;
-    int m = (int)(mn / p.N), n = (int)(mn - (long long)m * p.N);
+    const int bz = (int)(idx / per);
+    const long long mn = idx - (long long)bz * per;
+    const int m = (int)(mn / p.N), n = (int)(mn - (long long)m * p.N);
     float v = 0.f;
     for (int s = 0; s < p.ksplit; ++s) v += p.partial[((long long)(bz * p.ksplit + s)) * per + mn];
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
@@ -381,9 +597,21 @@ static bool operand_vec_ok(const bd_operand& o, int rows, int K) {
         if (o.kind == BD_OPK_DENSE) return (K & 3) == 0;
         return (o.C & 3) == 0;  // CONV / TCONV: a float4 never straddles a tap
     }
-    // RC: float4 along rows
     if (o.kind == BD_OPK_CONV) return (o.C & 3) == 0;
     return (rows & 3) == 0;
+}
+// shape conditions of the FAST loader of this operand
+static bool operand_fast_ok(const bd_operand& o, int rows, int K) {
+    if (!operand_vec_ok(o, rows, K)) return false;
+    switch (o.kind) {
+        case BD_OPK_DENSE: return true;
+        case BD_OPK_CONV:
+            if (o.kc) return o.C % BK == 0 && (long long)o.Hs * o.Ws * o.ld < (1ll << 31);
+            return true;
+        case BD_OPK_TCONV: return o.C % BK == 0 && (long long)o.Hs * o.Ws * o.ld < (1ll << 31);
+        case BD_OPK_WGT: return o.C % BK == 0;
+    }
+    return false;
 }
 
 static int validate_operand(const bd_operand& o, const char* which) {
@@ -398,8 +626,7 @@ static int validate_operand(const bd_operand& o, const char* which) {
     if (o.kind != BD_OPK_DENSE) {
         BD_CHECK(o.C > 0, BD_ERR_INVALID, "igemm: operand %s: C must be > 0", which);
         if (o.kind != BD_OPK_WGT) {
-            BD_CHECK(o.Hs > 0 && o.Ws > 0 && o.Ho > 0 && o.Wo > 0, BD_ERR_INVALID,
-                     "igemm: operand %s: bad conv geometry", which);
+            BD_CHECK(o.Hs > 0 && o.Ws > 0 && o.Ho > 0 && o.Wo > 0, BD_ERR_INVALID, "igemm: operand %s: bad conv geometry", which);
             BD_CHECK(o.stride == 1 || o.stride == 2, BD_ERR_UNSUPPORTED, "igemm: stride %d unsupported", o.stride);
             BD_CHECK(o.ups == 0 || o.ups == 1, BD_ERR_UNSUPPORTED, "igemm: ups %d unsupported", o.ups);
             BD_CHECK(!(o.ups && o.kind == BD_OPK_TCONV), BD_ERR_UNSUPPORTED, "igemm: TCONV with ups");
@@ -408,11 +635,21 @@ static int validate_operand(const bd_operand& o, const char* which) {
     return BD_OK;
 }
 
+static int ilog2_exact(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
 static Opnd make_opnd(const bd_operand& o, int rows, int K) {
     Opnd r;
     r.p = o.p; r.ld = o.ld; r.kind = o.kind; r.vec = operand_vec_ok(o, rows, K) ? 1 : 0;
     r.C = o.C > 0 ? o.C : 1; r.Hs = o.Hs; r.Ws = o.Ws; r.Ho = o.Ho > 0 ? o.Ho : 1; r.Wo = o.Wo > 0 ? o.Wo : 1;
     r.stride = o.stride > 0 ? o.stride : 1; r.pad_t = o.pad_t; r.pad_l = o.pad_l; r.ups = o.ups; r.rows = rows;
+    const int lw = ilog2_exact(r.Wo), lh = ilog2_exact(r.Ho);
+    r.lw = (lw >= 0 && lh >= 0) ? lw : -1;
+    r.lhw = (lw >= 0 && lh >= 0) ? lw + lh : -1;
     return r;
 }
 
@@ -452,12 +689,47 @@ size_t igemm_workspace_bytes(const bd_igemm_desc& d) {
     return (size_t)d.batch_outer * d.batch_inner * c.ksplit * (size_t)d.M * d.N * sizeof(float);
 }
 
+template <int T, class LA, class LB>
+static void launch1(const IGemmParams& p, dim3 grid, hipStream_t st) {
+    hipLaunchKernelGGL((igemm_kernel<T, T, LA, LB>), grid, dim3(256), 0, st, p);
+}
+
+enum Cls { CLS_GENERIC = 0, CLS_CONV_FWD, CLS_CONV_DGRAD, CLS_CONV_WGRAD, CLS_GEMM_NT, CLS_GEMM_NN, CLS_GEMM_TN };
+static const char* kClsName[] = {"generic", "conv_fwd", "conv_dgrad", "conv_wgrad", "gemm_nt", "gemm_nn", "gemm_tn"};
+
+static Cls classify(const bd_igemm_desc& d, bool fast) {
+    if (!fast) return CLS_GENERIC;
+    const int ak = d.A.kind, bk = d.B.kind;
+    const bool akc = d.A.kc != 0, bkc = d.B.kc != 0;
+    if (akc && bkc) {
+        if (ak == BD_OPK_CONV && bk == BD_OPK_DENSE) return CLS_CONV_FWD;
+        if (ak == BD_OPK_DENSE && bk == BD_OPK_DENSE) return CLS_GEMM_NT;
+    } else if (akc && !bkc) {
+        if (ak == BD_OPK_TCONV && bk == BD_OPK_WGT) return CLS_CONV_DGRAD;
+        if (ak == BD_OPK_DENSE && bk == BD_OPK_DENSE) return CLS_GEMM_NN;
+    } else if (!akc && !bkc) {
+        if (ak == BD_OPK_DENSE && bk == BD_OPK_CONV) return CLS_CONV_WGRAD;
+        if (ak == BD_OPK_DENSE && bk == BD_OPK_DENSE) return CLS_GEMM_TN;
+    }
+    return CLS_GENERIC;
+}
+
 template <int T>
-static void launch_tile(const IGemmParams& p, bool akc, bool bkc, dim3 grid, hipStream_t st) {
-    if (akc && bkc) hipLaunchKernelGGL((igemm_kernel<T, T, true, true>), grid, dim3(256), 0, st, p);
-    else if (akc && !bkc) hipLaunchKernelGGL((igemm_kernel<T, T, true, false>), grid, dim3(256), 0, st, p);
-    else if (!akc && !bkc) hipLaunchKernelGGL((igemm_kernel<T, T, false, false>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((igemm_kernel<T, T, false, true>), grid, dim3(256), 0, st, p);
+static void launch_tile(const IGemmParams& p, const bd_igemm_desc& d, Cls cls, dim3 grid, hipStream_t st) {
+    switch (cls) {
+        case CLS_CONV_FWD: launch1<T, ConvKC<T>, DenseKC<T>>(p, grid, st); return;
+        case CLS_GEMM_NT: launch1<T, DenseKC<T>, DenseKC<T>>(p, grid, st); return;
+        case CLS_CONV_DGRAD: launch1<T, TConvKC<T>, WgtRC<T>>(p, grid, st); return;
+        case CLS_GEMM_NN: launch1<T, DenseKC<T>, DenseRC<T>>(p, grid, st); return;
+        case CLS_CONV_WGRAD: launch1<T, DenseRC<T>, ConvRC<T>>(p, grid, st); return;
+        case CLS_GEMM_TN: launch1<T, DenseRC<T>, DenseRC<T>>(p, grid, st); return;
+        default: break;
+    }
+    const bool akc = d.A.kc != 0, bkc = d.B.kc != 0;
+    if (akc && bkc) launch1<T, GenericKC<T>, GenericKC<T>>(p, grid, st);
+    else if (akc && !bkc) launch1<T, GenericKC<T>, GenericRC<T>>(p, grid, st);
+    else if (!akc && !bkc) launch1<T, GenericRC<T>, GenericRC<T>>(p, grid, st);
+    else launch1<T, GenericRC<T>, GenericKC<T>>(p, grid, st);
 }
 
 int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
@@ -492,22 +764,24 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
     }
     dim3 grid(p.tiles_m * p.tiles_n, 1, nb * c.ksplit);
     BD_CHECK(grid.z <= 65535, BD_ERR_UNSUPPORTED, "igemm: batch*ksplit %u too large", grid.z);
+    const bool fast = operand_fast_ok(d.A, d.M, d.K) && operand_fast_ok(d.B, d.N, d.K);
+    const Cls cls = classify(d, fast);
     int rec = -1;
     if (prof_on()) {
         auto op_bytes = [&](const bd_operand& o, int rows) -> double {
             if (o.kind == BD_OPK_CONV || o.kind == BD_OPK_TCONV) {
-                const double pixels = o.kc ? (double)d.M / ((double)o.Ho * o.Wo) : (double)d.K / ((double)o.Ho * o.Wo);
-                return pixels * o.Hs * o.Ws * o.C * 4.0;
+                const double imgs = o.kc ? (double)d.M / ((double)o.Ho * o.Wo) : (double)d.K / ((double)o.Ho * o.Wo);
+                return imgs * o.Hs * o.Ws * o.C * 4.0;
             }
             return (double)rows * d.K * 4.0;
         };
         char name[64];
-        snprintf(name, sizeof(name), "igemm_%d_%s_%s", c.tile, d.A.kc ? "kc" : "rc", d.B.kc ? "kc" : "rc");
+        snprintf(name, sizeof(name), "igemm_%s_%d", kClsName[cls], c.tile);
         rec = prof_begin(name, 2.0 * d.M * d.N * (double)d.K * nb,
                          (op_bytes(d.A, d.M) + op_bytes(d.B, d.N) + (double)d.M * d.N * 4.0) * nb, stream);
     }
-    if (c.tile == 128) launch_tile<128>(p, d.A.kc != 0, d.B.kc != 0, grid, stream);
-    else launch_tile<64>(p, d.A.kc != 0, d.B.kc != 0, grid, stream);
+    if (c.tile == 128) launch_tile<128>(p, d, cls, grid, stream);
+    else launch_tile<64>(p, d, cls, grid, stream);
     BD_LAUNCH_CHECK("igemm");
     if (c.ksplit > 1) {
         long long total = (long long)d.M * d.N * nb;
