@@ -66,7 +66,7 @@ class IgemmDesc(C.Structure):
                 ("alpha", f32), ("out_scale", f32), ("bias", vp),
                 ("rowbias", vp), ("ld_rowbias", i64), ("rows_per_group", i32),
                 ("residual", vp), ("ldr", i64), ("accumulate", i32), ("ksplit", i32),
-                ("workspace", vp), ("workspace_bytes", sz), ("tile", i32)]
+                ("workspace", vp), ("workspace_bytes", sz), ("tile", i32), ("mode", i32)]
 
 
 class ConvFwdDesc(C.Structure):
@@ -74,21 +74,21 @@ class ConvFwdDesc(C.Structure):
                 ("pad_t", i32), ("pad_l", i32), ("ups", i32), ("Ho", i32), ("Wo", i32),
                 ("x", vp), ("ldx", i64), ("w", vp), ("bias", vp), ("rowbias", vp), ("ld_rowbias", i64),
                 ("residual", vp), ("ldr", i64), ("out_scale", f32), ("y", vp), ("ldy", i64),
-                ("workspace", vp), ("workspace_bytes", sz)]
+                ("workspace", vp), ("workspace_bytes", sz), ("mode", i32)]
 
 
 class ConvDgradDesc(C.Structure):
     _fields_ = [("B", i32), ("Hs", i32), ("Ws", i32), ("Cin", i32), ("Cout", i32), ("stride", i32),
                 ("pad_t", i32), ("pad_l", i32), ("ups", i32), ("Ho", i32), ("Wo", i32),
                 ("dy", vp), ("lddy", i64), ("w", vp), ("dx", vp), ("lddx", i64), ("accumulate", i32),
-                ("workspace", vp), ("workspace_bytes", sz)]
+                ("workspace", vp), ("workspace_bytes", sz), ("mode", i32)]
 
 
 class ConvWgradDesc(C.Structure):
     _fields_ = [("B", i32), ("Hs", i32), ("Ws", i32), ("Cin", i32), ("Cout", i32), ("stride", i32),
                 ("pad_t", i32), ("pad_l", i32), ("ups", i32), ("Ho", i32), ("Wo", i32),
                 ("x", vp), ("ldx", i64), ("dy", vp), ("lddy", i64), ("dw", vp),
-                ("workspace", vp), ("workspace_bytes", sz)]
+                ("workspace", vp), ("workspace_bytes", sz), ("mode", i32)]
 
 
 class UnetConfig(C.Structure):
@@ -96,7 +96,7 @@ class UnetConfig(C.Structure):
                 ("block_out_channels", i32 * 8), ("down_attn", i32 * 8), ("up_attn", i32 * 8),
                 ("layers_per_block", i32), ("downsample_padding", i32), ("flip_sin_to_cos", i32),
                 ("freq_shift", f32), ("norm_eps", f32), ("norm_num_groups", i32), ("attention_head_dim", i32),
-                ("mid_block_scale_factor", f32)]
+                ("mid_block_scale_factor", f32), ("compute_mode", i32)]
 
 
 # name -> (restype, argtypes).  Every symbol declared in include/bd_hip.h must appear here
@@ -139,6 +139,7 @@ SIGNATURES = {
     "bd_adam_clip_dev": (i32, [vp, vp, vp, vp, i64, vp, f64, vp, f64, f64, f64, vp, vp]),
     "bd_unet_create": (i32, [C.POINTER(UnetConfig), C.POINTER(vp)]),
     "bd_unet_destroy": (None, [vp]),
+    "bd_unet_set_compute_mode": (i32, [vp, i32]),
     "bd_unet_num_params": (i64, [vp]),
     "bd_unet_num_tensors": (i32, [vp]),
     "bd_unet_param_info": (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i32), i64 * 4, C.POINTER(i32)]),

@@ -26,7 +26,7 @@ int conv3x3_fwd(const bd_conv3x3_fwd_desc& d, hipStream_t st) {
     g.A.kind = BD_OPK_CONV; g.A.kc = 1; g.A.p = d.x; g.A.ld = d.ldx;
     g.A.C = d.Cin; g.A.Hs = d.Hs; g.A.Ws = d.Ws; g.A.Ho = d.Ho; g.A.Wo = d.Wo;
     g.A.stride = d.stride; g.A.pad_t = d.pad_t; g.A.pad_l = d.pad_l; g.A.ups = d.ups;
-    g.B.kind = BD_OPK_DENSE; g.B.kc = 1; g.B.p = d.w; g.B.ld = 9ll * d.Cin;
+    g.B.kind = BD_OPK_DENSE; g.B.kc = 1; g.B.p = d.w; g.B.ld = 9ll * d.Cin; g.B.C = d.Cin;
     g.M = d.B * d.Ho * d.Wo; g.N = d.Cout; g.K = 9 * d.Cin;
     g.batch_outer = g.batch_inner = 1;
     g.C = d.y; g.ldc = d.ldy;
@@ -34,7 +34,7 @@ int conv3x3_fwd(const bd_conv3x3_fwd_desc& d, hipStream_t st) {
     g.bias = d.bias;
     g.rowbias = d.rowbias; g.ld_rowbias = d.ld_rowbias; g.rows_per_group = d.Ho * d.Wo;
     g.residual = d.residual; g.ldr = d.ldr;
-    g.workspace = d.workspace; g.workspace_bytes = d.workspace_bytes;
+    g.workspace = d.workspace; g.workspace_bytes = d.workspace_bytes; g.mode = d.mode;
     return igemm_launch(g, st);
 }
 
@@ -51,7 +51,7 @@ int conv3x3_dgrad(const bd_conv3x3_dgrad_desc& d, hipStream_t st) {
     g.batch_outer = g.batch_inner = 1;
     g.C = d.dx; g.ldc = d.lddx;
     g.alpha = 1.f; g.out_scale = 1.f; g.accumulate = d.accumulate;
-    g.workspace = d.workspace; g.workspace_bytes = d.workspace_bytes;
+    g.workspace = d.workspace; g.workspace_bytes = d.workspace_bytes; g.mode = d.mode;
     return igemm_launch(g, st);
 }
 
@@ -67,7 +67,7 @@ int conv3x3_wgrad(const bd_conv3x3_wgrad_desc& d, hipStream_t st) {
     g.batch_outer = g.batch_inner = 1;
     g.C = d.dw; g.ldc = 9ll * d.Cin;
     g.alpha = 1.f; g.out_scale = 1.f;
-    g.workspace = d.workspace; g.workspace_bytes = d.workspace_bytes;
+    g.workspace = d.workspace; g.workspace_bytes = d.workspace_bytes; g.mode = d.mode;
     return igemm_launch(g, st);
 }
 

@@ -23,6 +23,18 @@
 namespace bd {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// split 8 fp32 values into hi + lo bf16 planes: hi = the upper 16 bits of x (truncation, exact), lo = RNE(x - hi);
+// x = hi + lo + O(2^-17 |x|).  ~2.6 VALU per element (v_and / v_perm / v_sub / v_cvt_pk_bf16_f32).
+__device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned u = __builtin_bit_cast(unsigned, x[j]);
+        hi[j] = __builtin_bit_cast(__bf16, (unsigned short)(u >> 16));
+        lo[j] = (__bf16)(x[j] - __builtin_bit_cast(float, u & 0xFFFF0000u));
+    }
+}
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;  // KC row stride (floats): 16B-aligned rows, conflict-free b128 reads
@@ -136,8 +148,9 @@ struct ConvKC : KCStore<R> {
     int kh, kw, c0;         // wave-uniform cursor
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
         const int k4 = (tid & 7) * 4;
-        const int tap = kbase / o.C;
-        c0 = kbase - tap * o.C;
+        const int chunk = kbase / BK;      // K order: channel block outer, tap inner (9 chunks share one input window)
+        const int tap = chunk % 9;
+        c0 = (chunk / 9) * BK;
         kh = tap / 3;
         kw = tap - kh * 3;
 #pragma unroll
@@ -155,17 +168,46 @@ struct ConvKC : KCStore<R> {
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
             const int ys = y0[i] + kh, xs = x0[i] + kw;
-            const bool okk = (unsigned)ys < (unsigned)He && (unsigned)xs < (unsigned)We && kh < 3;
+            const bool okk = (unsigned)ys < (unsigned)He && (unsigned)xs < (unsigned)We && c0 < o.C;
             const int off = ((ys >> o.ups) * o.Ws + (xs >> o.ups)) * (int)o.ld + c0;
             v[i] = okk ? ld4(base[i] + off) : zero4();
         }
     }
-    __device__ __forceinline__ void advance(const Opnd& o) {
-        c0 += BK;
-        if (c0 >= o.C) {
-            c0 = 0;
-            if (++kw == 3) { kw = 0; ++kh; }
+    __device__ __forceinline__ void advance(const Opnd&) {
+        if (++kw == 3) {
+            kw = 0;
+            if (++kh == 3) { kh = 0; c0 += BK; }
         }
+    }
+};
+
+// forward-conv weights W[co][tap][ci] (ld = 9*C) walked in ConvKC's K order (channel block outer, tap inner)
+template <int R>
+struct WgtKC : KCStore<R> {
+    static constexpr int NI = R / 32;
+    static constexpr bool kKC = true;
+    const float* ptr[NI];
+    bool ok[NI];
+    int tap, c0;
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
+        const int k4 = (tid & 7) * 4;
+        const int chunk = kbase / BK;
+        tap = chunk % 9;
+        c0 = (chunk / 9) * BK;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int r = row0 + (tid >> 3) + 32 * i;
+            ok[i] = r < o.rows;
+            ptr[i] = o.p + (long long)r * o.ld + k4;
+        }
+    }
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
+        const int off = tap * o.C + c0;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) v[i] = (ok[i] && c0 < o.C) ? ld4(ptr[i] + off) : zero4();
+    }
+    __device__ __forceinline__ void advance(const Opnd&) {
+        if (++tap == 9) { tap = 0; c0 += BK; }
     }
 };
 
@@ -179,8 +221,9 @@ struct TConvKC : KCStore<R> {
     int kh, kw, c0;
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
         const int k4 = (tid & 7) * 4;
-        const int tap = kbase / o.C;
-        c0 = kbase - tap * o.C;
+        const int chunk = kbase / BK;      // K order: channel block outer, tap inner (9 chunks share one input window)
+        const int tap = chunk % 9;
+        c0 = (chunk / 9) * BK;
         kh = tap / 3;
         kw = tap - kh * 3;
 #pragma unroll
@@ -199,16 +242,15 @@ struct TConvKC : KCStore<R> {
         for (int i = 0; i < NI; ++i) {
             const int yn = y0[i] - kh, xn = x0[i] - kw;
             const int ys = yn >> sh, xs = xn >> sh;
-            const bool okk = yn >= 0 && xn >= 0 && ((yn | xn) & sh) == 0 && ys < o.Hs && xs < o.Ws && kh < 3;
+            const bool okk = yn >= 0 && xn >= 0 && ((yn | xn) & sh) == 0 && ys < o.Hs && xs < o.Ws && c0 < o.C;
             const int off = (ys * o.Ws + xs) * (int)o.ld + c0;
             v[i] = okk ? ld4(base[i] + off) : zero4();
         }
     }
-    __device__ __forceinline__ void advance(const Opnd& o) {
-        c0 += BK;
-        if (c0 >= o.C) {
-            c0 = 0;
-            if (++kw == 3) { kw = 0; ++kh; }
+    __device__ __forceinline__ void advance(const Opnd&) {
+        if (++kw == 3) {
+            kw = 0;
+            if (++kh == 3) { kh = 0; c0 += BK; }
         }
     }
 };
@@ -252,19 +294,19 @@ struct WgtRC : RCStore<R> {
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
         const int r4 = (tid % (R / 4)) * 4, k0 = tid / (R / 4);
         ok = row0 + r4 < o.rows;
-        tap = kbase / o.C;
-        c0 = kbase - tap * o.C;
+        const int chunk = kbase / BK;      // same K order as TConvKC: channel block outer, tap inner
+        tap = chunk % 9;
+        c0 = (chunk / 9) * BK;
         ptr = o.p + (row0 + r4) + (long long)k0 * 9 * o.ld;
         step = (long long)KS * 9 * o.ld;
     }
     __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
         const float* q = ptr + ((long long)c0 * 9 + tap) * o.ld;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) v[i] = (ok && tap < 9) ? ld4(q + step * i) : zero4();
+        for (int i = 0; i < NI; ++i) v[i] = (ok && c0 < o.C) ? ld4(q + step * i) : zero4();
     }
-    __device__ __forceinline__ void advance(const Opnd& o) {
-        c0 += BK;
-        if (c0 >= o.C) { c0 = 0; ++tap; }
+    __device__ __forceinline__ void advance(const Opnd&) {
+        if (++tap == 9) { tap = 0; c0 += BK; }
     }
 };
 
@@ -447,7 +489,7 @@ constexpr int lds_floats() {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, class LA, class LB>
+template <int BM, int BN, class LA, class LB, int MODE>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     constexpr bool A_KC = LA::kKC, B_KC = LB::kKC;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -460,7 +502,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     const int li = lane & 31, h = lane >> 5;
 
     // tile coordinates: n fastest so neighbouring workgroups share the A (activation) panel
-    const int tile = blockIdx.x;
+    // XCD-aware order (cdna guide T1): workgroup b runs on XCD b % 8, so give every XCD a contiguous run of
+    // logical tiles -- neighbours (same A panel, next n; adjacent m) then share that XCD's L2.  Speed only.
+    int tile = blockIdx.x;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
     const int tn_i = tile % p.tiles_n, tm_i = tile / p.tiles_n;
     const int m0 = tm_i * BM, n0 = tn_i * BN;
     const int bz = blockIdx.z / p.ksplit, ks = blockIdx.z - bz * p.ksplit;
@@ -503,6 +549,54 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
             la.load(A, ra);
             lb.load(B, rb);
         }
+        if (MODE == BD_MODE_BF16X3) {
+            // split-bf16: per 16-wide k step every lane reads 8 fp32 per fragment (k = 16s + 8h + j), splits them
+            // into hi/lo bf16 and issues hi*hi + hi*lo + lo*hi on the bf16 MFMA (fp32 accumulate)
+#pragma unroll
+            for (int s = 0; s < BK / 16; ++s) {
+                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i) {
+                    const int r = wm * WM + i * 32 + li;
+                    float x[8];
+                    if (A_KC) {
+                        const float4 v0 = *reinterpret_cast<const float4*>(sA + r * LDK + s * 16 + 8 * h);
+                        const float4 v1 = *reinterpret_cast<const float4*>(sA + r * LDK + s * 16 + 8 * h + 4);
+                        x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) x[j] = sA[(s * 16 + 8 * h + j) * (BM + 4) + r];
+                    }
+                    split8(x, ah[i], al[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    const int r = wn * WN + i * 32 + li;
+                    float x[8];
+                    if (B_KC) {
+                        const float4 v0 = *reinterpret_cast<const float4*>(sB + r * LDK + s * 16 + 8 * h);
+                        const float4 v1 = *reinterpret_cast<const float4*>(sB + r * LDK + s * 16 + 8 * h + 4);
+                        x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 8; ++j) x[j] = sB[(s * 16 + 8 * h + j) * (BN + 4) + r];
+                    }
+                    split8(x, bh[i], bl[i]);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < TN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < TN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int q = 0; q < TN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
+            }
+        } else {
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             float fa[TM][4], fb[TN][4];
@@ -535,6 +629,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 #pragma unroll
                     for (int q = 0; q < TN; ++q)
                         acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[q][j], acc[i][q], 0, 0, 0);
+        }
         }
         __syncthreads();
     }
@@ -690,8 +785,9 @@ size_t igemm_workspace_bytes(const bd_igemm_desc& d) {
 }
 
 template <int T, class LA, class LB>
-static void launch1(const IGemmParams& p, dim3 grid, hipStream_t st) {
-    hipLaunchKernelGGL((igemm_kernel<T, T, LA, LB>), grid, dim3(256), 0, st, p);
+static void launch1(const IGemmParams& p, dim3 grid, hipStream_t st, int mode) {
+    if (mode == BD_MODE_BF16X3) hipLaunchKernelGGL((igemm_kernel<T, T, LA, LB, BD_MODE_BF16X3>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<T, T, LA, LB, BD_MODE_F32>), grid, dim3(256), 0, st, p);
 }
 
 enum Cls { CLS_GENERIC = 0, CLS_CONV_FWD, CLS_CONV_DGRAD, CLS_CONV_WGRAD, CLS_GEMM_NT, CLS_GEMM_NN, CLS_GEMM_TN };
@@ -716,20 +812,21 @@ static Cls classify(const bd_igemm_desc& d, bool fast) {
 
 template <int T>
 static void launch_tile(const IGemmParams& p, const bd_igemm_desc& d, Cls cls, dim3 grid, hipStream_t st) {
+    const int mode = d.mode;
     switch (cls) {
-        case CLS_CONV_FWD: launch1<T, ConvKC<T>, DenseKC<T>>(p, grid, st); return;
-        case CLS_GEMM_NT: launch1<T, DenseKC<T>, DenseKC<T>>(p, grid, st); return;
-        case CLS_CONV_DGRAD: launch1<T, TConvKC<T>, WgtRC<T>>(p, grid, st); return;
-        case CLS_GEMM_NN: launch1<T, DenseKC<T>, DenseRC<T>>(p, grid, st); return;
-        case CLS_CONV_WGRAD: launch1<T, DenseRC<T>, ConvRC<T>>(p, grid, st); return;
-        case CLS_GEMM_TN: launch1<T, DenseRC<T>, DenseRC<T>>(p, grid, st); return;
+        case CLS_CONV_FWD: launch1<T, ConvKC<T>, WgtKC<T>>(p, grid, st, mode); return;
+        case CLS_GEMM_NT: launch1<T, DenseKC<T>, DenseKC<T>>(p, grid, st, mode); return;
+        case CLS_CONV_DGRAD: launch1<T, TConvKC<T>, WgtRC<T>>(p, grid, st, mode); return;
+        case CLS_GEMM_NN: launch1<T, DenseKC<T>, DenseRC<T>>(p, grid, st, mode); return;
+        case CLS_CONV_WGRAD: launch1<T, DenseRC<T>, ConvRC<T>>(p, grid, st, mode); return;
+        case CLS_GEMM_TN: launch1<T, DenseRC<T>, DenseRC<T>>(p, grid, st, mode); return;
         default: break;
     }
     const bool akc = d.A.kc != 0, bkc = d.B.kc != 0;
-    if (akc && bkc) launch1<T, GenericKC<T>, GenericKC<T>>(p, grid, st);
-    else if (akc && !bkc) launch1<T, GenericKC<T>, GenericRC<T>>(p, grid, st);
-    else if (!akc && !bkc) launch1<T, GenericRC<T>, GenericRC<T>>(p, grid, st);
-    else launch1<T, GenericRC<T>, GenericKC<T>>(p, grid, st);
+    if (akc && bkc) launch1<T, GenericKC<T>, GenericKC<T>>(p, grid, st, mode);
+    else if (akc && !bkc) launch1<T, GenericKC<T>, GenericRC<T>>(p, grid, st, mode);
+    else if (!akc && !bkc) launch1<T, GenericRC<T>, GenericRC<T>>(p, grid, st, mode);
+    else launch1<T, GenericRC<T>, GenericKC<T>>(p, grid, st, mode);
 }
 
 int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
@@ -737,6 +834,7 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
     BD_CHECK(d.batch_outer >= 1 && d.batch_inner >= 1, BD_ERR_INVALID, "igemm: batch counts must be >= 1");
     BD_CHECK(d.C != nullptr, BD_ERR_INVALID, "igemm: C is null");
     BD_CHECK(d.tile == 0 || d.tile == 64 || d.tile == 128, BD_ERR_INVALID, "igemm: tile must be 0, 64 or 128");
+    BD_CHECK(d.mode == BD_MODE_F32 || d.mode == BD_MODE_BF16X3, BD_ERR_INVALID, "igemm: unknown compute mode %d", d.mode);
     BD_TRY(validate_operand(d.A, "A"));
     BD_TRY(validate_operand(d.B, "B"));
     BD_CHECK(!(d.rowbias && d.rows_per_group <= 0), BD_ERR_INVALID, "igemm: rowbias needs rows_per_group > 0");
@@ -776,7 +874,7 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
             return (double)rows * d.K * 4.0;
         };
         char name[64];
-        snprintf(name, sizeof(name), "igemm_%s_%d", kClsName[cls], c.tile);
+        snprintf(name, sizeof(name), "igemm_%s_%d%s", kClsName[cls], c.tile, d.mode == BD_MODE_BF16X3 ? "_bf16x3" : "");
         rec = prof_begin(name, 2.0 * d.M * d.N * (double)d.K * nb,
                          (op_bytes(d.A, d.M) + op_bytes(d.B, d.N) + (double)d.M * d.N * 4.0) * nb, stream);
     }

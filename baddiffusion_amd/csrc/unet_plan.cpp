@@ -142,7 +142,7 @@ struct bd_unet {
     static int64_t rows(const Ctx& c, const View& v) { return (int64_t)c.B * v.H * v.W; }
 
     int igemm(Ctx& c, bd_igemm_desc& g) const {
-        g.workspace = c.opws; g.workspace_bytes = c.opws_bytes;
+        g.workspace = c.opws; g.workspace_bytes = c.opws_bytes; g.mode = cfg.compute_mode;
         if (c.dry) {
             size_t n = igemm_workspace_bytes(g);
             if (n > c.opws_need) c.opws_need = n;
@@ -224,17 +224,17 @@ struct bd_unet {
         return add_launch(src, lds, dst, ldd, nrows, C, scale, acc, c.st);
     }
     int conv_f(Ctx& c, bd_conv3x3_fwd_desc& d) const {
-        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes; d.mode = cfg.compute_mode;
         if (c.dry) { note_conv(c); return BD_OK; }
         return conv3x3_fwd(d, c.st);
     }
     int conv_d(Ctx& c, bd_conv3x3_dgrad_desc& d) const {
-        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes; d.mode = cfg.compute_mode;
         if (c.dry) { note_conv(c); return BD_OK; }
         return conv3x3_dgrad(d, c.st);
     }
     int conv_w(Ctx& c, bd_conv3x3_wgrad_desc& d) const {
-        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes; d.mode = cfg.compute_mode;
         if (c.dry) { note_conv(c); return BD_OK; }
         return conv3x3_wgrad(d, c.st);
     }
@@ -809,6 +809,7 @@ extern "C" int bd_unet_create(const bd_unet_config* cfg, bd_unet** out) {
                      "bd_unet_create: attention_head_dim %d must divide %d and be a multiple of 4", cfg->attention_head_dim, C);
     }
     BD_CHECK(cfg->mid_block_scale_factor != 0.f, BD_ERR_INVALID, "bd_unet_create: mid_block_scale_factor == 0");
+    BD_CHECK(cfg->compute_mode == BD_MODE_F32 || cfg->compute_mode == BD_MODE_BF16X3, BD_ERR_INVALID, "bd_unet_create: compute_mode %d", cfg->compute_mode);
     bd_unet* u = new (std::nothrow) bd_unet();
     BD_CHECK(u, BD_ERR_INVALID, "bd_unet_create: out of host memory");
     u->cfg = *cfg;
@@ -817,6 +818,11 @@ extern "C" int bd_unet_create(const bd_unet_config* cfg, bd_unet** out) {
     return BD_OK;
 }
 extern "C" void bd_unet_destroy(bd_unet* u) { delete u; }
+extern "C" int bd_unet_set_compute_mode(bd_unet* u, int mode) {
+    BD_CHECK(u && (mode == BD_MODE_F32 || mode == BD_MODE_BF16X3), BD_ERR_INVALID, "bd_unet_set_compute_mode: bad arguments");
+    u->cfg.compute_mode = mode;
+    return BD_OK;
+}
 extern "C" int64_t bd_unet_num_params(const bd_unet* u) { return u ? u->nparams : 0; }
 extern "C" int bd_unet_num_tensors(const bd_unet* u) { return u ? (int)u->params.size() : 0; }
 extern "C" int bd_unet_param_info(const bd_unet* u, int i, const char** name, int64_t* offset, int* rank, int64_t shape[4],

@@ -200,7 +200,7 @@ def _conv_out_hw(Hs, Ws, stride, pad_t, pad_l, ups, pad_b=None, pad_r=None):
     return (Hi + pad_t + pad_b - 3) // stride + 1, (Wi + pad_l + pad_r - 3) // stride + 1
 
 
-def conv3x3_fwd(x, w, bias=None, stride=1, pad=1, ups=0, asym=False, rowbias=None, residual=None, out_scale=1.0):
+def conv3x3_fwd(x, w, bias=None, stride=1, pad=1, ups=0, asym=False, rowbias=None, residual=None, out_scale=1.0, mode=0):
     """x [B,Hs,Ws,Cin] NHWC ; w [Cout,3,3,Cin].  asym => F.pad(0,1,0,1) + stride-2 conv with padding 0."""
     lib = L.load(); _need_cuda(x, w, bias, rowbias, residual)
     B, Hs, Ws, Cin = x.shape
@@ -213,12 +213,12 @@ def conv3x3_fwd(x, w, bias=None, stride=1, pad=1, ups=0, asym=False, rowbias=Non
                       x=L.ptr(x), ldx=_ld(x), w=L.ptr(w), bias=L.ptr(bias), rowbias=L.ptr(rowbias),
                       ld_rowbias=rowbias.stride(0) if rowbias is not None else 0, residual=L.ptr(residual),
                       ldr=_ld(residual) if residual is not None else 0, out_scale=out_scale, y=L.ptr(y), ldy=Cout,
-                      workspace=L.ptr(ws), workspace_bytes=ws.numel())
+                      workspace=L.ptr(ws), workspace_bytes=ws.numel(), mode=mode)
     L.check(lib.bd_conv3x3_fwd(C.byref(d), L.stream()), "bd_conv3x3_fwd")
     return y
 
 
-def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False):
+def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False, mode=0):
     """Returns dx over the conv's own input grid [B, Hs<<ups, Ws<<ups, Cin]."""
     lib = L.load(); _need_cuda(dy, w)
     B, Hs, Ws, Cin = x_shape
@@ -229,12 +229,12 @@ def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False):
     ws = workspace(lib.bd_conv3x3_workspace_bytes(B, Ho, Wo, Hs, Ws, Cin, Cout, ups), dy.device)
     d = L.ConvDgradDesc(B=B, Hs=Hs, Ws=Ws, Cin=Cin, Cout=Cout, stride=stride, pad_t=pt, pad_l=pl, ups=ups, Ho=Ho, Wo=Wo,
                         dy=L.ptr(dy), lddy=_ld(dy), w=L.ptr(w), dx=L.ptr(dx), lddx=Cin, accumulate=0,
-                        workspace=L.ptr(ws), workspace_bytes=ws.numel())
+                        workspace=L.ptr(ws), workspace_bytes=ws.numel(), mode=mode)
     L.check(lib.bd_conv3x3_dgrad(C.byref(d), L.stream()), "bd_conv3x3_dgrad")
     return dx
 
 
-def conv3x3_wgrad(x, dy, stride=1, pad=1, ups=0, asym=False):
+def conv3x3_wgrad(x, dy, stride=1, pad=1, ups=0, asym=False, mode=0):
     lib = L.load(); _need_cuda(x, dy)
     B, Hs, Ws, Cin = x.shape
     Cout = dy.shape[-1]
@@ -244,12 +244,12 @@ def conv3x3_wgrad(x, dy, stride=1, pad=1, ups=0, asym=False):
     ws = workspace(lib.bd_conv3x3_workspace_bytes(B, Ho, Wo, Hs, Ws, Cin, Cout, ups), x.device)
     d = L.ConvWgradDesc(B=B, Hs=Hs, Ws=Ws, Cin=Cin, Cout=Cout, stride=stride, pad_t=pt, pad_l=pl, ups=ups, Ho=Ho, Wo=Wo,
                         x=L.ptr(x), ldx=_ld(x), dy=L.ptr(dy), lddy=_ld(dy), dw=L.ptr(dw), workspace=L.ptr(ws),
-                        workspace_bytes=ws.numel())
+                        workspace_bytes=ws.numel(), mode=mode)
     L.check(lib.bd_conv3x3_wgrad(C.byref(d), L.stream()), "bd_conv3x3_wgrad")
     return dw
 
 
-def gemm(a, b, trans_a=False, trans_b=True, bias=None, alpha=1.0, tile=0, ksplit=0):
+def gemm(a, b, trans_a=False, trans_b=True, bias=None, alpha=1.0, tile=0, ksplit=0, mode=0):
     """C = alpha * op(a) @ op(b)^T-style product on the igemm engine.
     a: [M,K] (trans_a False) or [K,M] (trans_a True); b: [N,K] (trans_b True, 'weights') or [K,N] (False).
     Batched when a/b are 3-D (same leading batch)."""
@@ -269,7 +269,7 @@ def gemm(a, b, trans_a=False, trans_b=True, bias=None, alpha=1.0, tile=0, ksplit
     d.batch_outer, d.batch_inner = nb, 1
     d.C = L.ptr(c); d.ldc = N; d.c_bs_outer = M * N
     d.alpha = alpha; d.out_scale = 1.0; d.bias = L.ptr(bias)
-    d.tile = tile; d.ksplit = ksplit
+    d.tile = tile; d.ksplit = ksplit; d.mode = mode
     need = lib.bd_igemm_workspace_bytes(C.byref(d))
     ws = workspace(need, a.device)
     d.workspace = L.ptr(ws); d.workspace_bytes = ws.numel()

@@ -40,6 +40,8 @@ class UNet2DOutput:
         self.sample = sample
 
 
+COMPUTE_MODES = {"f32": 0, "bf16x3": 1}   # include/bd_hip.h: bd_compute_mode
+
 _SUPPORTED_DOWN = ("DownBlock2D", "AttnDownBlock2D")
 _SUPPORTED_UP = ("UpBlock2D", "AttnUpBlock2D")
 
@@ -75,7 +77,7 @@ class UNet2DModel(nn.Module):
                  block_out_channels=(224, 448, 672, 896), layers_per_block=2, mid_block_scale_factor=1,
                  downsample_padding=1, act_fn="silu", attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5,
                  resnet_time_scale_shift="default", add_attention=True, class_embed_type=None, num_class_embeds=None,
-                 max_chunk=512, **unused):
+                 max_chunk=512, compute_mode="f32", **unused):
         super().__init__()
         # ---- loud failures for what the reference class supports but BadDiffusion never uses -------------
         if len(down_block_types) != len(up_block_types):
@@ -135,6 +137,8 @@ class UNet2DModel(nn.Module):
         c.norm_num_groups = int(norm_num_groups)
         c.attention_head_dim = int(attention_head_dim or 0)
         c.mid_block_scale_factor = float(mid_block_scale_factor)
+        c.compute_mode = COMPUTE_MODES[compute_mode]
+        self.compute_mode = compute_mode
         h = C.c_void_p()
         L.check(lib.bd_unet_create(C.byref(c), C.byref(h)), "bd_unet_create")
         self._plan = h
@@ -160,6 +164,12 @@ class UNet2DModel(nn.Module):
                 self._plan = None
         except Exception:
             pass
+
+    def set_compute_mode(self, mode):
+        """'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16, ~2^-16 relative per product, 3 MFMAs on the bf16 pipe)."""
+        L.check(self._lib.bd_unet_set_compute_mode(self._plan, COMPUTE_MODES[mode]), "bd_unet_set_compute_mode")
+        self.compute_mode = mode
+        return self
 
     def _logical_view(self, flat, key):
         off, shape, layout = self._table[key]
@@ -354,3 +364,4 @@ def unet_from_config(cfg, **kw):
                        downsample_padding=cfg.downsample_padding, flip_sin_to_cos=cfg.flip_sin_to_cos,
                        freq_shift=cfg.freq_shift, norm_eps=cfg.norm_eps, norm_num_groups=cfg.norm_num_groups,
                        attention_head_dim=cfg.attention_head_dim, mid_block_scale_factor=cfg.mid_block_scale_factor, **kw)
+

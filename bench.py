@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 
 TRAIN_GFLOP_PER_IMG = 37.324          # SURVEY 8d (fwd+bwd, 2*MAC of conv/GEMM/BMM), CIFAR-32 UNet
 FP32_MFMA_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+BF16_MFMA_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA (split-bf16 mode issues 3 MFMA flops per algorithmic flop)
 HBM_PEAK_GBS = 8000.0
 
 
@@ -114,6 +115,8 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--mode", default=os.environ.get("BD_COMPUTE_MODE", "f32"), choices=["f32", "bf16x3"],
+                    help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (hi+lo, 3 MFMAs, ~2^-16 rel. error)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
@@ -142,7 +145,7 @@ def main():
                         down_block_types=("DownBlock2D", "AttnDownBlock2D", "DownBlock2D", "DownBlock2D"),
                         up_block_types=("UpBlock2D", "UpBlock2D", "AttnUpBlock2D", "UpBlock2D"), layers_per_block=2,
                         downsample_padding=0, flip_sin_to_cos=False, freq_shift=1, norm_eps=1e-6,
-                        attention_head_dim=None).to(dev)
+                        attention_head_dim=None, compute_mode=args.mode).to(dev)
     sched = DDPMScheduler(num_train_timesteps=1000)
     B = args.batch
     eng = TrainEngine(model, sched, lr=2e-4, lr_warmup_steps=500, num_training_steps=469 * 50)
@@ -202,7 +205,7 @@ def main():
         value = world * B * args.steps / dt
         out = {"metric": "train images/sec (32x32 UNet, DDPM-CIFAR10-32 topology, bs128/GPU, poison_rate 0.1)",
                "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.mode == "f32" else "f32 (split-bf16 hi+lo products, fp32 accumulate)",
                "data": "synthetic (uint8 32x32x3 images resident in HBM, seeded default-init weights)",
                "config": {"workload": "BASELINE configs[1]: CIFAR10 DDPM-CIFAR10-32 train step, batch 128/GPU, poison_rate 0.1, "
                                       "BOX_14 trigger, CORNER target (HAT stand-in), clip 1.0 + Adam, fp32",
@@ -220,8 +223,10 @@ def main():
             if classes:
                 d = classes[0]
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-                out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": FP32_MFMA_PEAK_TFLOPS,
-                                   "unit": "TFLOP/s", "frac": ach / FP32_MFMA_PEAK_TFLOPS, "traffic": None,
+                peak = FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS
+                out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": peak,
+                                   "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                                   "mfma_flops_per_algorithmic_flop": 1 if args.mode == "f32" else 3,
                                    "launches_per_step": d["launches"] / args.steps,
                                    "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                                    "gflop_per_launch": d["flops"] / d["launches"] / 1e9,

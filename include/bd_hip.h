@@ -154,6 +154,13 @@ int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream);
  * Operand kinds select how (row, k) maps to memory; see DESIGN.md "igemm".
  * Replaces aten::convolution / convolution_backward / addmm / mm / bmm / baddbmm of SURVEY 2.3.
  * ------------------------------------------------------------------------------------------------ */
+/* arithmetic of the contraction:
+ *   BD_MODE_F32     v_mfma_f32_32x32x2_f32, exact fp32 products and accumulation (157 TFLOP/s roof)
+ *   BD_MODE_BF16X3  every fp32 operand is split on the fly into hi + lo bf16 (x = hi + lo + O(2^-17 x)) and the
+ *                   product is hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 with fp32 accumulation:
+ *                   ~2^-16 relative error per product, 3 MFMAs on the 2.5 PFLOP/s pipe                      */
+enum bd_compute_mode { BD_MODE_F32 = 0, BD_MODE_BF16X3 = 1 };
+
 enum bd_operand_kind {
     BD_OPK_DENSE = 0, /* KC: p[row*ld + k]            RC: p[k*ld + row]                          */
     BD_OPK_CONV = 1,  /* 3x3 gather of an NHWC tensor: KC rows = output pixels, k = tap*C + c;
@@ -181,6 +188,7 @@ typedef struct {
     int ksplit;                              /* 0 = choose; >1 needs workspace                  */
     void* workspace; size_t workspace_bytes;
     int tile;                                /* 0 = choose, 128 or 64                           */
+    int mode;                                /* bd_compute_mode                                 */
 } bd_igemm_desc;
 size_t bd_igemm_workspace_bytes(const bd_igemm_desc* d);
 int bd_igemm(const bd_igemm_desc* d, bd_stream_t stream);
@@ -201,6 +209,7 @@ typedef struct {
     float out_scale;
     float* y; int64_t ldy;
     void* workspace; size_t workspace_bytes;
+    int mode;                                   /* bd_compute_mode */
 } bd_conv3x3_fwd_desc;
 int bd_conv3x3_fwd(const bd_conv3x3_fwd_desc* d, bd_stream_t stream);
 
@@ -210,6 +219,7 @@ typedef struct {
     const float* w;
     float* dx; int64_t lddx; int accumulate;   /* dx over the (virtual, upsampled) input grid   */
     void* workspace; size_t workspace_bytes;
+    int mode;                                   /* bd_compute_mode */
 } bd_conv3x3_dgrad_desc;
 int bd_conv3x3_dgrad(const bd_conv3x3_dgrad_desc* d, bd_stream_t stream);
 
@@ -219,6 +229,7 @@ typedef struct {
     const float* dy; int64_t lddy;
     float* dw;
     void* workspace; size_t workspace_bytes;
+    int mode;                                   /* bd_compute_mode */
 } bd_conv3x3_wgrad_desc;
 int bd_conv3x3_wgrad(const bd_conv3x3_wgrad_desc* d, bd_stream_t stream);
 size_t bd_conv3x3_workspace_bytes(int B, int Ho, int Wo, int Hs, int Ws, int Cin, int Cout, int ups);
@@ -273,11 +284,13 @@ typedef struct {
     float norm_eps; int norm_num_groups;
     int attention_head_dim;         /* 0 => single head                                         */
     float mid_block_scale_factor;
+    int compute_mode;               /* bd_compute_mode of every conv / GEMM of the network      */
 } bd_unet_config;
 
 typedef struct bd_unet bd_unet;     /* host-only plan object (no device memory)                  */
 int bd_unet_create(const bd_unet_config* cfg, bd_unet** out);
 void bd_unet_destroy(bd_unet* u);
+int bd_unet_set_compute_mode(bd_unet* u, int mode);   /* bd_compute_mode; may be changed between calls */
 int64_t bd_unet_num_params(const bd_unet* u);
 int bd_unet_num_tensors(const bd_unet* u);
 /* i-th parameter tensor: state_dict key, offset (elements) in the flat buffer, logical shape

@@ -296,3 +296,41 @@ def test_adam_clip_vs_torch(ops):
         ops.adam_clip(pd, gd, m, v, ss, step, 2e-4, grad_norm_out=gn)
         close(gn, norm_ref, 1e-5, 0)
         close(pd, pr.detach(), 1e-6, 1e-7)
+
+
+# ------------------------------------------------------------------------------------------ split-bf16 mode
+@pytest.mark.parametrize("M,N,K,ta,tb", [(256, 256, 1152, False, True), (384, 128, 256, False, False), (1152, 128, 4096, True, False),
+                                         (130, 131, 36, False, True)])
+def test_gemm_bf16x3(ops, M, N, K, ta, tb):
+    """hi/lo bf16 split, 3 MFMAs: error ~2^-16 relative per product, far inside the 1e-3 parity budget"""
+    a = R(1, K, M) if ta else R(1, M, K)
+    b = R(2, N, K) if tb else R(2, K, N)
+    ref = (a.t() if ta else a).double() @ (b.t() if tb else b).double()
+    c = ops.gemm(dev(a), dev(b), ta, tb, mode=1).cpu().double()
+    scale = float(ref.abs().mean())
+    err = float((c - ref).abs().max()) / scale
+    assert err < 2e-4, err
+    c32 = ops.gemm(dev(a), dev(b), ta, tb, mode=0).cpu().double()
+    assert float((c32 - ref).abs().max()) / scale < 2e-5
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,stride,pad,ups,asym", [c for c in CONV_CASES if c[2] % 32 == 0 or c[2] == 3][:8])
+def test_conv3x3_bf16x3(ops, B, H, Cin, Cout, stride, pad, ups, asym):
+    x = R(1, B, Cin, H, H); w = R(2, Cout, Cin, 3, 3) / (3 * Cin ** 0.5); bias = R(3, Cout)
+    xr = x.clone().requires_grad_(True); wr = w.clone().requires_grad_(True)
+    xi = F.interpolate(xr, scale_factor=2.0, mode="nearest") if ups else xr
+    if asym:
+        xi = F.pad(xi, (0, 1, 0, 1))
+    y_ref = F.conv2d(xi, wr, bias, stride=stride, padding=0 if asym else pad)
+    dy = R(4, *y_ref.shape)
+    y_ref.backward(dy)
+    xn = dev(x.permute(0, 2, 3, 1).contiguous()); wn = dev(w.permute(0, 2, 3, 1).contiguous())
+    dyn = dev(dy.permute(0, 2, 3, 1).contiguous())
+    y = ops.conv3x3_fwd(xn, wn, dev(bias), stride, pad, ups, asym, mode=1)
+    close(y.permute(0, 3, 1, 2), y_ref, 3e-4, 3e-4)
+    dx = ops.conv3x3_dgrad(dyn, wn, (B, H, H, Cin), stride, pad, ups, asym, mode=1)
+    if ups:
+        dx = ops.sum2x2(dx)
+    close(dx.permute(0, 3, 1, 2), xr.grad, 3e-4, 3e-4)
+    dw = ops.conv3x3_wgrad(xn, dyn, stride, pad, ups, asym, mode=1)
+    close(dw.permute(0, 3, 1, 2), wr.grad, 3e-4, 3e-4 * max(1.0, float(wr.grad.abs().max())))
