@@ -24,6 +24,7 @@ namespace bd {
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
 // split 8 fp32 values into hi + lo bf16 planes: hi = the upper 16 bits of x (truncation, exact), lo = RNE(x - hi);
 // x = hi + lo + O(2^-17 |x|).  ~2.6 VALU per element (v_and / v_perm / v_sub / v_cvt_pk_bf16_f32).
@@ -98,17 +99,86 @@ struct KCStore {
 #pragma unroll
         for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * i) * LDK + k4) = v[i];
     }
+    __device__ __forceinline__ static void store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]);
 };
-template <int R>
-struct RCStore {
+// RC thread map: every thread owns the float4 of rows r4..r4+3 at NI values of k, k_i = kfirst + KSTEP*i.
+//   TR = false (fp32 LDS image [k][rows]):  r4 = (t % (R/4))*4, kfirst = t / (R/4), KSTEP = 1024/R
+//   TR = true  (bf16 LDS image [rows][k], split-bf16 mode): the NI k values are ADJACENT so that a thread can
+//              transpose its 4 x NI block in registers and write NI bf16 of one row with a single ds_write:
+//              kfirst = 4*(t%8) (+2*(t/128) for R = 64), r4 = ((t/8) % (R/4))*4, KSTEP = 1.  A wave instruction
+//              still touches 8 k-rows x 128 contiguous bytes (8 full cache lines).
+template <int R, bool TR>
+struct RCMap {
     static constexpr int NI = R / 32;
-    static constexpr int KS = 1024 / R;
-    __device__ __forceinline__ static void store(float* s, int tid, const float4 (&v)[NI]) {
-        const int r4 = (tid % (R / 4)) * 4, k0 = tid / (R / 4);
-#pragma unroll
-        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + (k0 + KS * i) * (R + 4) + r4) = v[i];
+    static constexpr int KSTEP = TR ? 1 : 1024 / R;
+    __device__ __forceinline__ static int r4(int t) { return TR ? ((t >> 3) % (R / 4)) * 4 : (t % (R / 4)) * 4; }
+    __device__ __forceinline__ static int kfirst(int t) {
+        return TR ? 4 * (t & 7) + (R == 64 ? 2 * (t >> 7) : 0) : t / (R / 4);
     }
 };
+
+constexpr int LDH = BK + 8;  // bf16 row stride of the split-bf16 LDS planes: 80 B (conflict-free b128 reads, b64 writes)
+
+__device__ __forceinline__ unsigned pack_hi(float a, float b) {   // upper halves = truncated bf16
+    return (__builtin_bit_cast(unsigned, a) >> 16) | (__builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
+}
+__device__ __forceinline__ unsigned pack_lo(float a, float b) {   // RNE(x - trunc_bf16(x))
+    const float ra = a - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFF0000u);
+    const float rb = b - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
+    bf16x2 t;
+    t[0] = (__bf16)ra; t[1] = (__bf16)rb;
+    return __builtin_bit_cast(unsigned, t);
+}
+
+template <int R, bool TR>
+struct RCStore {
+    static constexpr int NI = R / 32;
+    __device__ __forceinline__ static void store(float* s, int tid, const float4 (&v)[NI]) {
+        const int r4 = RCMap<R, TR>::r4(tid), k0 = RCMap<R, TR>::kfirst(tid);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + (k0 + RCMap<R, TR>::KSTEP * i) * (R + 4) + r4) = v[i];
+    }
+    // split-bf16 planes, row-contiguous image [k][R + 32] bf16 (the global loads stay fully coalesced); the MFMA
+    // fragments are gathered from it with ds_read_b64_tr_b16 (hardware 4x4 transpose), see rc_frag()
+    __device__ __forceinline__ static void store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]) {
+        const int r4 = RCMap<R, TR>::r4(tid), k0 = RCMap<R, TR>::kfirst(tid);
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int o = (k0 + RCMap<R, TR>::KSTEP * i) * (R + 32) + r4;
+            *reinterpret_cast<uint2*>(sh + o) = make_uint2(pack_hi(v[i].x, v[i].y), pack_hi(v[i].z, v[i].w));
+            *reinterpret_cast<uint2*>(sl + o) = make_uint2(pack_lo(v[i].x, v[i].y), pack_lo(v[i].z, v[i].w));
+        }
+    }
+};
+
+typedef short short4v __attribute__((ext_vector_type(4)));
+typedef short short8v __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) short4v lds_short4;
+
+// MFMA 32x32x16 bf16 fragment (lane: row = lane&31 of the 32-row tile at `rowtile`, k = kk + 8*(lane>>5) + 0..7) from a
+// row-contiguous plane [k][LD].  ds_read_b64_tr_b16 semantics on gfx950 (measured, scripts/tr_probe.hip): inside each
+// 16-lane group, lane l receives element (l&3) of the 64-bit words read by lanes (l>>2) + 4j, j = 0..3.  So lane sl
+// of a group reads the 4 rows [rb + 4*(sl&3), +4) at k = k0 + (sl>>2) and receives row rb + sl at k0..k0+3.
+template <int LD>
+__device__ __forceinline__ bf16x8 rc_frag(const unsigned short* plane, int rowtile, int kk, int lane) {
+    const int sl = lane & 15;
+    const int o = (kk + 8 * (lane >> 5) + (sl >> 2)) * LD + rowtile + 16 * ((lane >> 4) & 1) + 4 * (sl & 3);
+    const short4v v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(plane + o));
+    const short4v v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_short4*)(plane + o + 4 * LD));
+    const short8v v = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int R>
+__device__ __forceinline__ void KCStore<R>::store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]) {
+    const int k4 = (tid & 7) * 4;
+#pragma unroll
+    for (int i = 0; i < NI; ++i) {
+        const int o = ((tid >> 3) + 32 * i) * LDH + k4;
+        *reinterpret_cast<uint2*>(sh + o) = make_uint2(pack_hi(v[i].x, v[i].y), pack_hi(v[i].z, v[i].w));
+        *reinterpret_cast<uint2*>(sl + o) = make_uint2(pack_lo(v[i].x, v[i].y), pack_lo(v[i].z, v[i].w));
+    }
+}
 
 template <int R>
 struct DenseKC : KCStore<R> {
@@ -255,17 +325,17 @@ struct TConvKC : KCStore<R> {
     }
 };
 
-template <int R>
-struct DenseRC : RCStore<R> {
+template <int R, bool TR>
+struct DenseRC : RCStore<R, TR> {
     static constexpr int NI = R / 32;
-    static constexpr int KS = 1024 / R;
+    static constexpr int KS = RCMap<R, TR>::KSTEP;
     static constexpr bool kKC = false;
     const float* ptr;  // p + row + (kbase + k0)*ld
     long long step;    // KS * ld
     int krem;          // K - (kbase + k0)
     bool ok;
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int K) {
-        const int r4 = (tid % (R / 4)) * 4, k0 = tid / (R / 4);
+        const int r4 = RCMap<R, TR>::r4(tid), k0 = RCMap<R, TR>::kfirst(tid);
         ok = row0 + r4 < o.rows;
         ptr = o.p + (row0 + r4) + (long long)(kbase + k0) * o.ld;
         step = (long long)KS * o.ld;
@@ -282,17 +352,17 @@ struct DenseRC : RCStore<R> {
 };
 
 // weights seen from dgrad: rows = ci, k = tap*C + co (C = Cout, C % 32 == 0): W[(co*9 + tap)*ld + ci]
-template <int R>
-struct WgtRC : RCStore<R> {
+template <int R, bool TR>
+struct WgtRC : RCStore<R, TR> {
     static constexpr int NI = R / 32;
-    static constexpr int KS = 1024 / R;
+    static constexpr int KS = RCMap<R, TR>::KSTEP;
     static constexpr bool kKC = false;
     const float* ptr;  // p + row + k0*9*ld
     long long step;    // KS*9*ld
     int tap, c0;
     bool ok;
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
-        const int r4 = (tid % (R / 4)) * 4, k0 = tid / (R / 4);
+        const int r4 = RCMap<R, TR>::r4(tid), k0 = RCMap<R, TR>::kfirst(tid);
         ok = row0 + r4 < o.rows;
         const int chunk = kbase / BK;      // same K order as TConvKC: channel block outer, tap inner
         tap = chunk % 9;
@@ -311,15 +381,15 @@ struct WgtRC : RCStore<R> {
 };
 
 // conv gather, weight-gradient direction: rows = tap*C + ci (fixed per thread), k = output pixels
-template <int R>
-struct ConvRC : RCStore<R> {
+template <int R, bool TR>
+struct ConvRC : RCStore<R, TR> {
     static constexpr int NI = R / 32;
-    static constexpr int KS = 1024 / R;
+    static constexpr int KS = RCMap<R, TR>::KSTEP;
     static constexpr bool kKC = false;
     int kh, kw, ci, pix, Kp;
     bool ok;
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int K) {
-        const int r4 = (tid % (R / 4)) * 4, k0 = tid / (R / 4);
+        const int r4 = RCMap<R, TR>::r4(tid), k0 = RCMap<R, TR>::kfirst(tid);
         const int r = row0 + r4;
         const int tap = r / o.C;
         ci = r - tap * o.C;
@@ -420,17 +490,17 @@ struct GenericKC : KCStore<R> {
     __device__ __forceinline__ void advance(const Opnd&) { kbase += BK; }
 };
 
-template <int R>
-struct GenericRC : RCStore<R> {
+template <int R, bool TR>
+struct GenericRC : RCStore<R, TR> {
     static constexpr int NI = R / 32;
-    static constexpr int KS = 1024 / R;
+    static constexpr int KS = RCMap<R, TR>::KSTEP;
     static constexpr bool kKC = false;
     int k0, row, kbase, K;
     int kh[4], kw[4], ci[4];
     bool rok[4];
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kb, int K_) {
-        const int r4 = (tid % (R / 4)) * 4;
-        k0 = tid / (R / 4);
+        const int r4 = RCMap<R, TR>::r4(tid);
+        k0 = RCMap<R, TR>::kfirst(tid);
         row = row0 + r4; kbase = kb; K = K_;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -489,7 +559,38 @@ constexpr int lds_floats() {
 }
 
 // ------------------------------------------------------------------------------------------------
-template <int BM, int BN, class LA, class LB, int MODE>
+// ---- epilogue: lane holds column (n) li of rows (r&3) + 8*(r>>2) + 4*h of every 32x32 tile ---------------------
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const IGemmParams& p, floatx16 (&acc)[TM][TN], int mw, int nw, int li, int h, int bo, int bi) {
+    const long long coff = bo * p.c_bso + bi * p.c_bsi;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < TN; ++q) {
+            const int n = nw + q * 32 + li;
+            if (n >= p.N) continue;
+            const float bn = (p.ksplit == 1 && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m >= p.M) continue;
+                float v = acc[i][q][r];
+                if (p.ksplit > 1) {
+                    p.partial[((long long)blockIdx.z * p.M + m) * p.N + n] = v;
+                } else {
+                    v = v * p.alpha + bn;
+                    if (p.rowbias) v += p.rowbias[(long long)(m / p.rows_per_group) * p.ld_rowbias + n];
+                    if (p.residual) v += p.residual[coff + (long long)m * p.ldr + n];
+                    v *= p.out_scale;
+                    float* dst = p.C + coff + (long long)m * p.ldc + n;
+                    if (p.accumulate) v += *dst;
+                    *dst = v;
+                }
+            }
+        }
+}
+
+template <int BM, int BN, class LA, class LB>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     constexpr bool A_KC = LA::kKC, B_KC = LB::kKC;
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
@@ -549,54 +650,6 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
             la.load(A, ra);
             lb.load(B, rb);
         }
-        if (MODE == BD_MODE_BF16X3) {
-            // split-bf16: per 16-wide k step every lane reads 8 fp32 per fragment (k = 16s + 8h + j), splits them
-            // into hi/lo bf16 and issues hi*hi + hi*lo + lo*hi on the bf16 MFMA (fp32 accumulate)
-#pragma unroll
-            for (int s = 0; s < BK / 16; ++s) {
-                bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-                for (int i = 0; i < TM; ++i) {
-                    const int r = wm * WM + i * 32 + li;
-                    float x[8];
-                    if (A_KC) {
-                        const float4 v0 = *reinterpret_cast<const float4*>(sA + r * LDK + s * 16 + 8 * h);
-                        const float4 v1 = *reinterpret_cast<const float4*>(sA + r * LDK + s * 16 + 8 * h + 4);
-                        x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) x[j] = sA[(s * 16 + 8 * h + j) * (BM + 4) + r];
-                    }
-                    split8(x, ah[i], al[i]);
-                }
-#pragma unroll
-                for (int i = 0; i < TN; ++i) {
-                    const int r = wn * WN + i * 32 + li;
-                    float x[8];
-                    if (B_KC) {
-                        const float4 v0 = *reinterpret_cast<const float4*>(sB + r * LDK + s * 16 + 8 * h);
-                        const float4 v1 = *reinterpret_cast<const float4*>(sB + r * LDK + s * 16 + 8 * h + 4);
-                        x[0] = v0.x; x[1] = v0.y; x[2] = v0.z; x[3] = v0.w; x[4] = v1.x; x[5] = v1.y; x[6] = v1.z; x[7] = v1.w;
-                    } else {
-#pragma unroll
-                        for (int j = 0; j < 8; ++j) x[j] = sB[(s * 16 + 8 * h + j) * (BN + 4) + r];
-                    }
-                    split8(x, bh[i], bl[i]);
-                }
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int q = 0; q < TN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[q], acc[i][q], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int q = 0; q < TN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[q], acc[i][q], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int q = 0; q < TN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
-            }
-        } else {
 #pragma unroll
         for (int g = 0; g < BK / 8; ++g) {
             float fa[TM][4], fb[TN][4];
@@ -630,37 +683,117 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
                     for (int q = 0; q < TN; ++q)
                         acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][j], fb[q][j], acc[i][q], 0, 0, 0);
         }
-        }
         __syncthreads();
     }
 
-    // ---- epilogue: lane holds column (n) li of rows (r&3) + 8*(r>>2) + 4*h -----------------------
-    const long long coff = bo * p.c_bso + bi * p.c_bsi;
+    epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi);
+}
+
+// ------------------------------------------------------------------------------------------------
+// split-bf16 kernel: same tiling / staging, but the register -> LDS store splits every fp32 value ONCE into
+// hi + lo bf16 planes ([rows][32 + 8] bf16 each, RC operands transposed in registers on the way), and the
+// K loop issues hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) from ds_read_b128 fragments.
+template <int BM, int BN, class LA, class LB>
+__global__ __launch_bounds__(256) void igemm_bf16x3_kernel(IGemmParams p) {
+    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+    constexpr bool A_KC = LA::kKC, B_KC = LB::kKC;
+    constexpr int A_SZ = A_KC ? BM * LDH : BK * (BM + 32), B_SZ = B_KC ? BN * LDH : BK * (BN + 32);
+    __shared__ __attribute__((aligned(16))) unsigned short sAh[A_SZ];
+    __shared__ __attribute__((aligned(16))) unsigned short sAl[A_SZ];
+    __shared__ __attribute__((aligned(16))) unsigned short sBh[B_SZ];
+    __shared__ __attribute__((aligned(16))) unsigned short sBl[B_SZ];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+
+    int tile = blockIdx.x;
+    const int ntiles = p.tiles_m * p.tiles_n;
+    if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
+    const int tn_i = tile % p.tiles_n, tm_i = tile / p.tiles_n;
+    const int m0 = tm_i * BM, n0 = tn_i * BN;
+    const int bz = blockIdx.z / p.ksplit, ks = blockIdx.z - bz * p.ksplit;
+    const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
+
+    Opnd A = p.A, B = p.B;
+    A.p += bo * p.a_bso + bi * p.a_bsi;
+    B.p += bo * p.b_bso + bi * p.b_bsi;
+
+    const int nchunks_total = (p.K + BK - 1) / BK;
+    const int c_begin = ks * p.chunks_per_split;
+    int c_end = c_begin + p.chunks_per_split;
+    if (c_end > nchunks_total) c_end = nchunks_total;
+
+    LA la;
+    LB lb;
+    la.init(A, m0, tid, c_begin * BK, p.K);
+    lb.init(B, n0, tid, c_begin * BK, p.K);
+
+    floatx16 acc[TM][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int q = 0; q < TN; ++q) {
-            const int n = n0 + wn * WN + q * 32 + li;
-            if (n >= p.N) continue;
-            const float bn = (p.ksplit == 1 && p.bias) ? p.bias[n] : 0.f;
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = m0 + wm * WM + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                float v = acc[i][q][r];
-                if (p.ksplit > 1) {
-                    p.partial[((long long)blockIdx.z * p.M + m) * p.N + n] = v;
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    float4 ra[BM / 32], rb[BN / 32];
+    if (c_begin < c_end) {
+        la.load(A, ra);
+        lb.load(B, rb);
+    }
+    for (int c = c_begin; c < c_end; ++c) {
+        LA::store_split(sAh, sAl, tid, ra);
+        LB::store_split(sBh, sBl, tid, rb);
+        __syncthreads();
+        if (c + 1 < c_end) {
+            la.advance(A);
+            lb.advance(B);
+            la.load(A, ra);
+            lb.load(B, rb);
+        }
+#pragma unroll
+        for (int s = 0; s < BK / 16; ++s) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                if (A_KC) {
+                    const int o = (wm * WM + i * 32 + li) * LDH + 16 * s + 8 * h;
+                    ah[i] = *reinterpret_cast<const bf16x8*>(sAh + o);
+                    al[i] = *reinterpret_cast<const bf16x8*>(sAl + o);
                 } else {
-                    v = v * p.alpha + bn;
-                    if (p.rowbias) v += p.rowbias[(long long)(m / p.rows_per_group) * p.ld_rowbias + n];
-                    if (p.residual) v += p.residual[coff + (long long)m * p.ldr + n];
-                    v *= p.out_scale;
-                    float* dst = p.C + coff + (long long)m * p.ldc + n;
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
+                    ah[i] = rc_frag<BM + 32>(sAh, wm * WM + i * 32, 16 * s, lane);
+                    al[i] = rc_frag<BM + 32>(sAl, wm * WM + i * 32, 16 * s, lane);
                 }
             }
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                if (B_KC) {
+                    const int o = (wn * WN + i * 32 + li) * LDH + 16 * s + 8 * h;
+                    bh[i] = *reinterpret_cast<const bf16x8*>(sBh + o);
+                    bl[i] = *reinterpret_cast<const bf16x8*>(sBl + o);
+                } else {
+                    bh[i] = rc_frag<BN + 32>(sBh, wn * WN + i * 32, 16 * s, lane);
+                    bl[i] = rc_frag<BN + 32>(sBl, wn * WN + i * 32, 16 * s, lane);
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < TN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < TN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int q = 0; q < TN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
         }
+        __syncthreads();
+    }
+    epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi);
 }
 
 // split-K second pass: fixed-order (deterministic) sum of the partial slabs + epilogue
@@ -784,12 +917,6 @@ size_t igemm_workspace_bytes(const bd_igemm_desc& d) {
     return (size_t)d.batch_outer * d.batch_inner * c.ksplit * (size_t)d.M * d.N * sizeof(float);
 }
 
-template <int T, class LA, class LB>
-static void launch1(const IGemmParams& p, dim3 grid, hipStream_t st, int mode) {
-    if (mode == BD_MODE_BF16X3) hipLaunchKernelGGL((igemm_kernel<T, T, LA, LB, BD_MODE_BF16X3>), grid, dim3(256), 0, st, p);
-    else hipLaunchKernelGGL((igemm_kernel<T, T, LA, LB, BD_MODE_F32>), grid, dim3(256), 0, st, p);
-}
-
 enum Cls { CLS_GENERIC = 0, CLS_CONV_FWD, CLS_CONV_DGRAD, CLS_CONV_WGRAD, CLS_GEMM_NT, CLS_GEMM_NN, CLS_GEMM_TN };
 static const char* kClsName[] = {"generic", "conv_fwd", "conv_dgrad", "conv_wgrad", "gemm_nt", "gemm_nn", "gemm_tn"};
 
@@ -810,23 +937,30 @@ static Cls classify(const bd_igemm_desc& d, bool fast) {
     return CLS_GENERIC;
 }
 
-template <int T>
+// TR = true selects the split-bf16 kernel (RC operands keep the coalesced thread map; transposition happens in the
+// ds_read_b64_tr_b16 fragment reads)
+template <int T, bool TR, class LA, class LB>
+static void launch1(const IGemmParams& p, dim3 grid, hipStream_t st) {
+    if (TR) hipLaunchKernelGGL((igemm_bf16x3_kernel<T, T, LA, LB>), grid, dim3(256), 0, st, p);
+    else hipLaunchKernelGGL((igemm_kernel<T, T, LA, LB>), grid, dim3(256), 0, st, p);
+}
+
+template <int T, bool TR>
 static void launch_tile(const IGemmParams& p, const bd_igemm_desc& d, Cls cls, dim3 grid, hipStream_t st) {
-    const int mode = d.mode;
     switch (cls) {
-        case CLS_CONV_FWD: launch1<T, ConvKC<T>, WgtKC<T>>(p, grid, st, mode); return;
-        case CLS_GEMM_NT: launch1<T, DenseKC<T>, DenseKC<T>>(p, grid, st, mode); return;
-        case CLS_CONV_DGRAD: launch1<T, TConvKC<T>, WgtRC<T>>(p, grid, st, mode); return;
-        case CLS_GEMM_NN: launch1<T, DenseKC<T>, DenseRC<T>>(p, grid, st, mode); return;
-        case CLS_CONV_WGRAD: launch1<T, DenseRC<T>, ConvRC<T>>(p, grid, st, mode); return;
-        case CLS_GEMM_TN: launch1<T, DenseRC<T>, DenseRC<T>>(p, grid, st, mode); return;
+        case CLS_CONV_FWD: launch1<T, TR, ConvKC<T>, WgtKC<T>>(p, grid, st); return;
+        case CLS_GEMM_NT: launch1<T, TR, DenseKC<T>, DenseKC<T>>(p, grid, st); return;
+        case CLS_CONV_DGRAD: launch1<T, TR, TConvKC<T>, WgtRC<T, false>>(p, grid, st); return;
+        case CLS_GEMM_NN: launch1<T, TR, DenseKC<T>, DenseRC<T, false>>(p, grid, st); return;
+        case CLS_CONV_WGRAD: launch1<T, TR, DenseRC<T, false>, ConvRC<T, false>>(p, grid, st); return;
+        case CLS_GEMM_TN: launch1<T, TR, DenseRC<T, false>, DenseRC<T, false>>(p, grid, st); return;
         default: break;
     }
     const bool akc = d.A.kc != 0, bkc = d.B.kc != 0;
-    if (akc && bkc) launch1<T, GenericKC<T>, GenericKC<T>>(p, grid, st, mode);
-    else if (akc && !bkc) launch1<T, GenericKC<T>, GenericRC<T>>(p, grid, st, mode);
-    else if (!akc && !bkc) launch1<T, GenericRC<T>, GenericRC<T>>(p, grid, st, mode);
-    else launch1<T, GenericRC<T>, GenericKC<T>>(p, grid, st, mode);
+    if (akc && bkc) launch1<T, TR, GenericKC<T>, GenericKC<T>>(p, grid, st);
+    else if (akc && !bkc) launch1<T, TR, GenericKC<T>, GenericRC<T, false>>(p, grid, st);
+    else if (!akc && !bkc) launch1<T, TR, GenericRC<T, false>, GenericRC<T, false>>(p, grid, st);
+    else launch1<T, TR, GenericRC<T, false>, GenericKC<T>>(p, grid, st);
 }
 
 int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
@@ -878,8 +1012,13 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
         rec = prof_begin(name, 2.0 * d.M * d.N * (double)d.K * nb,
                          (op_bytes(d.A, d.M) + op_bytes(d.B, d.N) + (double)d.M * d.N * 4.0) * nb, stream);
     }
-    if (c.tile == 128) launch_tile<128>(p, d, cls, grid, stream);
-    else launch_tile<64>(p, d, cls, grid, stream);
+    if (d.mode == BD_MODE_BF16X3) {
+        if (c.tile == 128) launch_tile<128, true>(p, d, cls, grid, stream);
+        else launch_tile<64, true>(p, d, cls, grid, stream);
+    } else {
+        if (c.tile == 128) launch_tile<128, false>(p, d, cls, grid, stream);
+        else launch_tile<64, false>(p, d, cls, grid, stream);
+    }
     BD_LAUNCH_CHECK("igemm");
     if (c.ksplit > 1) {
         long long total = (long long)d.M * d.N * nb;
