@@ -74,47 +74,49 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, long long ldx, int 
     }
 }
 
-__global__ void gn_finalize_kernel(const double* __restrict__ part, int B, int S, int G, double n, float eps,
-                                   float* __restrict__ mean, float* __restrict__ rstd) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i >= B * G) return;
-    const int b = i / G, g = i - b * G;
-    double a = 0.0, c2 = 0.0;
-    for (int s = 0; s < S; ++s) {
-        const double* p = part + (((long long)b * S + s) * G + g) * 2;
-        a += p[0];
-        c2 += p[1];
-    }
-    const double mu = a / n;
-    double var = c2 / n - mu * mu;
-    if (var < 0.0) var = 0.0;
-    mean[i] = (float)mu;
-    rstd[i] = (float)(1.0 / sqrt(var + (double)eps));
-}
-
-// ---- forward apply: y = silu?((x - mean) * rstd * gamma + beta) ------------------------------------
+// ---- forward apply: y = silu?((x - mean) * rstd * gamma + beta); grid = (blocks per sample, B).
+// Prologue: the first G threads finalize this sample's (mean, rstd) from the S fixed-order partials (fp64);
+// block 0 of the sample also stores them for backward.
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
-                                                     long long ldy, long long total4, int HW, int C, int G,
-                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
-                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                     int silu) {
+                                                     long long ldy, int HW, int C, int G, int S, double n, float eps,
+                                                     const double* __restrict__ part, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, float* __restrict__ mean,
+                                                     float* __restrict__ rstd, int silu) {
+    extern __shared__ float st[];  // [G][2]
+    const int b = blockIdx.y;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        double a = 0.0, c2 = 0.0;
+        for (int sp = 0; sp < S; ++sp) {
+            const double* p = part + (((long long)b * S + sp) * G + g) * 2;
+            a += p[0];
+            c2 += p[1];
+        }
+        const double mu = a / n;
+        double var = c2 / n - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float m = (float)mu, r = (float)(1.0 / sqrt(var + (double)eps));
+        st[2 * g] = m; st[2 * g + 1] = r;
+        if (blockIdx.x == 0) { mean[b * G + g] = m; rstd[b * G + g] = r; }
+    }
+    __syncthreads();
     const int q = C / 4, cpg = C / G;
+    const long long total4 = (long long)HW * q;
+    const float* xb = x + (long long)b * HW * ldx;
+    float* yb = y + (long long)b * HW * ldy;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % q) * 4;
         const long long pix = i / q;
-        const int b = (int)(pix / HW);
-        const float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + c);
+        const float4 v = *reinterpret_cast<const float4*>(xb + pix * ldx + c);
         const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
         const float4 be = *reinterpret_cast<const float4*>(beta + c);
         float in[4] = {v.x, v.y, v.z, v.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w}, o[4];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int g = (c + j) / cpg;
-            const float mu = mean[b * G + g], rs = rstd[b * G + g];
-            float z = (in[j] - mu) * rs * gg[j] + bb[j];
+            float z = (in[j] - st[2 * g]) * st[2 * g + 1] * gg[j] + bb[j];
             o[j] = silu ? silu_dev(z) : z;
         }
-        *reinterpret_cast<float4*>(y + pix * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+        *reinterpret_cast<float4*>(yb + pix * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
     }
 }
 
@@ -178,54 +180,56 @@ __global__ void gn_bwd_stats_kernel(const float* __restrict__ x, long long ldx, 
 
 // ---- backward finalize -----------------------------------------------------------------------------
 // (a) dgamma/dbeta[c] = sum over the B*S partial rows: 64 columns x 4 row phases per block, fixed order
-__global__ __launch_bounds__(256) void gn_bwd_param_kernel(const float* __restrict__ part, int rows, int C,
-                                                         float* __restrict__ dgamma, float* __restrict__ dbeta) {
-    __shared__ double red[4][64];
-    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+__global__ __launch_bounds__(1024) void gn_bwd_param_kernel(const float* __restrict__ part, int rows, int C,
+                                                          float* __restrict__ dgamma, float* __restrict__ dbeta) {
+    __shared__ double red[16][64];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 columns x 16 row phases
     const int n = blockIdx.x * 64 + tx;   // column in [0, 2C): plane 0 = dgamma, plane 1 = dbeta
     double s = 0.0;
     if (n < 2 * C)
-        for (int r = ty; r < rows; r += 4) s += (double)part[(long long)r * 2 * C + n];
+        for (int r = ty; r < rows; r += 16) s += (double)part[(long long)r * 2 * C + n];
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && n < 2 * C) {
-        const float v = (float)((red[0][tx] + red[1][tx]) + (red[2][tx] + red[3][tx]));
+        double t = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t += red[k][tx];
+        const float v = (float)t;
         if (n < C) dgamma[n] = v; else dbeta[n - C] = v;
     }
 }
-// (b) per (b, g): s1 = sum gamma*dz, s2 = sum gamma*dz*xhat
-__global__ __launch_bounds__(256) void gn_bwd_group_kernel(const float* __restrict__ part, int B, int S, int C, int G,
-                                                         const float* __restrict__ gamma, float* __restrict__ ds) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= B * G) return;
-    const int b = i / G, g = i - b * G;
-    const int cpg = C / G;
-    double a = 0.0, e = 0.0;
-    for (int s = 0; s < S; ++s)
-        for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-            const float* p = part + ((long long)b * S + s) * 2 * C + c;
-            e += (double)p[0] * gamma[c];
-            a += (double)p[C] * gamma[c];
-        }
-    ds[i * 2 + 0] = (float)a;
-    ds[i * 2 + 1] = (float)e;
-}
-
-// ---- backward apply: dx (+)= rstd * (dz*gamma - (s1 + xhat*s2)/n) -----------------------------------
+// ---- backward apply: dx (+)= rstd * (dz*gamma - (s1 + xhat*s2)/n); grid = (blocks per sample, B).
+// Prologue: per group s1 = sum gamma*dz, s2 = sum gamma*dz*xhat from the per-channel partials (fixed order, fp64).
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, long long ldx,
                                                          const float* __restrict__ dy, long long lddy,
-                                                         float* __restrict__ dx, long long lddx, long long total4, int HW,
-                                                         int C, int G, const float* __restrict__ gamma,
+                                                         float* __restrict__ dx, long long lddx, int HW, int C, int G, int S,
+                                                         const float* __restrict__ part, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ mean,
-                                                         const float* __restrict__ rstd, const float* __restrict__ ds,
-                                                         float inv_n, int silu, int acc) {
+                                                         const float* __restrict__ rstd, float inv_n, int silu, int acc) {
+    extern __shared__ float st[];  // [G][4] = mean, rstd, s1, s2
+    const int b = blockIdx.y;
     const int q = C / 4, cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        double a = 0.0, e = 0.0;
+        for (int sp = 0; sp < S; ++sp)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                const float* p = part + ((long long)b * S + sp) * 2 * C + c;
+                e += (double)p[0] * gamma[c];
+                a += (double)p[C] * gamma[c];
+            }
+        st[4 * g] = mean[b * G + g]; st[4 * g + 1] = rstd[b * G + g];
+        st[4 * g + 2] = (float)a; st[4 * g + 3] = (float)e;
+    }
+    __syncthreads();
+    const long long total4 = (long long)HW * q;
+    const float* xb = x + (long long)b * HW * ldx;
+    const float* db = dy + (long long)b * HW * lddy;
+    float* ob = dx + (long long)b * HW * lddx;
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
         const int c = (int)(i % q) * 4;
         const long long pix = i / q;
-        const int b = (int)(pix / HW);
-        const float4 v = *reinterpret_cast<const float4*>(x + pix * ldx + c);
-        const float4 d = *reinterpret_cast<const float4*>(dy + pix * lddy + c);
+        const float4 v = *reinterpret_cast<const float4*>(xb + pix * ldx + c);
+        const float4 d = *reinterpret_cast<const float4*>(db + pix * lddy + c);
         const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
         const float4 be = *reinterpret_cast<const float4*>(beta + c);
         const float in[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w};
@@ -234,14 +238,13 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const int g = (c + j) / cpg;
-            const float mu = mean[b * G + g], rs = rstd[b * G + g];
-            const float s1 = ds[(b * G + g) * 2 + 0], s2 = ds[(b * G + g) * 2 + 1];
+            const float mu = st[4 * g], rs = st[4 * g + 1], s1 = st[4 * g + 2], s2 = st[4 * g + 3];
             const float xh = (in[j] - mu) * rs;
             float dz = dd[j];
             if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
             o[j] = rs * (dz * gg[j] - (s1 + xh * s2) * inv_n);
         }
-        float4* dst = reinterpret_cast<float4*>(dx + pix * lddx + c);
+        float4* dst = reinterpret_cast<float4*>(ob + pix * lddx + c);
         if (acc) {
             const float4 e = *dst;
             o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
@@ -286,14 +289,15 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
     hipLaunchKernelGGL(gn_stats_kernel, dim3(S_, d->B), dim3(threads), (size_t)r * d->C * 2 * sizeof(float), S(stream), d->x,
                        (long long)d->ldx, d->HW, d->C, d->G, r, S_, part);
     BD_LAUNCH_CHECK("gn_stats");
-    hipLaunchKernelGGL(gn_finalize_kernel, dim3((unsigned)cdiv(d->B * d->G, 256)), dim3(256), 0, S(stream), part, d->B, S_,
-                       d->G, (double)d->HW * (d->C / d->G), d->eps, d->mean, d->rstd);
-    BD_LAUNCH_CHECK("gn_finalize");
-    const long long total4 = (long long)d->B * d->HW * (d->C / 4);
-    long long nb = cdiv(total4, 256);
-    if (nb > 16384) nb = 16384;
-    hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nb), dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->y,
-                       (long long)d->ldy, total4, d->HW, d->C, d->G, d->gamma, d->beta, d->mean, d->rstd, d->silu);
+    {
+        const long long per4 = (long long)d->HW * (d->C / 4);
+        long long nbx = cdiv(per4, 256 * 4);           // ~4 float4 per thread
+        if (nbx < 1) nbx = 1;
+        if (nbx > 4096) nbx = 4096;
+        hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nbx, d->B), dim3(256), (size_t)d->G * 2 * sizeof(float), S(stream), d->x,
+                           (long long)d->ldx, d->y, (long long)d->ldy, d->HW, d->C, d->G, S_, (double)d->HW * (d->C / d->G), d->eps,
+                           part, d->gamma, d->beta, d->mean, d->rstd, d->silu);
+    }
     BD_LAUNCH_CHECK("gn_apply");
     return BD_OK;
 }
@@ -317,18 +321,18 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
                        (long long)d->ldx, d->dy, (long long)d->lddy, d->HW, d->C, d->G, r, S_, d->gamma, d->beta, d->mean,
                        d->rstd, d->silu, part);
     BD_LAUNCH_CHECK("gn_bwd_stats");
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(256), 0, S(stream), part, d->B * S_, d->C,
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(1024), 0, S(stream), part, d->B * S_, d->C,
                        d->dgamma, d->dbeta);
     BD_LAUNCH_CHECK("gn_bwd_param");
-    hipLaunchKernelGGL(gn_bwd_group_kernel, dim3((unsigned)cdiv(d->B * d->G, 256)), dim3(256), 0, S(stream), part, d->B, S_, d->C,
-                       d->G, d->gamma, ds);
-    BD_LAUNCH_CHECK("gn_bwd_group");
-    const long long total4 = (long long)d->B * d->HW * (d->C / 4);
-    long long nb = cdiv(total4, 256);
-    if (nb > 16384) nb = 16384;
-    hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)nb), dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->dy,
-                       (long long)d->lddy, d->dx, (long long)d->lddx, total4, d->HW, d->C, d->G, d->gamma, d->beta, d->mean,
-                       d->rstd, ds, 1.0f / ((float)d->HW * (d->C / d->G)), d->silu, d->accumulate_dx);
+    {
+        const long long per4 = (long long)d->HW * (d->C / 4);
+        long long nbx = cdiv(per4, 256 * 4);
+        if (nbx < 1) nbx = 1;
+        if (nbx > 4096) nbx = 4096;
+        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)nbx, d->B), dim3(256), (size_t)d->G * 4 * sizeof(float), S(stream), d->x,
+                           (long long)d->ldx, d->dy, (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, S_, part,
+                           d->gamma, d->beta, d->mean, d->rstd, 1.0f / ((float)d->HW * (d->C / d->G)), d->silu, d->accumulate_dx);
+    }
     BD_LAUNCH_CHECK("gn_bwd_apply");
     return BD_OK;
 }

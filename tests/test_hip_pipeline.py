@@ -142,3 +142,45 @@ def test_dataset_loader_dict_batches(gpu):
     np.testing.assert_allclose(batch["target"].cpu().numpy(), x0r.numpy(), rtol=0, atol=2e-7)
     imgs, p = next(iter(dsl.device_batches(shuffle=False, flip=False)))
     assert imgs.dtype == torch.uint8 and imgs.shape == (16, 32, 32, 3) and torch.equal(p.cpu(), pois)
+
+
+def _dp_worker(rank, world, port, ret):
+    import os, sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)       # both ranks share the one GPU of the test box
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    cfg = C.SMALL_CFGS["small"]
+    x0, R, t, eps = [v.cuda() for v in C.train_inputs(cfg, 4)]
+    m = make_model(cfg, 7, torch.device("cuda"))
+    e = TrainEngine(m, DDPMScheduler(), lr=1e-3)
+    assert e.world == world
+    sl = slice(rank, None, world)
+    e.train_step_batch(x0[sl], R[sl], eps[sl], t[sl])
+    torch.cuda.synchronize()
+    if rank == 0:
+        ret["flat"] = m.flat.detach().cpu()
+        ret["gn"] = float(e.grad_norm)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_train_engine_two_ranks_equal_one_big_batch(gpu):
+    """2 processes x batch 2 (flat-gradient all-reduce per backward segment) == 1 process x batch 4"""
+    import socket
+    import torch.multiprocessing as mp
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_dp_worker, args=(2, port, ret), nprocs=2, join=True)
+    cfg = C.SMALL_CFGS["small"]
+    x0, R, t, eps = [v.cuda() for v in C.train_inputs(cfg, 4)]
+    m = make_model(cfg, 7, gpu); e = TrainEngine(m, DDPMScheduler(), lr=1e-3)
+    e.train_step_batch(x0, R, eps, t)
+    assert abs(float(e.grad_norm) - ret["gn"]) < 1e-4 * float(e.grad_norm)
+    d = (m.flat.detach().cpu() - ret["flat"]).abs()
+    assert float((d > 1e-5).float().mean()) < 1e-3
