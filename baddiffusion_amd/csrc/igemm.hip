@@ -694,14 +694,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 // hi + lo bf16 planes ([rows][32 + 8] bf16 each, RC operands transposed in registers on the way), and the
 // K loop issues hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) from ds_read_b128 fragments.
 template <int BM, int BN, class LA, class LB>
-__global__ __launch_bounds__(256, 2) void igemm_bf16x3_kernel(IGemmParams p) {
+__global__ __launch_bounds__(256, 3) void igemm_bf16x3_kernel(IGemmParams p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr bool A_KC = LA::kKC, B_KC = LB::kKC;
     constexpr int A_SZ = A_KC ? BM * LDH : BK * (BM + 32), B_SZ = B_KC ? BN * LDH : BK * (BN + 32);
-    __shared__ __attribute__((aligned(16))) unsigned short sAh[2 * A_SZ];
-    __shared__ __attribute__((aligned(16))) unsigned short sAl[2 * A_SZ];
-    __shared__ __attribute__((aligned(16))) unsigned short sBh[2 * B_SZ];
-    __shared__ __attribute__((aligned(16))) unsigned short sBl[2 * B_SZ];
+    __shared__ __attribute__((aligned(16))) unsigned short sAh[A_SZ];
+    __shared__ __attribute__((aligned(16))) unsigned short sAl[A_SZ];
+    __shared__ __attribute__((aligned(16))) unsigned short sBh[B_SZ];
+    __shared__ __attribute__((aligned(16))) unsigned short sBl[B_SZ];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -738,11 +738,21 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16x3_kernel(IGemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // Double-buffered LDS, ONE barrier per chunk: while the MFMAs of chunk c run out of buffer c&1, the same wave
-    // splits + stores chunk c+1 (already in registers) into the other buffer and then requests chunk c+2 from memory,
-    // so the VALU/LDS-store phase overlaps the matrix pipe inside a workgroup instead of serialising with it.
     float4 ra[BM / 32], rb[BN / 32];
-    auto compute = [&](const unsigned short* Ah, const unsigned short* Al, const unsigned short* Bh, const unsigned short* Bl) {
+    if (c_begin < c_end) {
+        la.load(A, ra);
+        lb.load(B, rb);
+    }
+    for (int c = c_begin; c < c_end; ++c) {
+        LA::store_split(sAh, sAl, tid, ra);
+        LB::store_split(sBh, sBl, tid, rb);
+        __syncthreads();
+        if (c + 1 < c_end) {
+            la.advance(A);
+            lb.advance(B);
+            la.load(A, ra);
+            lb.load(B, rb);
+        }
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -750,22 +760,22 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16x3_kernel(IGemmParams p) {
             for (int i = 0; i < TM; ++i) {
                 if (A_KC) {
                     const int o = (wm * WM + i * 32 + li) * LDH + 16 * s + 8 * h;
-                    ah[i] = *reinterpret_cast<const bf16x8*>(Ah + o);
-                    al[i] = *reinterpret_cast<const bf16x8*>(Al + o);
+                    ah[i] = *reinterpret_cast<const bf16x8*>(sAh + o);
+                    al[i] = *reinterpret_cast<const bf16x8*>(sAl + o);
                 } else {
-                    ah[i] = rc_frag<BM + 32>(Ah, wm * WM + i * 32, 16 * s, lane);
-                    al[i] = rc_frag<BM + 32>(Al, wm * WM + i * 32, 16 * s, lane);
+                    ah[i] = rc_frag<BM + 32>(sAh, wm * WM + i * 32, 16 * s, lane);
+                    al[i] = rc_frag<BM + 32>(sAl, wm * WM + i * 32, 16 * s, lane);
                 }
             }
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
                 if (B_KC) {
                     const int o = (wn * WN + i * 32 + li) * LDH + 16 * s + 8 * h;
-                    bh[i] = *reinterpret_cast<const bf16x8*>(Bh + o);
-                    bl[i] = *reinterpret_cast<const bf16x8*>(Bl + o);
+                    bh[i] = *reinterpret_cast<const bf16x8*>(sBh + o);
+                    bl[i] = *reinterpret_cast<const bf16x8*>(sBl + o);
                 } else {
-                    bh[i] = rc_frag<BN + 32>(Bh, wn * WN + i * 32, 16 * s, lane);
-                    bl[i] = rc_frag<BN + 32>(Bl, wn * WN + i * 32, 16 * s, lane);
+                    bh[i] = rc_frag<BN + 32>(sBh, wn * WN + i * 32, 16 * s, lane);
+                    bl[i] = rc_frag<BN + 32>(sBl, wn * WN + i * 32, 16 * s, lane);
                 }
             }
 #pragma unroll
@@ -781,35 +791,6 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16x3_kernel(IGemmParams p) {
 #pragma unroll
                 for (int q = 0; q < TN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
         }
-    };
-    if (c_begin < c_end) {
-        la.load(A, ra);
-        lb.load(B, rb);
-        LA::store_split(sAh, sAl, tid, ra);
-        LB::store_split(sBh, sBl, tid, rb);
-        if (c_begin + 1 < c_end) {
-            la.advance(A);
-            lb.advance(B);
-            la.load(A, ra);
-            lb.load(B, rb);
-        }
-    }
-    __syncthreads();
-    for (int c = c_begin; c < c_end; ++c) {
-        const int cur = (c - c_begin) & 1;
-        const unsigned short* Ah = sAh + cur * A_SZ; const unsigned short* Al = sAl + cur * A_SZ;
-        const unsigned short* Bh = sBh + cur * B_SZ; const unsigned short* Bl = sBl + cur * B_SZ;
-        if (c + 1 < c_end) {   // chunk c+1: registers -> the other buffer (its last readers passed the previous barrier)
-            LA::store_split(sAh + (cur ^ 1) * A_SZ, sAl + (cur ^ 1) * A_SZ, tid, ra);
-            LB::store_split(sBh + (cur ^ 1) * B_SZ, sBl + (cur ^ 1) * B_SZ, tid, rb);
-            if (c + 2 < c_end) {
-                la.advance(A);
-                lb.advance(B);
-                la.load(A, ra);
-                lb.load(B, rb);
-            }
-        }
-        compute(Ah, Al, Bh, Bl);
         __syncthreads();
     }
     epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi);
