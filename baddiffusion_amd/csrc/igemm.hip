@@ -68,6 +68,14 @@ struct IGemmParams {
     float* partial;  // [batch*ksplit][M][N] when ksplit > 1
 };
 
+// KC thread map: thread t owns float4 column (t&7)*4 of rows krow(t) + 32*i.  krow permutes the rows inside every
+// group of 8 so that the two rows a 16-lane ds_write_b64 group touches are 4 apart: with the 80 B row stride of the
+// split-bf16 planes their bank ranges then do not overlap (rows 1 apart overlap in 4 banks -> 2-way conflicts).
+__device__ __forceinline__ int krow(int tid) {
+    const int q = tid >> 3;
+    return (q & ~7) | ((q & 1) << 2) | ((q >> 1) & 3);
+}
+
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
 
@@ -97,7 +105,7 @@ struct KCStore {
     __device__ __forceinline__ static void store(float* s, int tid, const float4 (&v)[NI]) {
         const int k4 = (tid & 7) * 4;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + ((tid >> 3) + 32 * i) * LDK + k4) = v[i];
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + (krow(tid) + 32 * i) * LDK + k4) = v[i];
     }
     __device__ __forceinline__ static void store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]);
 };
@@ -174,7 +182,7 @@ __device__ __forceinline__ void KCStore<R>::store_split(unsigned short* sh, unsi
     const int k4 = (tid & 7) * 4;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int o = ((tid >> 3) + 32 * i) * LDH + k4;
+        const int o = (krow(tid) + 32 * i) * LDH + k4;
         *reinterpret_cast<uint2*>(sh + o) = make_uint2(pack_hi(v[i].x, v[i].y), pack_hi(v[i].z, v[i].w));
         *reinterpret_cast<uint2*>(sl + o) = make_uint2(pack_lo(v[i].x, v[i].y), pack_lo(v[i].z, v[i].w));
     }
@@ -192,7 +200,7 @@ struct DenseKC : KCStore<R> {
         krem = K - kbase - k4;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = row0 + (tid >> 3) + 32 * i;
+            const int r = row0 + krow(tid) + 32 * i;
             ok[i] = r < o.rows;
             ptr[i] = o.p + (long long)r * o.ld + kbase + k4;
         }
@@ -225,7 +233,7 @@ struct ConvKC : KCStore<R> {
         kw = tap - kh * 3;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = row0 + (tid >> 3) + 32 * i;
+            const int r = row0 + krow(tid) + 32 * i;
             int b, y, x;
             decode_pixel(o, r, b, y, x);
             base[i] = o.p + (long long)b * o.Hs * o.Ws * o.ld + k4;
@@ -266,7 +274,7 @@ struct WgtKC : KCStore<R> {
         c0 = (chunk / 9) * BK;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = row0 + (tid >> 3) + 32 * i;
+            const int r = row0 + krow(tid) + 32 * i;
             ok[i] = r < o.rows;
             ptr[i] = o.p + (long long)r * o.ld + k4;
         }
@@ -298,7 +306,7 @@ struct TConvKC : KCStore<R> {
         kw = tap - kh * 3;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = row0 + (tid >> 3) + 32 * i;
+            const int r = row0 + krow(tid) + 32 * i;
             int b, y, x;
             decode_pixel(o, r, b, y, x);
             base[i] = o.p + (long long)b * o.Hs * o.Ws * o.ld + k4;
@@ -429,7 +437,7 @@ struct GenericKC : KCStore<R> {
         k4 = (tid & 7) * 4; kbase = kb; K = K_;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = row0 + (tid >> 3) + 32 * i;
+            const int r = row0 + krow(tid) + 32 * i;
             const bool ok = r < o.rows;
             if (o.kind == BD_OPK_DENSE) {
                 base[i] = (long long)r * o.ld;
