@@ -566,10 +566,29 @@ constexpr int lds_floats() {
     return KC ? R * LDK : BK * (R + 4);
 }
 
-// ------------------------------------------------------------------------------------------------
+// ---- workgroup -> (tile, batch/split) -----------------------------------------------------------------------------
+// 1-D grid over tiles x batch x ksplit.  Workgroup b runs on XCD b % 8 (cdna guide T1; speed only, nothing depends on
+// it), and each XCD has its own L2: hand every XCD one contiguous run of the logical order (n fastest, then m, then
+// split / batch), so the tiles that re-read the same A panel -- and, with split-K, the same k-slice of both operands --
+// meet in one L2 instead of being fetched by all eight.
+struct WgCoord {
+    int tm, tn, zz;
+};
+__device__ __forceinline__ WgCoord wg_coord(const IGemmParams& p) {
+    const unsigned L = blockIdx.x, T = gridDim.x, q = T >> 3;
+    const unsigned j = L < (q << 3) ? (L & 7) * q + (L >> 3) : L;
+    const unsigned ntiles = p.tiles_m * p.tiles_n;
+    const unsigned zz = j / ntiles, tile = j - zz * ntiles;
+    WgCoord w;
+    w.tm = tile / p.tiles_n;
+    w.tn = tile - w.tm * p.tiles_n;
+    w.zz = zz;
+    return w;
+}
+
 // ---- epilogue: lane holds column (n) li of rows (r&3) + 8*(r>>2) + 4*h of every 32x32 tile ---------------------
 template <int TM, int TN>
-__device__ __forceinline__ void epilogue(const IGemmParams& p, floatx16 (&acc)[TM][TN], int mw, int nw, int li, int h, int bo, int bi) {
+__device__ __forceinline__ void epilogue(const IGemmParams& p, floatx16 (&acc)[TM][TN], int mw, int nw, int li, int h, int bo, int bi, int zz) {
     const long long coff = bo * p.c_bso + bi * p.c_bsi;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
@@ -584,7 +603,7 @@ __device__ __forceinline__ void epilogue(const IGemmParams& p, floatx16 (&acc)[T
                 if (m >= p.M) continue;
                 float v = acc[i][q][r];
                 if (p.ksplit > 1) {
-                    p.partial[((long long)blockIdx.z * p.M + m) * p.N + n] = v;
+                    p.partial[((long long)zz * p.M + m) * p.N + n] = v;
                 } else {
                     v = v * p.alpha + bn;
                     if (p.rowbias) v += p.rowbias[(long long)(m / p.rows_per_group) * p.ld_rowbias + n];
@@ -613,12 +632,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     // tile coordinates: n fastest so neighbouring workgroups share the A (activation) panel
     // XCD-aware order (cdna guide T1): workgroup b runs on XCD b % 8, so give every XCD a contiguous run of
     // logical tiles -- neighbours (same A panel, next n; adjacent m) then share that XCD's L2.  Speed only.
-    int tile = blockIdx.x;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
-    const int tn_i = tile % p.tiles_n, tm_i = tile / p.tiles_n;
-    const int m0 = tm_i * BM, n0 = tn_i * BN;
-    const int bz = blockIdx.z / p.ksplit, ks = blockIdx.z - bz * p.ksplit;
+    const WgCoord wg = wg_coord(p);
+    const int m0 = wg.tm * BM, n0 = wg.tn * BN;
+    const int bz = wg.zz / p.ksplit, ks = wg.zz - bz * p.ksplit;
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
 
     Opnd A = p.A, B = p.B;
@@ -694,7 +710,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         __syncthreads();
     }
 
-    epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi);
+    epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi, wg.zz);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -716,12 +732,9 @@ __global__ __launch_bounds__(256, 3) void igemm_bf16x3_kernel(IGemmParams p) {
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, h = lane >> 5;
 
-    int tile = blockIdx.x;
-    const int ntiles = p.tiles_m * p.tiles_n;
-    if ((ntiles & 7) == 0) tile = (tile & 7) * (ntiles >> 3) + (tile >> 3);
-    const int tn_i = tile % p.tiles_n, tm_i = tile / p.tiles_n;
-    const int m0 = tm_i * BM, n0 = tn_i * BN;
-    const int bz = blockIdx.z / p.ksplit, ks = blockIdx.z - bz * p.ksplit;
+    const WgCoord wg = wg_coord(p);
+    const int m0 = wg.tm * BM, n0 = wg.tn * BN;
+    const int bz = wg.zz / p.ksplit, ks = wg.zz - bz * p.ksplit;
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
 
     Opnd A = p.A, B = p.B;
@@ -801,7 +814,7 @@ __global__ __launch_bounds__(256, 3) void igemm_bf16x3_kernel(IGemmParams p) {
         }
         __syncthreads();
     }
-    epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi);
+    epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi, wg.zz);
 }
 
 // split-K second pass: fixed-order (deterministic) sum of the partial slabs + epilogue
@@ -1002,7 +1015,7 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
                  "igemm: split-K needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
         p.partial = reinterpret_cast<float*>(d.workspace);
     }
-    dim3 grid(p.tiles_m * p.tiles_n, 1, nb * c.ksplit);
+    dim3 grid((unsigned)(p.tiles_m * p.tiles_n * nb * c.ksplit), 1, 1);
     BD_CHECK(grid.z <= 65535, BD_ERR_UNSUPPORTED, "igemm: batch*ksplit %u too large", grid.z);
     const bool fast = operand_fast_ok(d.A, d.M, d.K) && operand_fast_ok(d.B, d.N, d.K);
     const Cls cls = classify(d, fast);
