@@ -10,6 +10,7 @@ Physically the parameters are ONE flat fp32 nn.Parameter (`self.flat`) laid out 
 is `bd_unet_backward`.  There is no PyTorch implementation of the network here: without the HIP
 library or without a GPU tensor, forward raises.
 """
+import os
 import ctypes as C
 import math
 from collections import OrderedDict
@@ -77,7 +78,7 @@ class UNet2DModel(nn.Module):
                  block_out_channels=(224, 448, 672, 896), layers_per_block=2, mid_block_scale_factor=1,
                  downsample_padding=1, act_fn="silu", attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5,
                  resnet_time_scale_shift="default", add_attention=True, class_embed_type=None, num_class_embeds=None,
-                 max_chunk=512, compute_mode="f32", **unused):
+                 max_chunk=512, compute_mode=None, **unused):
         super().__init__()
         # ---- loud failures for what the reference class supports but BadDiffusion never uses -------------
         if len(down_block_types) != len(up_block_types):
@@ -137,6 +138,10 @@ class UNet2DModel(nn.Module):
         c.norm_num_groups = int(norm_num_groups)
         c.attention_head_dim = int(attention_head_dim or 0)
         c.mid_block_scale_factor = float(mid_block_scale_factor)
+        if compute_mode is None:   # matrix-product arithmetic: split-bf16 (default) or bit-exact fp32 (include/bd_hip.h)
+            compute_mode = os.environ.get("BD_COMPUTE_MODE", "bf16x3")
+        if compute_mode not in COMPUTE_MODES:
+            raise ValueError(f"compute_mode must be one of {sorted(COMPUTE_MODES)}, got {compute_mode!r}")
         c.compute_mode = COMPUTE_MODES[compute_mode]
         self.compute_mode = compute_mode
         h = C.c_void_p()

@@ -31,6 +31,32 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA (split-bf16 mode issues 
 HBM_PEAK_GBS = 8000.0
 
 
+_PMC_OPERANDS = {"conv_fwd": "ConvKC<{T}>, bd::WgtKC<{T}>", "conv_dgrad": "TConvKC<{T}>, bd::WgtRC<{T}, false>",
+                 "conv_wgrad": "DenseRC<{T}, false>, bd::ConvRC<{T}, false>", "gemm_nt": "DenseKC<{T}>, bd::DenseKC<{T}>",
+                 "gemm_nn": "DenseKC<{T}>, bd::DenseRC<{T}, false>", "gemm_tn": "DenseRC<{T}, false>, bd::DenseRC<{T}, false>"}
+
+
+def _pmc_traffic(cls):
+    """HBM-side bytes per launch of kernel class `cls` from the committed rocprofv3 PMC passes of this same command
+    (scripts/pmc_bench.sh -> profiles/r01_pmc_bench_<mode>.json; FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950
+    correction for 16 B/lane reads, + WRITE_SIZE; KB -> bytes).  None when that file or kernel is absent: counters
+    cannot be collected from inside the timed process."""
+    import re
+    m = re.match(r"igemm_(\w+?)_(\d+)(_bf16x3)?$", cls)
+    if not m or m.group(1) not in _PMC_OPERANDS:
+        return None
+    mode = "bf16x3" if m.group(3) else "f32"
+    path = os.path.join(ROOT, "profiles", f"r01_pmc_bench_{mode}.json")
+    if not os.path.exists(path):
+        return None
+    T = m.group(2)
+    want = ("igemm_bf16x3_kernel" if m.group(3) else "igemm_kernel") + f"<{T}, {T}, bd::" + _PMC_OPERANDS[m.group(1)].format(T=T)
+    for name, v in json.load(open(path))["kernels"].items():
+        if want in name and "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
+            return (2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0
+    return None
+
+
 def _host_cores():
     """Usable host cores: affinity mask capped by the cgroup CPU quota (the GPU boxes expose 256 hardware
     threads but a 16-CPU quota; running 256 OpenMP threads there is ~50x slower than running 16)."""
@@ -115,7 +141,7 @@ def main():
     ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
-    ap.add_argument("--mode", default=os.environ.get("BD_COMPUTE_MODE", "f32"), choices=["f32", "bf16x3"],
+    ap.add_argument("--mode", default=os.environ.get("BD_COMPUTE_MODE", "bf16x3"), choices=["f32", "bf16x3"],
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (hi+lo, 3 MFMAs, ~2^-16 rel. error)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -237,13 +263,18 @@ def main():
             if classes:
                 d = classes[0]
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-                peak = FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS
+                # split-bf16 issues 3 bf16 MFMA products per algorithmic multiply: its ceiling for ALGORITHMIC flops is
+                # the dense bf16 peak / 3 (833 TF), above the exact-fp32 MFMA peak (157 TF) the f32 mode is bound by
+                peak = FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 3
                 out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": peak,
-                                   "unit": "TFLOP/s", "frac": ach / peak, "traffic": None,
+                                   "unit": "TFLOP/s", "frac": ach / peak, "traffic": _pmc_traffic(d["kernel"]),
                                    "mfma_flops_per_algorithmic_flop": 1 if args.mode == "f32" else 3,
+                                   "mfma_dense_peak": FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS,
+                                   "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                                    "launches_per_step": d["launches"] / prof_steps, "sampled_steps": prof_steps,
                                    "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                                    "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                                   "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                                    "alg_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
                                    "share_of_step": d["ms"] / prof_steps / ms}
                 out["kernel_classes"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in classes]

@@ -1,0 +1,27 @@
+#!/bin/bash
+# HBM traffic of every kernel of the bench step from PMC counters, one counter per pass (guide: FETCH_SIZE and
+# WRITE_SIZE do not fit one pass; kernel-trace only).  usage: pmc_bench.sh <mode> -> gpurun_out/pmc_bench_<mode>.json
+mode=${1:-bf16x3}
+cd /tmp && export TMPDIR=/tmp
+for c in FETCH_SIZE WRITE_SIZE; do
+  rm -rf /tmp/pb_$c
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pb_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --mode $mode > /tmp/pb_$c.log 2>&1
+done
+python3 - $mode <<'PY'
+import csv, sys, glob, json, collections, os
+out = collections.defaultdict(dict)
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    f = glob.glob(f"/tmp/pb_{c}/**/*counter_collection.csv", recursive=True)
+    if not f:
+        continue
+    agg = collections.defaultdict(float); disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(f[0])):
+        if r["Counter_Name"] != c: continue
+        agg[r["Kernel_Name"]] += float(r["Counter_Value"]); disp[r["Kernel_Name"]].add(r["Dispatch_Id"])
+    for k, v in agg.items():
+        out[k][c + "_KB_per_launch"] = v / len(disp[k]); out[k]["launches"] = len(disp[k])
+root = os.environ["GRAFT_REPO_ROOT"]
+json.dump({"note": "rocprofv3 --pmc, KB per launch (raw counter values: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, "
+                   "MI355X_MICROARCH.md; bench.py applies the x2)", "kernels": out}, open(f"{root}/gpurun_out/pmc_bench_{sys.argv[1]}.json", "w"), indent=1)
+print({k[:60]: v for k, v in list(out.items())[:6]})
+PY
