@@ -66,7 +66,8 @@ class IgemmDesc(C.Structure):
                 ("alpha", f32), ("out_scale", f32), ("bias", vp),
                 ("rowbias", vp), ("ld_rowbias", i64), ("rows_per_group", i32),
                 ("residual", vp), ("ldr", i64), ("accumulate", i32), ("ksplit", i32),
-                ("workspace", vp), ("workspace_bytes", sz), ("tile", i32), ("mode", i32)]
+                ("workspace", vp), ("workspace_bytes", sz), ("tile", i32), ("mode", i32),
+                ("a_colsum", vp)]
 
 
 class ConvFwdDesc(C.Structure):
@@ -88,7 +89,7 @@ class ConvWgradDesc(C.Structure):
     _fields_ = [("B", i32), ("Hs", i32), ("Ws", i32), ("Cin", i32), ("Cout", i32), ("stride", i32),
                 ("pad_t", i32), ("pad_l", i32), ("ups", i32), ("Ho", i32), ("Wo", i32),
                 ("x", vp), ("ldx", i64), ("dy", vp), ("lddy", i64), ("dw", vp),
-                ("workspace", vp), ("workspace_bytes", sz), ("mode", i32)]
+                ("workspace", vp), ("workspace_bytes", sz), ("mode", i32), ("db", vp)]
 
 
 class UnetConfig(C.Structure):

@@ -68,13 +68,14 @@ int conv3x3_wgrad(const bd_conv3x3_wgrad_desc& d, hipStream_t st) {
     g.C = d.dw; g.ldc = 9ll * d.Cin;
     g.alpha = 1.f; g.out_scale = 1.f;
     g.workspace = d.workspace; g.workspace_bytes = d.workspace_bytes; g.mode = d.mode;
+    g.a_colsum = d.db;
     return igemm_launch(g, st);
 }
 
 size_t conv3x3_workspace_bytes(int B, int Ho, int Wo, int Hs, int Ws, int Cin, int Cout, int ups) {
     // upper bound over fwd / dgrad / wgrad split-K slabs: ksplit <= 128 only when tiles < 256, so
     // ksplit*tiles <= 512 + 256 tiles of at most 128x128 floats.
-    size_t a = (size_t)768 * 128 * 128 * sizeof(float);
+    size_t a = (size_t)768 * 128 * 128 * sizeof(float) + ((size_t)1 << 20);   // + fused bias-gradient partial rows
     (void)B; (void)Ho; (void)Wo; (void)Hs; (void)Ws; (void)Cin; (void)Cout; (void)ups;
     return a;
 }

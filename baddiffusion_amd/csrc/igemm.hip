@@ -65,7 +65,8 @@ struct IGemmParams {
     const float* residual;
     long long ldr;
     int accumulate;
-    float* partial;  // [batch*ksplit][M][N] when ksplit > 1
+    float* partial;  // [batch*ksplit][M][N] when ksplit > 1, then [ksplit][M] column-sum partials
+    float* a_colsum; // optional: out[m] = sum_k A(m,k) (RC A operand, batch 1)
 };
 
 // KC thread map: thread t owns float4 column (t&7)*4 of rows krow(t) + 32*i.  krow permutes the rows inside every
@@ -617,6 +618,25 @@ __device__ __forceinline__ void epilogue(const IGemmParams& p, floatx16 (&acc)[T
         }
 }
 
+// ---- fused row sums of the A operand (bias gradients: A = dY^T of a wgrad) --------------------------------------------
+// Every RC A value passes through the registers of exactly one thread of every n-tile's workgroup; the tn == 0
+// workgroups add theirs up (thread-fixed row quad r4, k phases kfirst + KSTEP*i), fold the k phases through LDS in a
+// fixed order and emit out[m] (or one split-K partial row).  No extra memory traffic, deterministic.
+template <int BM>
+__device__ __forceinline__ void colsum_tail(const IGemmParams& p, float* red, float4 cs, int tid, int m0, int zz) {
+    constexpr int NPH = 1024 / BM;   // k phases = 256 threads / (BM/4) row quads
+    *reinterpret_cast<float4*>(red + RCMap<BM, false>::kfirst(tid) * BM + RCMap<BM, false>::r4(tid)) = cs;
+    __syncthreads();
+    if (tid < BM && m0 + tid < p.M) {
+        float v = 0.f;
+#pragma unroll
+        for (int ph = 0; ph < NPH; ++ph) v += red[ph * BM + tid];
+        if (p.ksplit > 1) p.partial[(long long)p.ksplit * p.M * p.N + (long long)zz * p.M + m0 + tid] = v;
+        else p.a_colsum[m0 + tid] = v;
+    }
+}
+__device__ __forceinline__ void add4(float4& a, const float4& b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
 template <int BM, int BN, class LA, class LB>
 __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
     constexpr bool A_KC = LA::kKC, B_KC = LB::kKC;
@@ -664,7 +684,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         la.load(A, ra);
         lb.load(B, rb);
     }
+    const bool do_cs = !A_KC && p.a_colsum != nullptr && wg.tn == 0;
+    float4 cs = zero4();
     for (int c = c_begin; c < c_end; ++c) {
+        if (do_cs) {
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i) add4(cs, ra[i]);
+        }
         LA::store(sA, tid, ra);
         LB::store(sB, tid, rb);
         __syncthreads();
@@ -710,6 +736,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         __syncthreads();
     }
 
+    if (do_cs) colsum_tail<BM>(p, sA, cs, tid, m0, wg.zz);
     epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi, wg.zz);
 }
 
@@ -764,7 +791,13 @@ __global__ __launch_bounds__(256, 3) void igemm_bf16x3_kernel(IGemmParams p) {
         la.load(A, ra);
         lb.load(B, rb);
     }
+    const bool do_cs = !A_KC && p.a_colsum != nullptr && wg.tn == 0;
+    float4 cs = zero4();
     for (int c = c_begin; c < c_end; ++c) {
+        if (do_cs) {
+#pragma unroll
+            for (int i = 0; i < BM / 32; ++i) add4(cs, ra[i]);
+        }
         LA::store_split(sAh, sAl, tid, ra);
         LB::store_split(sBh, sBl, tid, rb);
         __syncthreads();
@@ -814,6 +847,7 @@ __global__ __launch_bounds__(256, 3) void igemm_bf16x3_kernel(IGemmParams p) {
         }
         __syncthreads();
     }
+    if (do_cs) colsum_tail<BM>(p, reinterpret_cast<float*>(sAh), cs, tid, m0, wg.zz);
     epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi, wg.zz);
 }
 
@@ -821,7 +855,15 @@ __global__ __launch_bounds__(256, 3) void igemm_bf16x3_kernel(IGemmParams p) {
 __global__ __launch_bounds__(256) void igemm_splitk_reduce(IGemmParams p, int nbatch) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long per = (long long)p.M * p.N;
-    if (idx >= per * nbatch) return;
+    if (idx >= per * nbatch) {   // tail threads: the fused A column sums (batch 1 only)
+        const long long m = idx - per * nbatch;
+        if (p.a_colsum && m < p.M) {
+            float v = 0.f;
+            for (int s = 0; s < p.ksplit; ++s) v += p.partial[(long long)p.ksplit * per + (long long)s * p.M + m];
+            p.a_colsum[m] = v;
+        }
+        return;
+    }
     const int bz = (int)(idx / per);
     const long long mn = idx - (long long)bz * per;
     const int m = (int)(mn / p.N), n = (int)(mn - (long long)m * p.N);
@@ -935,7 +977,7 @@ static Choice choose(const bd_igemm_desc& d) {
 size_t igemm_workspace_bytes(const bd_igemm_desc& d) {
     Choice c = choose(d);
     if (c.ksplit <= 1) return 0;
-    return (size_t)d.batch_outer * d.batch_inner * c.ksplit * (size_t)d.M * d.N * sizeof(float);
+    return (size_t)d.batch_outer * d.batch_inner * c.ksplit * ((size_t)d.M * d.N + (d.a_colsum ? (size_t)d.M : 0)) * sizeof(float);
 }
 
 enum Cls { CLS_GENERIC = 0, CLS_CONV_FWD, CLS_CONV_DGRAD, CLS_CONV_WGRAD, CLS_GEMM_NT, CLS_GEMM_NN, CLS_GEMM_TN };
@@ -1008,9 +1050,12 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
     p.rows_per_group = d.rows_per_group > 0 ? d.rows_per_group : 1;
     p.residual = d.residual; p.ldr = d.ldr; p.accumulate = d.accumulate;
     p.partial = nullptr;
+    p.a_colsum = d.a_colsum;
     const int nb = d.batch_outer * d.batch_inner;
+    BD_CHECK(!d.a_colsum || (nb == 1 && d.A.kc == 0 && d.A.kind == BD_OPK_DENSE && (d.M & 3) == 0), BD_ERR_UNSUPPORTED,
+             "igemm: a_colsum needs a row-contiguous DENSE A operand, M %% 4 == 0 and batch 1");
     if (c.ksplit > 1) {
-        size_t need = (size_t)nb * c.ksplit * (size_t)d.M * d.N * sizeof(float);
+        size_t need = (size_t)nb * c.ksplit * ((size_t)d.M * d.N + (d.a_colsum ? (size_t)d.M : 0)) * sizeof(float);
         BD_CHECK(d.workspace && d.workspace_bytes >= need, BD_ERR_WORKSPACE,
                  "igemm: split-K needs %zu workspace bytes, got %zu", need, d.workspace_bytes);
         p.partial = reinterpret_cast<float*>(d.workspace);
@@ -1042,7 +1087,7 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
     }
     BD_LAUNCH_CHECK("igemm");
     if (c.ksplit > 1) {
-        long long total = (long long)d.M * d.N * nb;
+        long long total = (long long)d.M * d.N * nb + (d.a_colsum ? d.M : 0);
         hipLaunchKernelGGL(igemm_splitk_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, p, nb);
         BD_LAUNCH_CHECK("igemm_splitk_reduce");
     }

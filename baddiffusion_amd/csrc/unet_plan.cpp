@@ -173,12 +173,13 @@ struct bd_unet {
         g.C = dX; g.ldc = lddx; g.alpha = 1.f; g.out_scale = 1.f; g.accumulate = acc;
         return igemm(c, g);
     }
-    // dW[N,K] = dY[M,N]^T * X[M,K]
-    int linear_wgrad(Ctx& c, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int M, int N, int K) const {
+    // dW[N,K] = dY[M,N]^T * X[M,K]; db[N] = column sums of dY, fused into the same launch (N % 4 == 0)
+    int linear_wgrad(Ctx& c, const float* dY, int64_t lddy, const float* X, int64_t ldx, float* dW, int M, int N, int K,
+                     float* db = nullptr) const {
         bd_igemm_desc g = {};
         g.A = dense(dY, lddy, 0); g.B = dense(X, ldx, 0);
         g.M = N; g.N = K; g.K = M; g.batch_outer = g.batch_inner = 1;
-        g.C = dW; g.ldc = K; g.alpha = 1.f; g.out_scale = 1.f;
+        g.C = dW; g.ldc = K; g.alpha = 1.f; g.out_scale = 1.f; g.a_colsum = db;
         return igemm(c, g);
     }
     int colsum(Ctx& c, const float* x, int64_t ldx, int64_t nrows, int N, int64_t rpg, float* out, int64_t ldo) const {
@@ -287,16 +288,13 @@ void bd_unet::node_time_embed() {
     });
     Bk([=](Ctx& c) {
         float* dtp = BP(c, b_dtproj);
-        BD_TRY(linear_wgrad(c, dtp, sumC, BP(c, b_embs), T, c.grads + p_tw, c.B, sumC, T));
-        BD_TRY(colsum(c, dtp, sumC, c.B, sumC, c.B, c.grads + p_tb, sumC));
+        BD_TRY(linear_wgrad(c, dtp, sumC, BP(c, b_embs), T, c.grads + p_tw, c.B, sumC, T, c.grads + p_tb));
         BD_TRY(linear_dgrad(c, dtp, sumC, c.params + p_tw, BP(c, b_dembs), T, c.B, sumC, T, 0));
         if (!c.dry) BD_TRY(bd_silu_bwd(BP(c, b_emb), BP(c, b_dembs), BP(c, b_demb), (int64_t)c.B * T, 0, (bd_stream_t)c.st));
-        BD_TRY(linear_wgrad(c, BP(c, b_demb), T, BP(c, b_e1s), T, c.grads + pw2, c.B, T, T));
-        BD_TRY(colsum(c, BP(c, b_demb), T, c.B, T, c.B, c.grads + pb2, T));
+        BD_TRY(linear_wgrad(c, BP(c, b_demb), T, BP(c, b_e1s), T, c.grads + pw2, c.B, T, T, c.grads + pb2));
         BD_TRY(linear_dgrad(c, BP(c, b_demb), T, c.params + pw2, BP(c, b_de1s), T, c.B, T, T, 0));
         if (!c.dry) BD_TRY(bd_silu_bwd(BP(c, b_e1), BP(c, b_de1s), BP(c, b_de1), (int64_t)c.B * T, 0, (bd_stream_t)c.st));
-        BD_TRY(linear_wgrad(c, BP(c, b_de1), T, BP(c, b_tsin), c0, c.grads + pw1, c.B, T, c0));
-        BD_TRY(colsum(c, BP(c, b_de1), T, c.B, T, c.B, c.grads + pb1, T));
+        BD_TRY(linear_wgrad(c, BP(c, b_de1), T, BP(c, b_tsin), c0, c.grads + pw1, c.B, T, c0, c.grads + pb1));
         return (int)BD_OK;
     });
 }
@@ -315,10 +313,9 @@ void bd_unet::node_conv_in(const View& y) {
     });
     Bk([=](Ctx& c) {
         const float* dy = GP(c, y);
-        BD_TRY(bias_grad(c, dy, y.ld, S_ * S_, Cout, b_bs, c.grads + pb));
         bd_conv3x3_wgrad_desc d = {};
         d.B = c.B; d.Hs = S_; d.Ws = S_; d.Cin = Cin; d.Cout = Cout; d.stride = 1; d.pad_t = 1; d.pad_l = 1; d.Ho = S_; d.Wo = S_;
-        d.x = c.x; d.ldx = c.ldx; d.dy = dy; d.lddy = y.ld; d.dw = c.grads + pw;
+        d.x = c.x; d.ldx = c.ldx; d.dy = dy; d.lddy = y.ld; d.dw = c.grads + pw; d.db = c.grads + pb;
         return conv_w(c, d);
     });
 }
@@ -377,10 +374,9 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             BD_TRY(add(c, dy, lddy, BP(c, b_dys), Cout, M, Cout, inv, 0));
             dy = BP(c, b_dys); lddy = Cout;
         }
-        BD_TRY(bias_grad(c, dy, lddy, HW, Cout, b_bs, c.grads + pc2b, shortcut ? c.grads + psb : nullptr));
         bd_conv3x3_wgrad_desc w2 = {};
         w2.B = c.B; w2.Hs = H; w2.Ws = W; w2.Cin = Cout; w2.Cout = Cout; w2.stride = 1; w2.pad_t = 1; w2.pad_l = 1; w2.Ho = H; w2.Wo = W;
-        w2.x = BP(c, b_a2); w2.ldx = Cout; w2.dy = dy; w2.lddy = lddy; w2.dw = c.grads + pc2w;
+        w2.x = BP(c, b_a2); w2.ldx = Cout; w2.dy = dy; w2.lddy = lddy; w2.dw = c.grads + pc2w; w2.db = c.grads + pc2b;
         BD_TRY(conv_w(c, w2));
         bd_conv3x3_dgrad_desc g2 = {};
         g2.B = c.B; g2.Hs = H; g2.Ws = W; g2.Cin = Cout; g2.Cout = Cout; g2.stride = 1; g2.pad_t = 1; g2.pad_l = 1; g2.Ho = H; g2.Wo = W;
@@ -399,10 +395,9 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
         // time-embedding gradient (per-sample column sums of dh1) and conv1 bias gradient
         float* dtp = BP(c, b_dtproj) + toff;
         BD_TRY(colsum(c, BP(c, b_dh1), Cout, M, Cout, HW, dtp, sumC_));
-        BD_TRY(colsum(c, dtp, sumC_, c.B, Cout, c.B, c.grads + pc1b, Cout));
         bd_conv3x3_wgrad_desc w1 = {};
         w1.B = c.B; w1.Hs = H; w1.Ws = W; w1.Cin = Cin; w1.Cout = Cout; w1.stride = 1; w1.pad_t = 1; w1.pad_l = 1; w1.Ho = H; w1.Wo = W;
-        w1.x = BP(c, b_a1); w1.ldx = Cin; w1.dy = BP(c, b_dh1); w1.lddy = Cout; w1.dw = c.grads + pc1w;
+        w1.x = BP(c, b_a1); w1.ldx = Cin; w1.dy = BP(c, b_dh1); w1.lddy = Cout; w1.dw = c.grads + pc1w; w1.db = c.grads + pc1b;
         BD_TRY(conv_w(c, w1));
         bd_conv3x3_dgrad_desc g1 = {};
         g1.B = c.B; g1.Hs = H; g1.Ws = W; g1.Cin = Cin; g1.Cout = Cout; g1.stride = 1; g1.pad_t = 1; g1.pad_l = 1; g1.Ho = H; g1.Wo = W;
@@ -411,7 +406,7 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
         BD_TRY(gn_bwd(c, x, pn1w, pn1b, b_st1, BP(c, b_da1), Cin, 1));
         // residual path
         if (shortcut) {
-            BD_TRY(linear_wgrad(c, dy, lddy, VP(c, x), x.ld, c.grads + psw, M, Cout, Cin));
+            BD_TRY(linear_wgrad(c, dy, lddy, VP(c, x), x.ld, c.grads + psw, M, Cout, Cin, c.grads + psb));
             BD_TRY(linear_dgrad(c, dy, lddy, c.params + psw, GP(c, x), x.ld, M, Cout, Cin, 1));
         } else {
             BD_TRY(add(c, dy, lddy, GP(c, x), x.ld, M, Cout, 1.f, 1));
@@ -480,8 +475,7 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
         }
         float* qkv = BP(c, b_qkv); float* dqkv = BP(c, b_dqkv); float* P = BP(c, b_p); float* dP = BP(c, b_dp);
         float* dO = BP(c, b_do);
-        BD_TRY(bias_grad(c, dy, lddy, N, C, b_bs, c.grads + ppb));
-        BD_TRY(linear_wgrad(c, dy, lddy, BP(c, b_o), C, c.grads + ppw, M, C, C));
+        BD_TRY(linear_wgrad(c, dy, lddy, BP(c, b_o), C, c.grads + ppw, M, C, C, c.grads + ppb));
         BD_TRY(linear_dgrad(c, dy, lddy, c.params + ppw, dO, C, M, C, C, 0));
         {   // dP = dO V^T
             bd_igemm_desc g = {};
@@ -520,8 +514,7 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
             g.alpha = sm_scale; g.out_scale = 1.f;
             BD_TRY(igemm(c, g));
         }
-        BD_TRY(bias_grad(c, dqkv, 3 * C, N, 3 * C, b_bs, c.grads + pqb));
-        BD_TRY(linear_wgrad(c, dqkv, 3 * C, BP(c, b_n), C, c.grads + pqw, M, 3 * C, C));
+        BD_TRY(linear_wgrad(c, dqkv, 3 * C, BP(c, b_n), C, c.grads + pqw, M, 3 * C, C, c.grads + pqb));
         BD_TRY(linear_dgrad(c, dqkv, 3 * C, c.params + pqw, BP(c, b_dn), C, M, 3 * C, C, 0));
         BD_TRY(gn_bwd(c, x, pgw, pgb, b_st, BP(c, b_dn), C, 0));
         return add(c, dy, lddy, GP(c, x), x.ld, M, C, 1.f, 1);
@@ -542,10 +535,9 @@ void bd_unet::node_downsample(const std::string& pre, const View& x, const View&
     });
     Bk([=](Ctx& c) {
         const float* dy = GP(c, y);
-        BD_TRY(bias_grad(c, dy, y.ld, Ho * Wo, C, b_bs, c.grads + pb));
         bd_conv3x3_wgrad_desc w = {};
         w.B = c.B; w.Hs = H; w.Ws = W; w.Cin = C; w.Cout = C; w.stride = 2; w.pad_t = pad; w.pad_l = pad; w.Ho = Ho; w.Wo = Wo;
-        w.x = VP(c, x); w.ldx = x.ld; w.dy = dy; w.lddy = y.ld; w.dw = c.grads + pw;
+        w.x = VP(c, x); w.ldx = x.ld; w.dy = dy; w.lddy = y.ld; w.dw = c.grads + pw; w.db = c.grads + pb;
         BD_TRY(conv_w(c, w));
         bd_conv3x3_dgrad_desc g = {};
         g.B = c.B; g.Hs = H; g.Ws = W; g.Cin = C; g.Cout = C; g.stride = 2; g.pad_t = pad; g.pad_l = pad; g.Ho = Ho; g.Wo = Wo;
@@ -568,10 +560,9 @@ void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y
     });
     Bk([=](Ctx& c) {
         const float* dy = GP(c, y);
-        BD_TRY(bias_grad(c, dy, y.ld, 4 * H * W, C, b_bs, c.grads + pb));
         bd_conv3x3_wgrad_desc w = {};
         w.B = c.B; w.Hs = H; w.Ws = W; w.Cin = C; w.Cout = C; w.stride = 1; w.pad_t = 1; w.pad_l = 1; w.ups = 1; w.Ho = 2 * H; w.Wo = 2 * W;
-        w.x = VP(c, x); w.ldx = x.ld; w.dy = dy; w.lddy = y.ld; w.dw = c.grads + pw;
+        w.x = VP(c, x); w.ldx = x.ld; w.dy = dy; w.lddy = y.ld; w.dw = c.grads + pw; w.db = c.grads + pb;
         BD_TRY(conv_w(c, w));
         bd_conv3x3_dgrad_desc g = {};
         g.B = c.B; g.Hs = H; g.Ws = W; g.Cin = C; g.Cout = C; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.ups = 1; g.Ho = 2 * H; g.Wo = 2 * W;

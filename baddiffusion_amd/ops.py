@@ -234,7 +234,8 @@ def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False, mode=0):
     return dx
 
 
-def conv3x3_wgrad(x, dy, stride=1, pad=1, ups=0, asym=False, mode=0):
+def conv3x3_wgrad(x, dy, stride=1, pad=1, ups=0, asym=False, mode=0, with_db=False):
+    """dw [Cout,3,3,Cin]; with_db also returns the bias gradient (sum of dy over pixels) fused into the same launch."""
     lib = L.load(); _need_cuda(x, dy)
     B, Hs, Ws, Cin = x.shape
     Cout = dy.shape[-1]
@@ -245,11 +246,13 @@ def conv3x3_wgrad(x, dy, stride=1, pad=1, ups=0, asym=False, mode=0):
     d = L.ConvWgradDesc(B=B, Hs=Hs, Ws=Ws, Cin=Cin, Cout=Cout, stride=stride, pad_t=pt, pad_l=pl, ups=ups, Ho=Ho, Wo=Wo,
                         x=L.ptr(x), ldx=_ld(x), dy=L.ptr(dy), lddy=_ld(dy), dw=L.ptr(dw), workspace=L.ptr(ws),
                         workspace_bytes=ws.numel(), mode=mode)
+    db = torch.empty(Cout, device=x.device) if with_db else None
+    d.db = L.ptr(db)
     L.check(lib.bd_conv3x3_wgrad(C.byref(d), L.stream()), "bd_conv3x3_wgrad")
-    return dw
+    return (dw, db) if with_db else dw
 
 
-def gemm(a, b, trans_a=False, trans_b=True, bias=None, alpha=1.0, tile=0, ksplit=0, mode=0):
+def gemm(a, b, trans_a=False, trans_b=True, bias=None, alpha=1.0, tile=0, ksplit=0, mode=0, a_colsum=None):
     """C = alpha * op(a) @ op(b)^T-style product on the igemm engine.
     a: [M,K] (trans_a False) or [K,M] (trans_a True); b: [N,K] (trans_b True, 'weights') or [K,N] (False).
     Batched when a/b are 3-D (same leading batch)."""
@@ -269,7 +272,7 @@ def gemm(a, b, trans_a=False, trans_b=True, bias=None, alpha=1.0, tile=0, ksplit
     d.batch_outer, d.batch_inner = nb, 1
     d.C = L.ptr(c); d.ldc = N; d.c_bs_outer = M * N
     d.alpha = alpha; d.out_scale = 1.0; d.bias = L.ptr(bias)
-    d.tile = tile; d.ksplit = ksplit; d.mode = mode
+    d.tile = tile; d.ksplit = ksplit; d.mode = mode; d.a_colsum = L.ptr(a_colsum)
     need = lib.bd_igemm_workspace_bytes(C.byref(d))
     ws = workspace(need, a.device)
     d.workspace = L.ptr(ws); d.workspace_bytes = ws.numel()

@@ -189,6 +189,8 @@ typedef struct {
     void* workspace; size_t workspace_bytes;
     int tile;                                /* 0 = choose, 128 or 64                           */
     int mode;                                /* bd_compute_mode                                 */
+    float* a_colsum;                         /* optional [M]: sum_k A(m,k), fused (bias gradient of a
+                                                wgrad, A = dY^T); needs DENSE row-contiguous A, batch 1 */
 } bd_igemm_desc;
 size_t bd_igemm_workspace_bytes(const bd_igemm_desc* d);
 int bd_igemm(const bd_igemm_desc* d, bd_stream_t stream);
@@ -197,7 +199,7 @@ int bd_igemm(const bd_igemm_desc* d, bd_stream_t stream);
  * conv fwd:   y[B,Ho,Wo,Cout] = conv3x3(x[B,Hs,Ws,Cin] (nearest-upsampled x2 if ups), stride, pads)
  *             (+bias) (+rowbias per sample) (+residual) ; resnet.py:493,514,118,185,201-203
  * dgrad:      dx[B,Hs<<ups,Ws<<ups,Cin] (the conv's own input grid)
- * wgrad:      dw[Cout][3][3][Cin] (written), db[Cout] via bd_colsum                            */
+ * wgrad:      dw[Cout][3][3][Cin] (written) and, if db != NULL, db[Cout] = sum over pixels of dy      */
 typedef struct {
     int B, Hs, Ws, Cin, Cout, stride, pad_t, pad_l, ups; /* Ho/Wo derived by the callee         */
     int Ho, Wo;
@@ -230,6 +232,7 @@ typedef struct {
     float* dw;
     void* workspace; size_t workspace_bytes;
     int mode;                                   /* bd_compute_mode */
+    float* db;                                  /* optional [Cout]: bias gradient sum_pixels dy, fused  */
 } bd_conv3x3_wgrad_desc;
 int bd_conv3x3_wgrad(const bd_conv3x3_wgrad_desc* d, bd_stream_t stream);
 size_t bd_conv3x3_workspace_bytes(int B, int Ho, int Wo, int Hs, int Ws, int Cin, int Cout, int ups);

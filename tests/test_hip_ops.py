@@ -234,7 +234,12 @@ def test_conv3x3(ops, B, H, Cin, Cout, stride, pad, ups, asym):
     if ups:
         dx = ops.sum2x2(dx)
     close(dx.permute(0, 3, 1, 2), xr.grad, 2e-4, 2e-4)
-    dw = ops.conv3x3_wgrad(xn, dyn, stride, pad, ups, asym)
+    fused = Cout % 4 == 0     # bias gradient in the same launch (sum of dy over pixels)
+    dw = ops.conv3x3_wgrad(xn, dyn, stride, pad, ups, asym, with_db=fused)
+    if fused:
+        dw, db = dw
+        ref_db = dy.double().sum((0, 2, 3)).float()
+        close(db, ref_db, 2e-5, 2e-5 * max(1.0, float(ref_db.abs().max())))
     close(dw.permute(0, 3, 1, 2), wr.grad, 2e-4, 2e-4 * max(1.0, float(wr.grad.abs().max())))
 
 
@@ -332,5 +337,30 @@ def test_conv3x3_bf16x3(ops, B, H, Cin, Cout, stride, pad, ups, asym):
     if ups:
         dx = ops.sum2x2(dx)
     close(dx.permute(0, 3, 1, 2), xr.grad, 3e-4, 3e-4)
-    dw = ops.conv3x3_wgrad(xn, dyn, stride, pad, ups, asym, mode=1)
+    fused = Cout % 4 == 0
+    dw = ops.conv3x3_wgrad(xn, dyn, stride, pad, ups, asym, mode=1, with_db=fused)
+    if fused:   # the fused bias gradient is summed in fp32 from the unsplit values in both modes
+        dw, db = dw
+        ref_db = dy.double().sum((0, 2, 3)).float()
+        close(db, ref_db, 2e-5, 2e-5 * max(1.0, float(ref_db.abs().max())))
     close(dw.permute(0, 3, 1, 2), wr.grad, 3e-4, 3e-4 * max(1.0, float(wr.grad.abs().max())))
+
+
+@pytest.mark.parametrize("mode", [0, 1])
+@pytest.mark.parametrize("M,N,K,ksplit", [(128, 256, 4096, 0), (384, 128, 512, 1), (64, 64, 96, 1), (132, 72, 1000, 0), (256, 1152, 131072, 0)])
+def test_gemm_fused_colsum(ops, M, N, K, ksplit, mode):
+    """dW = dY^T X with db = column sums of dY out of the same launch (with and without split-K)"""
+    a = R(1, K, M); b = R(2, K, N)
+    cs = torch.full((M,), float("nan"), device="cuda")
+    c = ops.gemm(dev(a), dev(b), True, False, ksplit=ksplit, mode=mode, a_colsum=cs).cpu().double()
+    ref = a.double().t() @ b.double()
+    assert float((c - ref).abs().max()) / float(ref.abs().mean()) < 2e-4
+    ref_cs = a.double().sum(0)
+    # fp32 summation: a few ulps of the column's L1 norm
+    assert float((cs.cpu().double() - ref_cs).abs().max()) < 3e-7 * float(a.double().abs().sum(0).max())
+
+
+def test_gemm_fused_colsum_rejects_kc(ops):
+    a = R(1, 64, 128); b = R(2, 64, 128)
+    with pytest.raises(RuntimeError, match="a_colsum"):
+        ops.gemm(dev(a), dev(b), False, True, a_colsum=torch.empty(64, device="cuda"))
