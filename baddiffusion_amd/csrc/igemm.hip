@@ -19,6 +19,7 @@
 // conv_out (Cout = 3), odd GEMM sizes.  Replaces aten::convolution(_backward), addmm/mm/bmm/baddbmm
 // of the reference's UNet.
 #include "common.h"
+#include <cstdlib>
 
 namespace bd {
 
@@ -79,6 +80,17 @@ __device__ __forceinline__ int krow(int tid) {
 
 __device__ __forceinline__ float4 ld4(const float* p) { return *reinterpret_cast<const float4*>(p); }
 __device__ __forceinline__ float4 zero4() { return make_float4(0.f, 0.f, 0.f, 0.f); }
+// predicated 16-byte load without control flow and without a dependent select: masked-off lanes read 16 zero bytes
+// that live in the code object.  Branch-free loads keep the s_waitcnt vmcnt() counting exact, and nothing touches the
+// loaded registers until the split, which the two-chunk-deep register prefetch of the kernels depends on (a skipped
+// load would force vmcnt(0) at the join, a select would wait for the load right behind its issue).
+__device__ __attribute__((aligned(16))) const float kZero16[4] = {0.f, 0.f, 0.f, 0.f};
+typedef float v4f __attribute__((ext_vector_type(4)));
+typedef const v4f __attribute__((address_space(1))) * gptr4;   // global address space: global_load, not flat_load
+__device__ __forceinline__ float4 ld4_if(const float* p, bool ok, const float*) {
+    const v4f t = *(gptr4)(ok ? p : kZero16);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
 
 // pixel index -> (b, y, x) over an (Ho, Wo) grid
 __device__ __forceinline__ void decode_pixel(const Opnd& o, int pix, int& b, int& y, int& x) {
@@ -206,9 +218,9 @@ struct DenseKC : KCStore<R> {
             ptr[i] = o.p + (long long)r * o.ld + kbase + k4;
         }
     }
-    __device__ __forceinline__ void load(const Opnd&, float4 (&v)[NI]) const {
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) v[i] = (ok[i] && krem > 0) ? ld4(ptr[i]) : zero4();
+        for (int i = 0; i < NI; ++i) v[i] = ld4_if(ptr[i], ok[i] && krem > 0, o.p);
     }
     __device__ __forceinline__ void advance(const Opnd&) {
         krem -= BK;
@@ -249,7 +261,7 @@ struct ConvKC : KCStore<R> {
             const int ys = y0[i] + kh, xs = x0[i] + kw;
             const bool okk = (unsigned)ys < (unsigned)He && (unsigned)xs < (unsigned)We && c0 < o.C;
             const int off = ((ys >> o.ups) * o.Ws + (xs >> o.ups)) * (int)o.ld + c0;
-            v[i] = okk ? ld4(base[i] + off) : zero4();
+            v[i] = ld4_if(base[i] + off, okk, o.p);
         }
     }
     __device__ __forceinline__ void advance(const Opnd&) {
@@ -283,7 +295,7 @@ struct WgtKC : KCStore<R> {
     __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
         const int off = tap * o.C + c0;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) v[i] = (ok[i] && c0 < o.C) ? ld4(ptr[i] + off) : zero4();
+        for (int i = 0; i < NI; ++i) v[i] = ld4_if(ptr[i] + off, ok[i] && c0 < o.C, o.p);
     }
     __device__ __forceinline__ void advance(const Opnd&) {
         if (++tap == 9) { tap = 0; c0 += BK; }
@@ -323,7 +335,7 @@ struct TConvKC : KCStore<R> {
             const int ys = yn >> sh, xs = xn >> sh;
             const bool okk = yn >= 0 && xn >= 0 && ((yn | xn) & sh) == 0 && ys < o.Hs && xs < o.Ws && c0 < o.C;
             const int off = (ys * o.Ws + xs) * (int)o.ld + c0;
-            v[i] = okk ? ld4(base[i] + off) : zero4();
+            v[i] = ld4_if(base[i] + off, okk, o.p);
         }
     }
     __device__ __forceinline__ void advance(const Opnd&) {
@@ -350,9 +362,9 @@ struct DenseRC : RCStore<R, TR> {
         step = (long long)KS * o.ld;
         krem = K - kbase - k0;
     }
-    __device__ __forceinline__ void load(const Opnd&, float4 (&v)[NI]) const {
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
 #pragma unroll
-        for (int i = 0; i < NI; ++i) v[i] = (ok && krem > KS * i) ? ld4(ptr + step * i) : zero4();
+        for (int i = 0; i < NI; ++i) v[i] = ld4_if(ptr + step * i, ok && krem > KS * i, o.p);
     }
     __device__ __forceinline__ void advance(const Opnd& o) {
         ptr += (long long)BK * o.ld;
@@ -382,7 +394,7 @@ struct WgtRC : RCStore<R, TR> {
     __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
         const float* q = ptr + ((long long)c0 * 9 + tap) * o.ld;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) v[i] = (ok && c0 < o.C) ? ld4(q + step * i) : zero4();
+        for (int i = 0; i < NI; ++i) v[i] = ld4_if(q + step * i, ok && c0 < o.C, o.p);
     }
     __device__ __forceinline__ void advance(const Opnd&) {
         if (++tap == 9) { tap = 0; c0 += BK; }
@@ -418,7 +430,7 @@ struct ConvRC : RCStore<R, TR> {
             const int ys = y * o.stride - o.pad_t + kh, xs = x * o.stride - o.pad_l + kw;
             const bool okk = ok && p < Kp && (unsigned)ys < (unsigned)He && (unsigned)xs < (unsigned)We;
             const long long off = ((long long)b * o.Hs * o.Ws + (ys >> o.ups) * o.Ws + (xs >> o.ups)) * o.ld + ci;
-            v[i] = okk ? ld4(o.p + off) : zero4();
+            v[i] = ld4_if(o.p + off, okk, o.p);
         }
     }
     __device__ __forceinline__ void advance(const Opnd&) { pix += BK; }
@@ -745,7 +757,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 // hi + lo bf16 planes ([rows][32 + 8] bf16 each, RC operands transposed in registers on the way), and the
 // K loop issues hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) from ds_read_b128 fragments.
 template <int BM, int BN, class LA, class LB>
-__global__ __launch_bounds__(256, 3) void igemm_bf16x3_kernel(IGemmParams p) {
+__global__ __launch_bounds__(256, 2) void igemm_bf16x3_kernel(IGemmParams p) {
     constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr bool A_KC = LA::kKC, B_KC = LB::kKC;
     constexpr int A_SZ = A_KC ? BM * LDH : BK * (BM + 32), B_SZ = B_KC ? BN * LDH : BK * (BN + 32);
@@ -786,27 +798,31 @@ __global__ __launch_bounds__(256, 3) void igemm_bf16x3_kernel(IGemmParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    float4 ra[BM / 32], rb[BN / 32];
-    if (c_begin < c_end) {
-        la.load(A, ra);
-        lb.load(B, rb);
-    }
+    // Register prefetch two chunks deep: ra0/rb0 hold chunk c, ra1/rb1 chunk c+1; after a pair has been split into LDS it
+    // is refilled with chunk c+2, whose loads then have two MFMA sections to land.  The loads are unconditional
+    // (predicated by address, ld4_if) and there is no branch in the loop body, so the compiler waits with exact
+    // vmcnt(N) instead of vmcnt(0).  Chunks past c_end are loaded and never used (in-range addresses or masked off).
+    float4 ra0[BM / 32], rb0[BN / 32], ra1[BM / 32], rb1[BN / 32];
+    la.load(A, ra0);
+    lb.load(B, rb0);
+    la.advance(A);
+    lb.advance(B);
+    la.load(A, ra1);
+    lb.load(B, rb1);
     const bool do_cs = !A_KC && p.a_colsum != nullptr && wg.tn == 0;
     float4 cs = zero4();
-    for (int c = c_begin; c < c_end; ++c) {
+    auto step = [&](float4 (&ua)[BM / 32], float4 (&ub)[BN / 32]) {
         if (do_cs) {
 #pragma unroll
-            for (int i = 0; i < BM / 32; ++i) add4(cs, ra[i]);
+            for (int i = 0; i < BM / 32; ++i) add4(cs, ua[i]);
         }
-        LA::store_split(sAh, sAl, tid, ra);
-        LB::store_split(sBh, sBl, tid, rb);
+        LA::store_split(sAh, sAl, tid, ua);
+        LB::store_split(sBh, sBl, tid, ub);
         __syncthreads();
-        if (c + 1 < c_end) {
-            la.advance(A);
-            lb.advance(B);
-            la.load(A, ra);
-            lb.load(B, rb);
-        }
+        la.advance(A);
+        lb.advance(B);
+        la.load(A, ua);
+        lb.load(B, ub);
 #pragma unroll
         for (int s = 0; s < BK / 16; ++s) {
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -846,7 +862,13 @@ __global__ __launch_bounds__(256, 3) void igemm_bf16x3_kernel(IGemmParams p) {
                 for (int q = 0; q < TN; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
         }
         __syncthreads();
+    };
+    int c = c_begin;
+    for (; c + 1 < c_end; c += 2) {
+        step(ra0, rb0);
+        step(ra1, rb1);
     }
+    if (c < c_end) step(ra0, rb0);
     if (do_cs) colsum_tail<BM>(p, reinterpret_cast<float*>(sAh), cs, tid, m0, wg.zz);
     epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi, wg.zz);
 }
@@ -952,7 +974,8 @@ static Choice choose(const bd_igemm_desc& d) {
     Choice c;
     const int nb = d.batch_outer * d.batch_inner;
     auto tiles = [&](int t) { return cdiv(d.M, t) * cdiv(d.N, t) * nb; };
-    // 128x128 tiles (32 flop per staged byte) whenever both dims allow; split K to put >= ~1.5 workgroups on each CU
+    // 128x128 tiles (32 flop per staged byte) whenever both dims allow; split K to put ~1.5 workgroups on each CU
+    // (measured sweep of the target 256..640: 384 is the optimum for the CIFAR UNet step, more splits cost partial traffic)
     c.tile = d.tile ? d.tile : ((d.M >= 128 && d.N >= 128) ? 128 : 64);
     const int nchunks = (int)cdiv(d.K, BK);
     int ks = d.ksplit;
