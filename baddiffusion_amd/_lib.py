@@ -50,7 +50,8 @@ class GnBwdDesc(C.Structure):
     _fields_ = [("B", i32), ("HW", i32), ("C", i32), ("G", i32), ("silu", i32),
                 ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp),
                 ("dy", vp), ("lddy", i64), ("dx", vp), ("lddx", i64), ("accumulate_dx", i32),
-                ("dgamma", vp), ("dbeta", vp), ("workspace", vp), ("workspace_bytes", sz)]
+                ("dgamma", vp), ("dbeta", vp), ("workspace", vp), ("workspace_bytes", sz),
+                ("dx_colsum", vp), ("ld_colsum", i64)]
 
 
 class Operand(C.Structure):

@@ -6,6 +6,12 @@
 // groups afterwards.  Reductions are two-stage and fixed-order (deterministic): per-(sample, split)
 // partials -> tiny finalize.  HBM-bound: stats pass reads x once, apply pass reads x + writes y.
 //
+// RESIDENT variants (gn_fwd_res / gn_bwd_res): when HW x (a block of whole groups) fits the register file of one
+// workgroup (<= 16 float4 per thread and tensor -- every layer of the 32x32 UNet), one workgroup owns a
+// (sample, channel block) slab: it reads x (and dy) ONCE, reduces inside the workgroup (LDS, fixed order), and
+// applies from registers.  One launch and 2 (fwd) / 3 (bwd) tensor passes instead of 2 launches + 3 passes /
+// 3 launches + 5 passes.  Larger images (CelebA-HQ 256^2) keep the split two-stage kernels below.
+//
 // Replaces aten::native_group_norm / native_group_norm_backward / silu / silu_backward
 // (resnet.py:559,591; attention.py:125; unet_2d.py:312-313).
 #include "common.h"
@@ -253,6 +259,229 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// =====================================================================================================================
+// RESIDENT single-pass kernels: one workgroup = one (sample, cb-channel block), data held in registers
+// =====================================================================================================================
+constexpr int GN_RES_EMAX = 16;   // float4 per thread per tensor
+
+struct GnRes {
+    int cb, q, R, E, nblk;   // channels per block, float4 per pixel row, pixel rows in flight, float4 per thread, blocks
+};
+static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
+// the widest channel block (whole groups, float4-aligned) whose slab fits; then narrower (>= 64 B rows) while the
+// grid would leave CUs idle
+static bool gn_resident_plan(int B, int HW, int C, int G, GnRes& o) {
+    const int cpg = C / G;
+    const int unit = cpg / gcd_i(cpg, 4) * 4;
+    int best = 0;
+    for (int cb = unit; cb <= C; cb += unit) {
+        if (C % cb) continue;
+        const int q = cb / 4;
+        if (q > 256) break;
+        if (cdiv(HW, 256 / q) <= GN_RES_EMAX) best = cb;
+    }
+    if (!best || (best < 16 && best < C)) return false;   // rows narrower than 64 B: the split kernels coalesce better
+    while ((long long)B * (C / best) < 512) {
+        const int half = best / 2;
+        if (half < 16 || half % unit || C % half) break;
+        best = half;
+    }
+    o.cb = best; o.q = best / 4; o.R = 256 / o.q; o.E = (int)cdiv(HW, o.R); o.nblk = C / best;
+    return true;
+}
+
+template <int EMAX>
+__global__ __launch_bounds__(256) void gn_fwd_res_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
+                                                       long long ldy, int HW, int C, int G, int cb, int q, int R, int E,
+                                                       float eps, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float* __restrict__ mean,
+                                                       float* __restrict__ rstd, int silu) {
+    __shared__ float sh[2 * 1024];   // [R][cb][2], R*cb <= 1024
+    __shared__ float st[2 * 256];    // per group of the block: mean, rstd
+    const int t = threadIdx.x;
+    const int cq = t % q, prow = t / q;
+    const bool active = prow < R;
+    const int b = blockIdx.y, c0 = blockIdx.x * cb;
+    const int cpg = C / G, ng = cb / cpg;
+    const float* xb = x + (long long)b * HW * ldx + c0 + cq * 4;
+    float4 v[EMAX];
+    float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        const int p = prow + R * i;
+        const bool ok = active && i < E && p < HW;
+        v[i] = ok ? *reinterpret_cast<const float4*>(xb + (long long)p * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        sm[0] += v[i].x; sm[1] += v[i].y; sm[2] += v[i].z; sm[3] += v[i].w;
+        sq[0] += v[i].x * v[i].x; sq[1] += v[i].y * v[i].y; sq[2] += v[i].z * v[i].z; sq[3] += v[i].w * v[i].w;
+    }
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            sh[(prow * cb + cq * 4 + j) * 2 + 0] = sm[j];
+            sh[(prow * cb + cq * 4 + j) * 2 + 1] = sq[j];
+        }
+    }
+    __syncthreads();
+    if (t < ng) {
+        double a = 0.0, c2 = 0.0;
+        for (int pr = 0; pr < R; ++pr)
+            for (int c = t * cpg; c < (t + 1) * cpg; ++c) {
+                a += (double)sh[(pr * cb + c) * 2 + 0];
+                c2 += (double)sh[(pr * cb + c) * 2 + 1];
+            }
+        const double n = (double)HW * cpg;
+        const double mu = a / n;
+        double var = c2 / n - mu * mu;
+        if (var < 0.0) var = 0.0;
+        const float m = (float)mu, r = (float)(1.0 / sqrt(var + (double)eps));
+        st[2 * t] = m; st[2 * t + 1] = r;
+        const int g = c0 / cpg + t;
+        mean[b * G + g] = m; rstd[b * G + g] = r;
+    }
+    __syncthreads();
+    if (!active) return;
+    float mu[4], rs[4], gg[4], bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int lc = cq * 4 + j;
+        mu[j] = st[2 * (lc / cpg)]; rs[j] = st[2 * (lc / cpg) + 1];
+        gg[j] = gamma[c0 + lc]; bb[j] = beta[c0 + lc];
+    }
+    float* yb = y + (long long)b * HW * ldy + c0 + cq * 4;
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        const int p = prow + R * i;
+        if (i < E && p < HW) {
+            const float in[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = (in[j] - mu[j]) * rs[j] * gg[j] + bb[j];
+                o[j] = silu ? silu_dev(z) : z;
+            }
+            *reinterpret_cast<float4*>(yb + (long long)p * ldy) = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
+// backward: dx (+)= rstd * (dz*gamma - (s1 + xhat*s2)/n); per-sample per-channel (sum dz*xhat, sum dz) rows go to
+// `part` ([B][2][C], reduced over B by gn_bwd_param_kernel); optional dx_colsum[b][c] = sum over pixels of this
+// launch's dx term in closed form: rstd * (gamma*sum dz - (HW*s1 + s2*sum xhat)/n)   (time-embedding gradient)
+template <int EMAX>
+__global__ __launch_bounds__(256) void gn_bwd_res_kernel(const float* __restrict__ x, long long ldx,
+                                                       const float* __restrict__ dy, long long lddy, float* __restrict__ dx,
+                                                       long long lddx, int HW, int C, int G, int cb, int q, int R, int E,
+                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                       int silu, int acc, float* __restrict__ part,
+                                                       float* __restrict__ dx_colsum, long long ld_colsum) {
+    __shared__ float sh[3 * 1024];   // [R][cb][3]: sum dz, sum dz*xhat, sum xhat
+    __shared__ float ch[3 * 1024];   // [cb][3] channel totals (cb <= 1024)
+    __shared__ float sg[2 * 256];    // per group: s1, s2
+    const int t = threadIdx.x;
+    const int cq = t % q, prow = t / q;
+    const bool active = prow < R;
+    const int b = blockIdx.y, c0 = blockIdx.x * cb;
+    const int cpg = C / G, ng = cb / cpg;
+    const float inv_n = 1.0f / ((float)HW * cpg);
+    float mu[4], rs[4], gg[4], bb[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int c = c0 + (active ? cq * 4 + j : 0);
+        mu[j] = mean[b * G + c / cpg]; rs[j] = rstd[b * G + c / cpg];
+        gg[j] = gamma[c]; bb[j] = beta[c];
+    }
+    const float* xb = x + (long long)b * HW * ldx + c0 + cq * 4;
+    const float* db = dy + (long long)b * HW * lddy + c0 + cq * 4;
+    float4 xh[EMAX], dz[EMAX];
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        const int p = prow + R * i;
+        const bool ok = active && i < E && p < HW;
+        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+        xh[i] = ok ? *reinterpret_cast<const float4*>(xb + (long long)p * ldx) : z4;
+        dz[i] = ok ? *reinterpret_cast<const float4*>(db + (long long)p * lddy) : z4;
+    }
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        const int p = prow + R * i;
+        const bool ok = active && i < E && p < HW;
+        float in[4] = {xh[i].x, xh[i].y, xh[i].z, xh[i].w}, dd[4] = {dz[i].x, dz[i].y, dz[i].z, dz[i].w};
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float h = ok ? (in[j] - mu[j]) * rs[j] : 0.f;
+            float d = dd[j];
+            if (silu) d *= silu_grad_dev(h * gg[j] + bb[j]);
+            in[j] = h; dd[j] = d;
+            s0[j] += d; s1[j] += d * h; s2[j] += h;
+        }
+        xh[i] = make_float4(in[0], in[1], in[2], in[3]);
+        dz[i] = make_float4(dd[0], dd[1], dd[2], dd[3]);
+    }
+    if (active) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            float* o = sh + (prow * cb + cq * 4 + j) * 3;
+            o[0] = s0[j]; o[1] = s1[j]; o[2] = s2[j];
+        }
+    }
+    __syncthreads();
+    for (int c = t; c < cb; c += 256) {
+        float a = 0.f, e = 0.f, h = 0.f;
+        for (int pr = 0; pr < R; ++pr) {
+            const float* o = sh + (pr * cb + c) * 3;
+            a += o[0]; e += o[1]; h += o[2];
+        }
+        ch[3 * c] = a; ch[3 * c + 1] = e; ch[3 * c + 2] = h;
+        float* o = part + (long long)b * 2 * C + c0 + c;
+        o[0] = e;   // plane 0: sum dz * xhat -> dgamma
+        o[C] = a;   // plane 1: sum dz        -> dbeta
+    }
+    __syncthreads();
+    if (t < ng) {
+        double a = 0.0, e = 0.0;
+        for (int c = t * cpg; c < (t + 1) * cpg; ++c) {
+            a += (double)ch[3 * c] * gamma[c0 + c];
+            e += (double)ch[3 * c + 1] * gamma[c0 + c];
+        }
+        sg[2 * t] = (float)a; sg[2 * t + 1] = (float)e;
+    }
+    __syncthreads();
+    if (dx_colsum) {
+        for (int c = t; c < cb; c += 256) {
+            const int g = c / cpg;
+            const float r = rstd[b * G + (c0 + c) / cpg];
+            dx_colsum[(long long)b * ld_colsum + c0 + c] =
+                r * (gamma[c0 + c] * ch[3 * c] - ((float)HW * sg[2 * g] + sg[2 * g + 1] * ch[3 * c + 2]) * inv_n);
+        }
+    }
+    if (!active) return;
+    float g1[4], g2[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int g = (cq * 4 + j) / cpg;
+        g1[j] = sg[2 * g]; g2[j] = sg[2 * g + 1];
+    }
+    float* ob = dx + (long long)b * HW * lddx + c0 + cq * 4;
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        const int p = prow + R * i;
+        if (i < E && p < HW) {
+            const float h[4] = {xh[i].x, xh[i].y, xh[i].z, xh[i].w}, d[4] = {dz[i].x, dz[i].y, dz[i].z, dz[i].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = rs[j] * (d[j] * gg[j] - (g1[j] + h[j] * g2[j]) * inv_n);
+            float4* dst = reinterpret_cast<float4*>(ob + (long long)p * lddx);
+            if (acc) {
+                const float4 e = *dst;
+                o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
+            }
+            *dst = make_float4(o[0], o[1], o[2], o[3]);
+        }
+    }
+}
+
 static int gn_common_checks(const char* who, int B, int HW, int C, int G, const void* x, long long ldx) {
     BD_CHECK(B > 0 && HW > 0 && C > 0 && G > 0, BD_ERR_INVALID, "%s: bad shape", who);
     BD_CHECK(C % G == 0, BD_ERR_INVALID, "%s: C=%d not divisible by G=%d", who, C, G);
@@ -280,6 +509,19 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
     BD_CHECK(d->gamma && d->beta && d->y && d->mean && d->rstd && d->workspace, BD_ERR_INVALID, "bd_gn_fwd: null pointer");
     BD_CHECK((d->ldy & 3) == 0 && aligned16(d->y) && aligned16(d->gamma) && aligned16(d->beta), BD_ERR_UNSUPPORTED,
              "bd_gn_fwd: y/gamma/beta must be 16B aligned, ldy multiple of 4");
+    GnRes rp;
+    if (gn_resident_plan(d->B, d->HW, d->C, d->G, rp)) {
+        const dim3 grid((unsigned)rp.nblk, (unsigned)d->B);
+        if (rp.E <= 4)
+            hipLaunchKernelGGL(gn_fwd_res_kernel<4>, grid, dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->y, (long long)d->ldy,
+                               d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->eps, d->gamma, d->beta, d->mean, d->rstd, d->silu);
+        else
+            hipLaunchKernelGGL(gn_fwd_res_kernel<GN_RES_EMAX>, grid, dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->y,
+                               (long long)d->ldy, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->eps, d->gamma, d->beta, d->mean,
+                               d->rstd, d->silu);
+        BD_LAUNCH_CHECK("gn_fwd_res");
+        return BD_OK;
+    }
     const int S_ = gn_splits(d->B, d->HW);
     const size_t need = (size_t)d->B * S_ * d->G * 2 * sizeof(double);
     BD_CHECK(d->workspace_bytes >= need, BD_ERR_WORKSPACE, "bd_gn_fwd: workspace %zu < %zu", d->workspace_bytes, need);
@@ -309,6 +551,29 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
              BD_ERR_INVALID, "bd_gn_bwd: null pointer");
     BD_CHECK((d->lddy & 3) == 0 && (d->lddx & 3) == 0 && aligned16(d->dy) && aligned16(d->dx) && aligned16(d->gamma) &&
                  aligned16(d->beta), BD_ERR_UNSUPPORTED, "bd_gn_bwd: pointers must be 16B aligned, ld multiples of 4");
+    BD_CHECK(!(d->dx_colsum && d->accumulate_dx), BD_ERR_INVALID, "bd_gn_bwd: dx_colsum is the column sum of the written dx");
+    GnRes rp;
+    if (gn_resident_plan(d->B, d->HW, d->C, d->G, rp)) {
+        const size_t need_r = (size_t)d->B * d->C * 2 * sizeof(float);
+        BD_CHECK(d->workspace_bytes >= need_r, BD_ERR_WORKSPACE, "bd_gn_bwd: workspace %zu < %zu", d->workspace_bytes, need_r);
+        float* part_r = reinterpret_cast<float*>(d->workspace);
+        const dim3 grid((unsigned)rp.nblk, (unsigned)d->B);
+        if (rp.E <= 4)
+            hipLaunchKernelGGL(gn_bwd_res_kernel<4>, grid, dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->dy,
+                               (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->gamma,
+                               d->beta, d->mean, d->rstd, d->silu, d->accumulate_dx, part_r, d->dx_colsum,
+                               (long long)d->ld_colsum);
+        else
+            hipLaunchKernelGGL(gn_bwd_res_kernel<GN_RES_EMAX>, grid, dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->dy,
+                               (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->gamma,
+                               d->beta, d->mean, d->rstd, d->silu, d->accumulate_dx, part_r, d->dx_colsum,
+                               (long long)d->ld_colsum);
+        BD_LAUNCH_CHECK("gn_bwd_res");
+        hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(1024), 0, S(stream), part_r, d->B, d->C,
+                           d->dgamma, d->dbeta);
+        BD_LAUNCH_CHECK("gn_bwd_param");
+        return BD_OK;
+    }
     const int S_ = gn_splits(d->B, d->HW);
     const size_t part_bytes = align_up((size_t)d->B * S_ * d->C * 2 * sizeof(float), 256);
     const size_t need = part_bytes + (size_t)d->B * d->G * 2 * sizeof(float);
@@ -334,5 +599,7 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
                            d->gamma, d->beta, d->mean, d->rstd, 1.0f / ((float)d->HW * (d->C / d->G)), d->silu, d->accumulate_dx);
     }
     BD_LAUNCH_CHECK("gn_bwd_apply");
+    if (d->dx_colsum)   // split path: per-sample column sums of the dx just written
+        BD_TRY(bd_colsum(d->dx, d->lddx, (int64_t)d->B * d->HW, d->C, d->HW, d->dx_colsum, d->ld_colsum, 0, stream));
     return BD_OK;
 }

@@ -390,11 +390,10 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             d.dy = BP(c, b_da2); d.lddy = Cout; d.dx = BP(c, b_dh1); d.lddx = Cout; d.accumulate_dx = 0;
             d.dgamma = c.grads + pn2w; d.dbeta = c.grads + pn2b;
             d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+            // time-embedding gradient = per-sample column sums of dh1, out of the same launch
+            d.dx_colsum = BP(c, b_dtproj) + toff; d.ld_colsum = sumC_;
             if (!c.dry) BD_TRY(bd_gn_bwd(&d, (bd_stream_t)c.st));
         }
-        // time-embedding gradient (per-sample column sums of dh1) and conv1 bias gradient
-        float* dtp = BP(c, b_dtproj) + toff;
-        BD_TRY(colsum(c, BP(c, b_dh1), Cout, M, Cout, HW, dtp, sumC_));
         bd_conv3x3_wgrad_desc w1 = {};
         w1.B = c.B; w1.Hs = H; w1.Ws = W; w1.Cin = Cin; w1.Cout = Cout; w1.stride = 1; w1.pad_t = 1; w1.pad_l = 1; w1.Ho = H; w1.Wo = W;
         w1.x = BP(c, b_a1); w1.ldx = Cin; w1.dy = BP(c, b_dh1); w1.lddy = Cout; w1.dw = c.grads + pc1w; w1.db = c.grads + pc1b;

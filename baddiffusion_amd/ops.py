@@ -177,7 +177,8 @@ def gn_fwd(x, gamma, beta, G, eps, silu):
     return y, stats[0], stats[1]
 
 
-def gn_bwd(x, gamma, beta, mean, rstd, dy, G, silu, dx=None, accumulate=False):
+def gn_bwd(x, gamma, beta, mean, rstd, dy, G, silu, dx=None, accumulate=False, with_colsum=False):
+    """Returns (dx, dgamma, dbeta) and, with_colsum, the per-sample sum over pixels of dx [B, C]."""
     lib = L.load(); _need_cuda(x, gamma, beta, mean, rstd, dy)
     B, HW, Cc = x.shape
     if dx is None:
@@ -188,8 +189,10 @@ def gn_bwd(x, gamma, beta, mean, rstd, dy, G, silu, dx=None, accumulate=False):
                     mean=L.ptr(mean), rstd=L.ptr(rstd), dy=L.ptr(dy), lddy=_ld(dy), dx=L.ptr(dx), lddx=_ld(dx),
                     accumulate_dx=int(accumulate), dgamma=L.ptr(dg), dbeta=L.ptr(db), workspace=L.ptr(ws),
                     workspace_bytes=ws.numel())
+    cs = torch.empty(B, Cc, device=x.device) if with_colsum else None
+    d.dx_colsum = L.ptr(cs); d.ld_colsum = Cc
     L.check(lib.bd_gn_bwd(C.byref(d), L.stream()), "bd_gn_bwd")
-    return dx, dg, db
+    return (dx, dg, db, cs) if with_colsum else (dx, dg, db)
 
 
 # ------------------------------------------------------------------------------------------------ igemm family

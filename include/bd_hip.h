@@ -144,6 +144,9 @@ typedef struct {
     float* dx; int64_t lddx; int accumulate_dx;  /* dx (+)= ...                                */
     float* dgamma; float* dbeta;            /* [C], written (not accumulated)                  */
     void* workspace; size_t workspace_bytes;
+    float* dx_colsum; int64_t ld_colsum;    /* optional [B, C] (row stride ld_colsum): per-sample sum
+                                               over pixels of the written dx (needs accumulate_dx=0);
+                                               the time-embedding gradient of resnet.py:571            */
 } bd_gn_bwd_desc;
 int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream);
 

@@ -147,8 +147,10 @@ def test_timestep_embedding(ops, golden):
 
 
 # ------------------------------------------------------------------------------------------ GroupNorm
+# resident single-pass kernels (slab in registers): all but the 4096-pixel cases, which take the split two-stage path
 @pytest.mark.parametrize("B,HW,Cc,silu", [(3, 64, 128, True), (2, 256, 384, True), (2, 16, 512, False), (5, 1024, 256, True),
-                                          (130, 16, 128, True)])
+                                          (130, 16, 128, True), (2, 1024, 128, True), (3, 900, 128, False), (2, 4096, 128, True),
+                                          (2, 4096, 64, False), (2, 1024, 384, True)])
 def test_groupnorm_fwd_bwd(ops, B, HW, Cc, silu):
     x = R(1, B, HW, Cc) * 1.7 + 0.3
     gam = 1 + 0.1 * R(2, Cc); bet = 0.1 * R(3, Cc); dy = R(4, B, HW, Cc)
@@ -160,8 +162,10 @@ def test_groupnorm_fwd_bwd(ops, B, HW, Cc, silu):
     y_ref.backward(dy)
     y, mean, rstd = ops.gn_fwd(dev(x), dev(gam), dev(bet), 32, 1e-6, silu)
     close(y, y_ref, 1e-4, 1e-5)
-    dx, dg, db = ops.gn_bwd(dev(x), dev(gam), dev(bet), mean, rstd, dev(dy), 32, silu)
+    dx, dg, db, cs = ops.gn_bwd(dev(x), dev(gam), dev(bet), mean, rstd, dev(dy), 32, silu, with_colsum=True)
     close(dx, xr.grad, 1e-3, 2e-5)
+    ref_cs = xr.grad.double().sum(1)            # per-sample column sums of dx (time-embedding gradient)
+    close(cs, ref_cs.float(), 1e-3, 1e-5 * HW ** 0.5 * max(1.0, float(xr.grad.abs().max())))
     close(dg, gr.grad, 1e-3, 1e-3 * float(gr.grad.abs().max()))
     close(db, br.grad, 1e-3, 1e-3 * float(br.grad.abs().max()))
     # strided (channel-slice) input + accumulate
