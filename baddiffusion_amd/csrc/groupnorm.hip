@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
 constexpr int GN_RES_EMAX = 16;   // float4 per thread per tensor
 
 struct GnRes {
-    int cb, q, R, E, nblk;   // channels per block, float4 per pixel row, pixel rows in flight, float4 per thread, blocks
+    int cb, q, R, E, nblk, nt;   // channels per block, float4 per pixel row, pixel rows in flight, float4 per thread, blocks, threads
 };
 static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 // the widest channel block (whole groups, float4-aligned) whose slab fits; then narrower (>= 64 B rows) while the
@@ -273,35 +273,55 @@ static int gcd_i(int a, int b) { return b ? gcd_i(b, a % b) : a; }
 static bool gn_resident_plan(int B, int HW, int C, int G, GnRes& o) {
     const int cpg = C / G;
     const int unit = cpg / gcd_i(cpg, 4) * 4;
-    int best = 0;
-    for (int cb = unit; cb <= C; cb += unit) {
-        if (C % cb) continue;
-        const int q = cb / 4;
-        if (q > 256) break;
-        if (cdiv(HW, 256 / q) <= GN_RES_EMAX) best = cb;
+    for (int nt = 256; nt <= 512; nt *= 2) {   // 512-thread workgroups only where 256 threads cannot hold 64-byte rows
+        int best = 0;
+        for (int cb = unit; cb <= C; cb += unit) {
+            if (C % cb) continue;
+            const int q = cb / 4;
+            if (q > nt) break;
+            if (cdiv(HW, nt / q) <= GN_RES_EMAX && cb / cpg <= 256) best = cb;
+        }
+        if (!best || (best < 16 && best < C)) continue;   // rows narrower than 64 B: the split kernels coalesce better
+        while ((long long)B * (C / best) < 512) {
+            const int half = best / 2;
+            if (half < 16 || half % unit || C % half) break;
+            best = half;
+        }
+        o.cb = best; o.q = best / 4; o.R = nt / o.q; o.E = (int)cdiv(HW, o.R); o.nblk = C / best; o.nt = nt;
+        return true;
     }
-    if (!best || (best < 16 && best < C)) return false;   // rows narrower than 64 B: the split kernels coalesce better
-    while ((long long)B * (C / best) < 512) {
-        const int half = best / 2;
-        if (half < 16 || half % unit || C % half) break;
-        best = half;
-    }
-    o.cb = best; o.q = best / 4; o.R = 256 / o.q; o.E = (int)cdiv(HW, o.R); o.nblk = C / best;
-    return true;
+    return false;
 }
 
-template <int EMAX>
-__global__ __launch_bounds__(256) void gn_fwd_res_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
+// 1-D grid over (sample, channel block), remapped so that each XCD (workgroup id % 8) owns a contiguous run with the
+// channel blocks of a sample adjacent: the 64-byte row pieces of neighbouring channel blocks share 128-byte lines, and
+// this way they meet in one L2 instead of being fetched by two XCDs.  Speed only.
+struct GnCoord {
+    int b, bx;
+};
+__device__ __forceinline__ GnCoord gn_res_coord(int nblk) {
+    const unsigned L = blockIdx.x, T = gridDim.x, qq = T >> 3;
+    unsigned j = (L & 7) * qq + (L >> 3);
+    if (L >= (qq << 3)) j = L;   // (an if, not a select: the ternary form trips a gfx950 backend assertion in this kernel)
+    GnCoord c;
+    c.b = (int)(j / (unsigned)nblk);
+    c.bx = (int)(j - (unsigned)c.b * (unsigned)nblk);
+    return c;
+}
+
+template <int EMAX, int NT>
+__global__ __launch_bounds__(NT) void gn_fwd_res_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
                                                        long long ldy, int HW, int C, int G, int cb, int q, int R, int E,
                                                        float eps, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ mean,
                                                        float* __restrict__ rstd, int silu) {
-    __shared__ float sh[2 * 1024];   // [R][cb][2], R*cb <= 1024
+    __shared__ float sh[2 * 4 * NT];   // [R][cb][2], R*cb <= 4*NT
     __shared__ float st[2 * 256];    // per group of the block: mean, rstd
     const int t = threadIdx.x;
     const int cq = t % q, prow = t / q;
     const bool active = prow < R;
-    const int b = blockIdx.y, c0 = blockIdx.x * cb;
+    const GnCoord wgc = gn_res_coord(C / cb);
+    const int b = wgc.b, c0 = wgc.bx * cb;
     const int cpg = C / G, ng = cb / cpg;
     const float* xb = x + (long long)b * HW * ldx + c0 + cq * 4;
     float4 v[EMAX];
@@ -367,21 +387,22 @@ __global__ __launch_bounds__(256) void gn_fwd_res_kernel(const float* __restrict
 // backward: dx (+)= rstd * (dz*gamma - (s1 + xhat*s2)/n); per-sample per-channel (sum dz*xhat, sum dz) rows go to
 // `part` ([B][2][C], reduced over B by gn_bwd_param_kernel); optional dx_colsum[b][c] = sum over pixels of this
 // launch's dx term in closed form: rstd * (gamma*sum dz - (HW*s1 + s2*sum xhat)/n)   (time-embedding gradient)
-template <int EMAX>
-__global__ __launch_bounds__(256) void gn_bwd_res_kernel(const float* __restrict__ x, long long ldx,
+template <int EMAX, int NT>
+__global__ __launch_bounds__(NT) void gn_bwd_res_kernel(const float* __restrict__ x, long long ldx,
                                                        const float* __restrict__ dy, long long lddy, float* __restrict__ dx,
                                                        long long lddx, int HW, int C, int G, int cb, int q, int R, int E,
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        int silu, int acc, float* __restrict__ part,
                                                        float* __restrict__ dx_colsum, long long ld_colsum) {
-    __shared__ float sh[3 * 1024];   // [R][cb][3]: sum dz, sum dz*xhat, sum xhat
-    __shared__ float ch[3 * 1024];   // [cb][3] channel totals (cb <= 1024)
+    __shared__ float sh[3 * 4 * NT];   // [R][cb][3]: sum dz, sum dz*xhat, sum xhat
+    __shared__ float ch[3 * 4 * NT];   // [cb][3] channel totals (cb <= 4*NT)
     __shared__ float sg[2 * 256];    // per group: s1, s2
     const int t = threadIdx.x;
     const int cq = t % q, prow = t / q;
     const bool active = prow < R;
-    const int b = blockIdx.y, c0 = blockIdx.x * cb;
+    const GnCoord wgc = gn_res_coord(C / cb);
+    const int b = wgc.b, c0 = wgc.bx * cb;
     const int cpg = C / G, ng = cb / cpg;
     const float inv_n = 1.0f / ((float)HW * cpg);
     float mu[4], rs[4], gg[4], bb[4];
@@ -427,7 +448,7 @@ __global__ __launch_bounds__(256) void gn_bwd_res_kernel(const float* __restrict
         }
     }
     __syncthreads();
-    for (int c = t; c < cb; c += 256) {
+    for (int c = t; c < cb; c += NT) {
         float a = 0.f, e = 0.f, h = 0.f;
         for (int pr = 0; pr < R; ++pr) {
             const float* o = sh + (pr * cb + c) * 3;
@@ -449,7 +470,7 @@ __global__ __launch_bounds__(256) void gn_bwd_res_kernel(const float* __restrict
     }
     __syncthreads();
     if (dx_colsum) {
-        for (int c = t; c < cb; c += 256) {
+        for (int c = t; c < cb; c += NT) {
             const int g = c / cpg;
             const float r = rstd[b * G + (c0 + c) / cpg];
             dx_colsum[(long long)b * ld_colsum + c0 + c] =
@@ -511,14 +532,15 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
              "bd_gn_fwd: y/gamma/beta must be 16B aligned, ldy multiple of 4");
     GnRes rp;
     if (gn_resident_plan(d->B, d->HW, d->C, d->G, rp)) {
-        const dim3 grid((unsigned)rp.nblk, (unsigned)d->B);
-        if (rp.E <= 4)
-            hipLaunchKernelGGL(gn_fwd_res_kernel<4>, grid, dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->y, (long long)d->ldy,
-                               d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->eps, d->gamma, d->beta, d->mean, d->rstd, d->silu);
-        else
-            hipLaunchKernelGGL(gn_fwd_res_kernel<GN_RES_EMAX>, grid, dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->y,
-                               (long long)d->ldy, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->eps, d->gamma, d->beta, d->mean,
-                               d->rstd, d->silu);
+        const dim3 grid((unsigned)rp.nblk * (unsigned)d->B);
+#define BD_GN_FWD_RES(EM, NT)                                                                                              \
+    hipLaunchKernelGGL((gn_fwd_res_kernel<EM, NT>), grid, dim3(NT), 0, S(stream), d->x, (long long)d->ldx, d->y,             \
+                       (long long)d->ldy, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->eps, d->gamma, d->beta, d->mean,       \
+                       d->rstd, d->silu)
+        if (rp.nt == 512) BD_GN_FWD_RES(GN_RES_EMAX, 512);
+        else if (rp.E <= 4) BD_GN_FWD_RES(4, 256);
+        else BD_GN_FWD_RES(GN_RES_EMAX, 256);
+#undef BD_GN_FWD_RES
         BD_LAUNCH_CHECK("gn_fwd_res");
         return BD_OK;
     }
@@ -557,17 +579,15 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
         const size_t need_r = (size_t)d->B * d->C * 2 * sizeof(float);
         BD_CHECK(d->workspace_bytes >= need_r, BD_ERR_WORKSPACE, "bd_gn_bwd: workspace %zu < %zu", d->workspace_bytes, need_r);
         float* part_r = reinterpret_cast<float*>(d->workspace);
-        const dim3 grid((unsigned)rp.nblk, (unsigned)d->B);
-        if (rp.E <= 4)
-            hipLaunchKernelGGL(gn_bwd_res_kernel<4>, grid, dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->dy,
-                               (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->gamma,
-                               d->beta, d->mean, d->rstd, d->silu, d->accumulate_dx, part_r, d->dx_colsum,
-                               (long long)d->ld_colsum);
-        else
-            hipLaunchKernelGGL(gn_bwd_res_kernel<GN_RES_EMAX>, grid, dim3(256), 0, S(stream), d->x, (long long)d->ldx, d->dy,
-                               (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->gamma,
-                               d->beta, d->mean, d->rstd, d->silu, d->accumulate_dx, part_r, d->dx_colsum,
-                               (long long)d->ld_colsum);
+        const dim3 grid((unsigned)rp.nblk * (unsigned)d->B);
+#define BD_GN_BWD_RES(EM, NT)                                                                                              \
+    hipLaunchKernelGGL((gn_bwd_res_kernel<EM, NT>), grid, dim3(NT), 0, S(stream), d->x, (long long)d->ldx, d->dy,            \
+                       (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->gamma,     \
+                       d->beta, d->mean, d->rstd, d->silu, d->accumulate_dx, part_r, d->dx_colsum, (long long)d->ld_colsum)
+        if (rp.nt == 512) BD_GN_BWD_RES(GN_RES_EMAX, 512);
+        else if (rp.E <= 4) BD_GN_BWD_RES(4, 256);
+        else BD_GN_BWD_RES(GN_RES_EMAX, 256);
+#undef BD_GN_BWD_RES
         BD_LAUNCH_CHECK("gn_bwd_res");
         hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(1024), 0, S(stream), part_r, d->B, d->C,
                            d->dgamma, d->dbeta);
