@@ -18,8 +18,12 @@
 
 namespace bd {
 
-constexpr int GN_MAX_SPLITS = 16;
+constexpr int GN_MAX_SPLITS = 128;   // small batches of large images (B = 4 at 256x256) need the pixel splits to fill the chip
 
+static int gn_max_splits(int B) {
+    int s = 512 / (B > 0 ? B : 1);
+    return s < 1 ? 1 : (s > GN_MAX_SPLITS ? GN_MAX_SPLITS : s);
+}
 static int gn_splits(int B, int HW) {
     int s = 512 / (B > 0 ? B : 1);
     if (s < 1) s = 1;
@@ -80,16 +84,10 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, long long ldx, int 
     }
 }
 
-// ---- forward apply: y = silu?((x - mean) * rstd * gamma + beta); grid = (blocks per sample, B).
-// Prologue: the first G threads finalize this sample's (mean, rstd) from the S fixed-order partials (fp64);
-// block 0 of the sample also stores them for backward.
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
-                                                     long long ldy, int HW, int C, int G, int S, double n, float eps,
-                                                     const double* __restrict__ part, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, float* __restrict__ mean,
-                                                     float* __restrict__ rstd, int silu) {
-    extern __shared__ float st[];  // [G][2]
-    const int b = blockIdx.y;
+// ---- forward finalize: (mean, rstd)[b][g] from the S fixed-order partials (fp64); one block per sample
+__global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(const double* __restrict__ part, int G, int S, double n, float eps,
+                                                            float* __restrict__ mean, float* __restrict__ rstd) {
+    const int b = blockIdx.x;
     for (int g = threadIdx.x; g < G; g += 256) {
         double a = 0.0, c2 = 0.0;
         for (int sp = 0; sp < S; ++sp) {
@@ -100,9 +98,21 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
         const double mu = a / n;
         double var = c2 / n - mu * mu;
         if (var < 0.0) var = 0.0;
-        const float m = (float)mu, r = (float)(1.0 / sqrt(var + (double)eps));
-        st[2 * g] = m; st[2 * g + 1] = r;
-        if (blockIdx.x == 0) { mean[b * G + g] = m; rstd[b * G + g] = r; }
+        mean[b * G + g] = (float)mu;
+        rstd[b * G + g] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+// ---- forward apply: y = silu?((x - mean) * rstd * gamma + beta); grid = (blocks per sample, B)
+__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
+                                                     long long ldy, int HW, int C, int G, const float* __restrict__ gamma,
+                                                     const float* __restrict__ beta, const float* __restrict__ mean,
+                                                     const float* __restrict__ rstd, int silu) {
+    extern __shared__ float st[];  // [G][2]
+    const int b = blockIdx.y;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        st[2 * g] = mean[b * G + g];
+        st[2 * g + 1] = rstd[b * G + g];
     }
     __syncthreads();
     const int q = C / 4, cpg = C / G;
@@ -130,8 +140,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
 __global__ void gn_bwd_stats_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy, long long lddy,
                                     int HW, int C, int G, int r, int S, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ mean,
-                                    const float* __restrict__ rstd, int silu, float* __restrict__ part /* [B][S][C][2] */) {
-    extern __shared__ float sh[];  // [r][C][2]
+                                    const float* __restrict__ rstd, int silu, float* __restrict__ part /* [B][S][3][C] */) {
+    extern __shared__ float sh[];  // [r][C][3]
     const int q = C / 4, cpg = C / G;
     const int t = threadIdx.x;
     const int cq = t % q, prow = t / q;
@@ -150,7 +160,7 @@ __global__ void gn_bwd_stats_kernel(const float* __restrict__ x, long long ldx, 
         gg[j] = gamma[c];
         bb[j] = beta[c];
     }
-    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f};
+    float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const float* xb = x + (long long)b * HW * ldx + cq * 4;
     const float* db = dy + (long long)b * HW * lddy + cq * 4;
     for (int p = p0 + prow; p < p1; p += r) {
@@ -164,36 +174,40 @@ __global__ void gn_bwd_stats_kernel(const float* __restrict__ x, long long ldx, 
             if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
             s0[j] += dz;
             s1[j] += dz * xh;
+            s2[j] += xh;
         }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-        sh[(prow * C + cq * 4 + j) * 2 + 0] = s0[j];
-        sh[(prow * C + cq * 4 + j) * 2 + 1] = s1[j];
+        sh[(prow * C + cq * 4 + j) * 3 + 0] = s0[j];
+        sh[(prow * C + cq * 4 + j) * 3 + 1] = s1[j];
+        sh[(prow * C + cq * 4 + j) * 3 + 2] = s2[j];
     }
     __syncthreads();
     for (int c = t; c < C; c += blockDim.x) {
-        float a = 0.f, e = 0.f;
+        float a = 0.f, e = 0.f, h = 0.f;
         for (int pr = 0; pr < r; ++pr) {
-            a += sh[(pr * C + c) * 2 + 0];
-            e += sh[(pr * C + c) * 2 + 1];
+            a += sh[(pr * C + c) * 3 + 0];
+            e += sh[(pr * C + c) * 3 + 1];
+            h += sh[(pr * C + c) * 3 + 2];
         }
-        float* o = part + ((long long)b * S + s) * 2 * C + c;
-        o[0] = e;   // plane 0: sum dz * xhat  -> dgamma
-        o[C] = a;   // plane 1: sum dz         -> dbeta
+        float* o = part + ((long long)b * S + s) * 3 * C + c;
+        o[0] = e;       // plane 0: sum dz * xhat  -> dgamma
+        o[C] = a;       // plane 1: sum dz         -> dbeta
+        o[2 * C] = h;   // plane 2: sum xhat       -> closed-form column sums of dx
     }
 }
 
 // ---- backward finalize -----------------------------------------------------------------------------
 // (a) dgamma/dbeta[c] = sum over the B*S partial rows: 64 columns x 4 row phases per block, fixed order
-__global__ __launch_bounds__(1024) void gn_bwd_param_kernel(const float* __restrict__ part, int rows, int C,
+__global__ __launch_bounds__(1024) void gn_bwd_param_kernel(const float* __restrict__ part, int rows, int row_stride, int C,
                                                           float* __restrict__ dgamma, float* __restrict__ dbeta) {
     __shared__ double red[16][64];
     const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 columns x 16 row phases
     const int n = blockIdx.x * 64 + tx;   // column in [0, 2C): plane 0 = dgamma, plane 1 = dbeta
     double s = 0.0;
     if (n < 2 * C)
-        for (int r = ty; r < rows; r += 16) s += (double)part[(long long)r * 2 * C + n];
+        for (int r = ty; r < rows; r += 16) s += (double)part[(long long)r * row_stride + n];
     red[ty][tx] = s;
     __syncthreads();
     if (ty == 0 && n < 2 * C) {
@@ -204,27 +218,56 @@ __global__ __launch_bounds__(1024) void gn_bwd_param_kernel(const float* __restr
         if (n < C) dgamma[n] = v; else dbeta[n - C] = v;
     }
 }
-// ---- backward apply: dx (+)= rstd * (dz*gamma - (s1 + xhat*s2)/n); grid = (blocks per sample, B).
-// Prologue: per group s1 = sum gamma*dz, s2 = sum gamma*dz*xhat from the per-channel partials (fixed order, fp64).
+// ---- backward group finalize: per (b, g) s1 = sum gamma*dz, s2 = sum gamma*dz*xhat from the per-channel partials
+// (fixed order, fp64); optional per-sample column sums of dx in closed form (see gn_bwd_res_kernel).  One block per sample.
+__global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, int HW, int C, int G, int S,
+                                                            const float* __restrict__ gamma, const float* __restrict__ rstd,
+                                                            float inv_n, float* __restrict__ ds /* [B][G][2] */,
+                                                            float* __restrict__ dx_colsum, long long ld_colsum) {
+    extern __shared__ float sg[];  // [G][2]
+    const int b = blockIdx.x;
+    const int cpg = C / G;
+    for (int g = threadIdx.x; g < G; g += 256) {
+        double a = 0.0, e = 0.0;
+        for (int sp = 0; sp < S; ++sp)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                const float* p = part + ((long long)b * S + sp) * 3 * C + c;
+                e += (double)p[0] * gamma[c];
+                a += (double)p[C] * gamma[c];
+            }
+        sg[2 * g] = (float)a; sg[2 * g + 1] = (float)e;
+        ds[((long long)b * G + g) * 2] = (float)a;
+        ds[((long long)b * G + g) * 2 + 1] = (float)e;
+    }
+    __syncthreads();
+    if (dx_colsum) {
+        for (int c = threadIdx.x; c < C; c += 256) {
+            float a = 0.f, h = 0.f;
+            for (int sp = 0; sp < S; ++sp) {
+                const float* p = part + ((long long)b * S + sp) * 3 * C + c;
+                a += p[C];
+                h += p[2 * C];
+            }
+            const int g = c / cpg;
+            dx_colsum[(long long)b * ld_colsum + c] =
+                rstd[b * G + g] * (gamma[c] * a - ((float)HW * sg[2 * g] + sg[2 * g + 1] * h) * inv_n);
+        }
+    }
+}
+
+// ---- backward apply: dx (+)= rstd * (dz*gamma - (s1 + xhat*s2)/n); grid = (blocks per sample, B)
 __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, long long ldx,
                                                          const float* __restrict__ dy, long long lddy,
-                                                         float* __restrict__ dx, long long lddx, int HW, int C, int G, int S,
-                                                         const float* __restrict__ part, const float* __restrict__ gamma,
+                                                         float* __restrict__ dx, long long lddx, int HW, int C, int G,
+                                                         const float* __restrict__ ds, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ mean,
                                                          const float* __restrict__ rstd, float inv_n, int silu, int acc) {
     extern __shared__ float st[];  // [G][4] = mean, rstd, s1, s2
     const int b = blockIdx.y;
     const int q = C / 4, cpg = C / G;
     for (int g = threadIdx.x; g < G; g += 256) {
-        double a = 0.0, e = 0.0;
-        for (int sp = 0; sp < S; ++sp)
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-                const float* p = part + ((long long)b * S + sp) * 2 * C + c;
-                e += (double)p[0] * gamma[c];
-                a += (double)p[C] * gamma[c];
-            }
         st[4 * g] = mean[b * G + g]; st[4 * g + 1] = rstd[b * G + g];
-        st[4 * g + 2] = (float)a; st[4 * g + 3] = (float)e;
+        st[4 * g + 2] = ds[((long long)b * G + g) * 2]; st[4 * g + 3] = ds[((long long)b * G + g) * 2 + 1];
     }
     __syncthreads();
     const long long total4 = (long long)HW * q;
@@ -518,9 +561,10 @@ static int gn_common_checks(const char* who, int B, int HW, int C, int G, const 
 using namespace bd;
 
 extern "C" size_t bd_gn_workspace_bytes(int B, int C) {
-    // fwd: [B][S][G<=C][2] doubles ; bwd: [B][S][C][2] floats + [B][G][2] floats
-    size_t fwd = (size_t)B * GN_MAX_SPLITS * (size_t)C * 2 * sizeof(double);
-    size_t bwd = (size_t)B * GN_MAX_SPLITS * (size_t)C * 2 * sizeof(float) + (size_t)B * C * 2 * sizeof(float) + 256;
+    // fwd: [B][S][G<=C][2] doubles ; bwd: [B][S][3][C] floats + [B][G][2] floats
+    const size_t ms = (size_t)gn_max_splits(B);
+    size_t fwd = (size_t)B * ms * (size_t)C * 2 * sizeof(double);
+    size_t bwd = (size_t)B * ms * (size_t)C * 3 * sizeof(float) + (size_t)B * C * 2 * sizeof(float) + 256;
     return fwd > bwd ? fwd : bwd;
 }
 
@@ -558,9 +602,11 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
         long long nbx = cdiv(per4, 256 * 4);           // ~4 float4 per thread
         if (nbx < 1) nbx = 1;
         if (nbx > 4096) nbx = 4096;
+        hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(d->B), dim3(256), 0, S(stream), part, d->G, S_,
+                           (double)d->HW * (d->C / d->G), d->eps, d->mean, d->rstd);
         hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nbx, d->B), dim3(256), (size_t)d->G * 2 * sizeof(float), S(stream), d->x,
-                           (long long)d->ldx, d->y, (long long)d->ldy, d->HW, d->C, d->G, S_, (double)d->HW * (d->C / d->G), d->eps,
-                           part, d->gamma, d->beta, d->mean, d->rstd, d->silu);
+                           (long long)d->ldx, d->y, (long long)d->ldy, d->HW, d->C, d->G, d->gamma, d->beta, d->mean, d->rstd,
+                           d->silu);
     }
     BD_LAUNCH_CHECK("gn_apply");
     return BD_OK;
@@ -589,37 +635,38 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
         else BD_GN_BWD_RES(GN_RES_EMAX, 256);
 #undef BD_GN_BWD_RES
         BD_LAUNCH_CHECK("gn_bwd_res");
-        hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(1024), 0, S(stream), part_r, d->B, d->C,
-                           d->dgamma, d->dbeta);
+        hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(1024), 0, S(stream), part_r, d->B, 2 * d->C,
+                           d->C, d->dgamma, d->dbeta);
         BD_LAUNCH_CHECK("gn_bwd_param");
         return BD_OK;
     }
     const int S_ = gn_splits(d->B, d->HW);
-    const size_t part_bytes = align_up((size_t)d->B * S_ * d->C * 2 * sizeof(float), 256);
+    const size_t part_bytes = align_up((size_t)d->B * S_ * d->C * 3 * sizeof(float), 256);
     const size_t need = part_bytes + (size_t)d->B * d->G * 2 * sizeof(float);
     BD_CHECK(d->workspace_bytes >= need, BD_ERR_WORKSPACE, "bd_gn_bwd: workspace %zu < %zu", d->workspace_bytes, need);
     float* part = reinterpret_cast<float*>(d->workspace);
     float* ds = reinterpret_cast<float*>(reinterpret_cast<char*>(d->workspace) + part_bytes);
     int threads, r;
     gn_block(d->C, threads, r);
-    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(S_, d->B), dim3(threads), (size_t)r * d->C * 2 * sizeof(float), S(stream), d->x,
+    hipLaunchKernelGGL(gn_bwd_stats_kernel, dim3(S_, d->B), dim3(threads), (size_t)r * d->C * 3 * sizeof(float), S(stream), d->x,
                        (long long)d->ldx, d->dy, (long long)d->lddy, d->HW, d->C, d->G, r, S_, d->gamma, d->beta, d->mean,
                        d->rstd, d->silu, part);
     BD_LAUNCH_CHECK("gn_bwd_stats");
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(1024), 0, S(stream), part, d->B * S_, d->C,
-                       d->dgamma, d->dbeta);
+    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(1024), 0, S(stream), part, d->B * S_, 3 * d->C,
+                       d->C, d->dgamma, d->dbeta);
     BD_LAUNCH_CHECK("gn_bwd_param");
     {
         const long long per4 = (long long)d->HW * (d->C / 4);
         long long nbx = cdiv(per4, 256 * 4);
         if (nbx < 1) nbx = 1;
         if (nbx > 4096) nbx = 4096;
+        const float inv_n = 1.0f / ((float)d->HW * (d->C / d->G));
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(d->B), dim3(256), (size_t)d->G * 2 * sizeof(float), S(stream), part, d->HW,
+                           d->C, d->G, S_, d->gamma, d->rstd, inv_n, ds, d->dx_colsum, (long long)d->ld_colsum);
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)nbx, d->B), dim3(256), (size_t)d->G * 4 * sizeof(float), S(stream), d->x,
-                           (long long)d->ldx, d->dy, (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, S_, part,
-                           d->gamma, d->beta, d->mean, d->rstd, 1.0f / ((float)d->HW * (d->C / d->G)), d->silu, d->accumulate_dx);
+                           (long long)d->ldx, d->dy, (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, ds, d->gamma,
+                           d->beta, d->mean, d->rstd, inv_n, d->silu, d->accumulate_dx);
     }
     BD_LAUNCH_CHECK("gn_bwd_apply");
-    if (d->dx_colsum)   // split path: per-sample column sums of the dx just written
-        BD_TRY(bd_colsum(d->dx, d->lddx, (int64_t)d->B * d->HW, d->C, d->HW, d->dx_colsum, d->ld_colsum, 0, stream));
     return BD_OK;
 }

@@ -138,7 +138,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=128, help="per-GPU batch")
+    ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 128 for cifar, 4 for celeba)")
+    ap.add_argument("--workload", default="cifar", choices=["cifar", "celeba"],
+                    help="cifar = BASELINE configs[1] (the metric); celeba = the 256x256 DDPM-CELEBA-HQ-256 topology (side measurement)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--mode", default=os.environ.get("BD_COMPUTE_MODE", "bf16x3"), choices=["f32", "bf16x3"],
@@ -173,27 +175,28 @@ def main():
 
     # DDPM-CIFAR10-32 topology, torch default init with seed 0 (no hub weights offline)
     torch.manual_seed(0)
-    model = UNet2DModel(sample_size=32, in_channels=3, out_channels=3, block_out_channels=(128, 256, 256, 256),
-                        down_block_types=("DownBlock2D", "AttnDownBlock2D", "DownBlock2D", "DownBlock2D"),
-                        up_block_types=("UpBlock2D", "UpBlock2D", "AttnUpBlock2D", "UpBlock2D"), layers_per_block=2,
-                        downsample_padding=0, flip_sin_to_cos=False, freq_shift=1, norm_eps=1e-6,
-                        attention_head_dim=None, compute_mode=args.mode).to(dev)
+    from baddiffusion_amd.model import KNOWN_TOPOLOGIES
+    celeba = args.workload == "celeba"      # BASELINE configs[3] topology (256x256, 113.7 M params), a side measurement
+    topo = KNOWN_TOPOLOGIES["google/ddpm-ema-celebahq-256" if celeba else "google/ddpm-cifar10-32"]
+    S_IMG = topo["sample_size"]
+    model = UNet2DModel(**topo, compute_mode=args.mode).to(dev)
     sched = DDPMScheduler(num_train_timesteps=1000)
-    B = args.batch
+    B = args.batch if args.batch > 0 else (4 if celeba else 128)
     eng = TrainEngine(model, sched, lr=2e-4, lr_warmup_steps=500, num_training_steps=469 * 50)
 
     # synthetic CIFAR-like data, resident in HBM: uint8 images, BOX_14 trigger, CORNER target (HAT stand-in:
     # static/fedora-hat.png is a reference asset and does not travel), poison flags i % 10 == 0
     from baddiffusion_amd.dataset import Backdoor
     bd = Backdoor(root=None)
-    trigger = bd.get_trigger("BOX_14", 3, 32).to(dev)
+    trigger = bd.get_trigger("BOX_14", 3, S_IMG).to(dev)
     target = bd.get_target("CORNER", trigger.cpu()).to(dev)
-    NIMG = 8192
+    NIMG = 256 if celeba else 8192
     g = torch.Generator().manual_seed(1000 + rank)
-    images = torch.randint(0, 256, (NIMG, 32, 32, 3), generator=g, dtype=torch.uint8).to(dev)
+    images = torch.randint(0, 256, (NIMG, S_IMG, S_IMG, 3), generator=g, dtype=torch.uint8).to(dev)
     flags = (torch.arange(NIMG) % 10 == 0).to(dev)
     NPOOL = 8
-    noise = torch.randn(NPOOL, B, 3, 32, 32, generator=g).to(dev)
+    NPOOL = 2 if celeba else 8
+    noise = torch.randn(NPOOL, B, 3, S_IMG, S_IMG, generator=g).to(dev)
     ts = torch.randint(0, 1000, (NPOOL, B), generator=g).to(dev)
 
     def step(i):
@@ -243,16 +246,27 @@ def main():
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
-        out = {"metric": "train images/sec (32x32 UNet, DDPM-CIFAR10-32 topology, bs128/GPU, poison_rate 0.1)",
+        gflop_img = 1490.63 if celeba else TRAIN_GFLOP_PER_IMG
+        hbm_floor_ms = (16688e6 * B + 6.65e9 if celeba else 452.3e6 * B + 2.25e9) / 8e12 * 1e3   # eager-level bytes / 8 TB/s
+        if celeba:
+            metric = f"train images/sec (256x256 UNet, DDPM-CELEBA-HQ-256 topology, bs{B}/GPU, poison_rate 0.1)"
+            workload = (f"BASELINE configs[3] topology: DDPM-CELEBA-HQ-256 train step, batch {B}/GPU, poison_rate 0.1, BOX_14 trigger, "
+                        "CORNER target, clip 1.0 + Adam (side measurement, not the headline metric)")
+        else:
+            metric = "train images/sec (32x32 UNet, DDPM-CIFAR10-32 topology, bs128/GPU, poison_rate 0.1)"
+            workload = ("BASELINE configs[1]: CIFAR10 DDPM-CIFAR10-32 train step, batch 128/GPU, poison_rate 0.1, "
+                        "BOX_14 trigger, CORNER target (HAT stand-in), clip 1.0 + Adam, fp32 storage")
+        out = {"metric": metric,
                "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32" if args.mode == "f32" else "f32 (split-bf16 hi+lo products, fp32 accumulate)",
-               "data": "synthetic (uint8 32x32x3 images resident in HBM, seeded default-init weights)",
-               "config": {"workload": "BASELINE configs[1]: CIFAR10 DDPM-CIFAR10-32 train step, batch 128/GPU, poison_rate 0.1, "
-                                      "BOX_14 trigger, CORNER target (HAT stand-in), clip 1.0 + Adam, fp32",
-                          "global_batch": world * B, "parallelism": f"dp{world}", "params": 35746307},
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f32" if args.mode == "f32" else "f32 (split-bf16 hi+lo products, fp32 accumulate)",
+               "data": f"synthetic (uint8 {S_IMG}x{S_IMG}x3 images resident in HBM, seeded default-init weights)",
+               "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}",
+                          "params": int(model.num_flat)},
                "final_loss": final_loss,
-               "step_tflops": TRAIN_GFLOP_PER_IMG * B * world / (ms * 1e-3) / 1e3,
-               "step_frac_of_fp32_mfma_peak": TRAIN_GFLOP_PER_IMG * B / (ms * 1e-3) / 1e3 / FP32_MFMA_PEAK_TFLOPS}
+               "step_tflops": gflop_img * B * world / (ms * 1e-3) / 1e3,
+               "step_frac_of_fp32_mfma_peak": gflop_img * B / (ms * 1e-3) / 1e3 / FP32_MFMA_PEAK_TFLOPS,
+               "step_frac_of_hbm_roofline": hbm_floor_ms / ms}
         if not args.no_prof:
             classes = []
             for c in range(lib.bd_prof_num_classes()):
