@@ -128,6 +128,57 @@ def test_small_unet_train_step_bf16x3(bd, golden):
     _train_step(bd, C.SMALL_CFGS["small"], 7, 2, "small", golden("unet_small"), mode="bf16x3")
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_celeba_topology_train_step_vs_oracle(bd, mode):
+    """BASELINE configs[3] topology (6 levels, (128,128,256,256,512,512), attention on level 4) at 64x64 so that the
+    CPU oracle finishes in seconds: loss and every gradient tensor against the oracle's autograd.  64x64 feature
+    maps also take the split (non-resident) GroupNorm kernels and split-K / non-split conv paths the 32x32 net
+    never reaches."""
+    import dataclasses
+    unet, ops = bd
+    cfg = dataclasses.replace(U.CELEBA_HQ_256, sample_size=64)
+    _, a, ac = sched_ref.make_tables()
+    m = make_model(unet, cfg, 11).set_compute_mode(mode)
+    x0, R, t, eps = C.train_inputs(cfg, 2)
+    x0, R, t, eps = x0[:1], R[:1], t[:1], eps[:1]
+    xn, tg = ops.qsample(x0.cuda(), R.cuda(), eps.cuda(), t.cuda(), a.cuda(), ac.cuda())
+    pred = m(xn.permute(0, 3, 1, 2), t.cuda(), return_dict=False)[0]
+    loss, dp = ops.loss_fwd_bwd(pred.permute(0, 2, 3, 1), tg, "l2")
+    pred.backward(dp.reshape(pred.permute(0, 2, 3, 1).shape).permute(0, 3, 1, 2))
+    ref_loss, G = train_ref.loss_and_grads(cfg, U.gen_params(cfg, 11), a, ac, x0, R, t, eps)
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss))
+    grads = m.logical_grads()
+    total = float(torch.sqrt(sum((v.double() ** 2).sum() for v in G.values())))
+    def err(k):
+        d = float((grads[k].detach().cpu().double() - G[k].double()).norm())
+        return d / max(float(G[k].double().norm()), 1e-3 * total)
+    worst = max((err(k), k) for k in G)
+    assert worst[0] < 1e-3, worst
+
+
+def test_celeba_full_resolution_modes_agree(bd):
+    """the real 256x256 DDPM-CELEBA-HQ-256 network (113.7 M parameters), batch 1: forward + backward run, are finite,
+    and the split-bf16 contraction agrees with the exact-fp32 one (size-independent self-consistency; the oracle
+    would need minutes here)."""
+    unet, ops = bd
+    cfg = U.CELEBA_HQ_256
+    m = make_model(unet, cfg, 5)
+    assert m.num_flat >= 113673219
+    x = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(3)).cuda()
+    t = torch.tensor([417]).cuda()
+    dout = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(4)).cuda()
+    res = {}
+    for mode in ("f32", "bf16x3"):
+        m.set_compute_mode(mode)
+        m.flat.grad = None
+        out = m(x, t, return_dict=False)[0]
+        out.backward(dout)
+        assert torch.isfinite(out).all() and torch.isfinite(m.flat.grad).all()
+        res[mode] = (out.detach().clone(), m.flat.grad.detach().clone())
+    assert relerr(res["bf16x3"][0], res["f32"][0]) < 1e-4
+    assert relerr(res["bf16x3"][1], res["f32"][1]) < 1e-3
+
+
 def test_backward_segments_equal_whole(bd):
     """bd_unet_backward_segment over all segments == bd_unet_backward (the DP overlap path)."""
     unet, ops = bd
