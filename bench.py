@@ -281,7 +281,7 @@ def main():
                 # the dense bf16 peak / 3 (833 TF), above the exact-fp32 MFMA peak (157 TF) the f32 mode is bound by
                 peak = FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 3
                 out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": peak,
-                                   "unit": "TFLOP/s", "frac": ach / peak, "traffic": _pmc_traffic(d["kernel"]),
+                                   "unit": "TFLOP/s", "frac": ach / peak, "traffic": None if celeba else _pmc_traffic(d["kernel"]),
                                    "mfma_flops_per_algorithmic_flop": 1 if args.mode == "f32" else 3,
                                    "mfma_dense_peak": FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS,
                                    "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
