@@ -43,6 +43,7 @@ constexpr int LDK = BK + 4;  // KC row stride (floats): 16B-aligned rows, confli
 
 struct Opnd {
     const float* p;
+    const unsigned short *hi, *lo;   // pre-split bf16 planes of the same operand (or null)
     long long ld;
     int kind, vec;
     int C, Hs, Ws, Ho, Wo, stride, pad_t, pad_l, ups;
@@ -398,6 +399,108 @@ struct WgtRC : RCStore<R, TR> {
     }
     __device__ __forceinline__ void advance(const Opnd&) {
         if (++tap == 9) { tap = 0; c0 += BK; }
+    }
+};
+
+// ---- pre-split weights: bf16 hi / lo planes written once per step by bd_split_bf16 (same indexing as the fp32 buffer).
+// A thread moves 8 k-values (KC) or 8 rows (RC) of one plane per 16-byte load straight into the LDS plane: no VALU
+// work at all for this operand.  v[0..NU) = hi units, v[NU..2NU) = lo units (raw bits carried in float4).
+__device__ __forceinline__ float4 ldb8_if(const unsigned short* p, bool ok) {   // 8 bf16 as raw bits in a float4
+    const v4f t = *(gptr4)(ok ? (const void*)p : (const void*)kZero16);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
+// row handled by thread quad g = tid / 4 of the pre-split KC loaders: 16 consecutive lanes write rows r, r+4, r+8, r+12,
+// whose 64-byte pieces (row stride 80 B) tile one 256-byte bank sweep -> conflict-free ds_write_b128
+__device__ __forceinline__ int wrow(int tid) {
+    const int g = tid >> 2;
+    return (g & ~15) | ((g & 3) << 2) | ((g >> 2) & 3);
+}
+
+// forward-conv weights, rows = co, K order of ConvKC (channel block outer, tap inner)
+template <int R>
+struct WgtKCs {
+    static constexpr int NI = R / 32, NU = R / 64;
+    static constexpr bool kKC = true;
+    const unsigned short *ph[NU], *pl[NU];
+    bool ok[NU];
+    int tap, c0;
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
+        const int k8 = (tid & 3) * 8;
+        const int chunk = kbase / BK;
+        tap = chunk % 9;
+        c0 = (chunk / 9) * BK;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int r = row0 + wrow(tid) + 64 * u;
+            ok[u] = r < o.rows;
+            ph[u] = o.hi + (long long)r * o.ld + k8;
+            pl[u] = o.lo + (long long)r * o.ld + k8;
+        }
+    }
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
+        const int off = tap * o.C + c0;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            v[u] = ldb8_if(ph[u] + off, ok[u] && c0 < o.C);
+            v[NU + u] = ldb8_if(pl[u] + off, ok[u] && c0 < o.C);
+        }
+    }
+    __device__ __forceinline__ void advance(const Opnd&) {
+        if (++tap == 9) { tap = 0; c0 += BK; }
+    }
+    __device__ __forceinline__ static void store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]) {
+        const int k8 = (tid & 3) * 8;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int o = (wrow(tid) + 64 * u) * LDH + k8;
+            *reinterpret_cast<float4*>(sh + o) = v[u];
+            *reinterpret_cast<float4*>(sl + o) = v[NU + u];
+        }
+    }
+};
+
+// weights seen from dgrad (rows = ci contiguous, k = (tap, co)), LDS image [k][R + 32] like RCStore
+template <int R>
+struct WgtRCs {
+    static constexpr int NI = R / 32, NU = R / 64;
+    static constexpr int UPR = R / 8;          // 16-byte units per k row
+    static constexpr int KS = 256 / UPR;       // k rows covered per pass
+    static constexpr bool kKC = false;
+    const unsigned short *ph, *pl;
+    long long step;
+    int tap, c0;
+    bool ok;
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
+        const int r8 = (tid % UPR) * 8, k0 = tid / UPR;
+        ok = row0 + r8 < o.rows;
+        const int chunk = kbase / BK;
+        tap = chunk % 9;
+        c0 = (chunk / 9) * BK;
+        const long long base = (row0 + r8) + (long long)k0 * 9 * o.ld;
+        ph = o.hi + base;
+        pl = o.lo + base;
+        step = (long long)KS * 9 * o.ld;
+    }
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
+        const long long q = ((long long)c0 * 9 + tap) * o.ld;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            v[u] = ldb8_if(ph + q + step * u, ok && c0 < o.C);
+            v[NU + u] = ldb8_if(pl + q + step * u, ok && c0 < o.C);
+        }
+    }
+    __device__ __forceinline__ void advance(const Opnd&) {
+        if (++tap == 9) { tap = 0; c0 += BK; }
+    }
+    __device__ __forceinline__ static void store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]) {
+        const int r8 = (tid % UPR) * 8, k0 = tid / UPR;
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+            const int o = (k0 + KS * u) * (R + 32) + r8;
+            *reinterpret_cast<float4*>(sh + o) = v[u];
+            *reinterpret_cast<float4*>(sl + o) = v[NU + u];
+        }
     }
 };
 
@@ -873,6 +976,16 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16x3_kernel(IGemmParams p) {
     epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi, wg.zz);
 }
 
+// the on-the-fly split, applied once to a whole buffer (weights): 8 elements per thread
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ src, long long n8, unsigned short* __restrict__ hi,
+                                                       unsigned short* __restrict__ lo) {
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
+        const float4 a = ld4(src + 8 * i), b = ld4(src + 8 * i + 4);
+        *reinterpret_cast<uint4*>(hi + 8 * i) = make_uint4(pack_hi(a.x, a.y), pack_hi(a.z, a.w), pack_hi(b.x, b.y), pack_hi(b.z, b.w));
+        *reinterpret_cast<uint4*>(lo + 8 * i) = make_uint4(pack_lo(a.x, a.y), pack_lo(a.z, a.w), pack_lo(b.x, b.y), pack_lo(b.z, b.w));
+    }
+}
+
 // split-K second pass: fixed-order (deterministic) sum of the partial slabs + epilogue
 __global__ __launch_bounds__(256) void igemm_splitk_reduce(IGemmParams p, int nbatch) {
     const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -957,7 +1070,7 @@ static int ilog2_exact(int v) {
 
 static Opnd make_opnd(const bd_operand& o, int rows, int K) {
     Opnd r;
-    r.p = o.p; r.ld = o.ld; r.kind = o.kind; r.vec = operand_vec_ok(o, rows, K) ? 1 : 0;
+    r.p = o.p; r.hi = o.hi; r.lo = o.lo; r.ld = o.ld; r.kind = o.kind; r.vec = operand_vec_ok(o, rows, K) ? 1 : 0;
     r.C = o.C > 0 ? o.C : 1; r.Hs = o.Hs; r.Ws = o.Ws; r.Ho = o.Ho > 0 ? o.Ho : 1; r.Wo = o.Wo > 0 ? o.Wo : 1;
     r.stride = o.stride > 0 ? o.stride : 1; r.pad_t = o.pad_t; r.pad_l = o.pad_l; r.ups = o.ups; r.rows = rows;
     const int lw = ilog2_exact(r.Wo), lh = ilog2_exact(r.Ho);
@@ -1003,18 +1116,26 @@ size_t igemm_workspace_bytes(const bd_igemm_desc& d) {
     return (size_t)d.batch_outer * d.batch_inner * c.ksplit * ((size_t)d.M * d.N + (d.a_colsum ? (size_t)d.M : 0)) * sizeof(float);
 }
 
-enum Cls { CLS_GENERIC = 0, CLS_CONV_FWD, CLS_CONV_DGRAD, CLS_CONV_WGRAD, CLS_GEMM_NT, CLS_GEMM_NN, CLS_GEMM_TN };
-static const char* kClsName[] = {"generic", "conv_fwd", "conv_dgrad", "conv_wgrad", "gemm_nt", "gemm_nn", "gemm_tn"};
+enum Cls { CLS_GENERIC = 0, CLS_CONV_FWD, CLS_CONV_DGRAD, CLS_CONV_WGRAD, CLS_GEMM_NT, CLS_GEMM_NN, CLS_GEMM_TN,
+           CLS_CONV_FWD_WS, CLS_CONV_DGRAD_WS };   // _WS: weights (B) taken from pre-split bf16 planes
+static const char* kClsName[] = {"generic", "conv_fwd", "conv_dgrad", "conv_wgrad", "gemm_nt", "gemm_nn", "gemm_tn",
+                                 "conv_fwd", "conv_dgrad"};
+
+static bool presplit_ok(const bd_igemm_desc& d) {
+    const bd_operand& o = d.B;
+    return d.mode == BD_MODE_BF16X3 && o.hi && o.lo && aligned16(o.hi) && aligned16(o.lo) && (o.ld & 7) == 0 && (d.N & 7) == 0 &&
+           d.batch_outer * d.batch_inner == 1;
+}
 
 static Cls classify(const bd_igemm_desc& d, bool fast) {
     if (!fast) return CLS_GENERIC;
     const int ak = d.A.kind, bk = d.B.kind;
     const bool akc = d.A.kc != 0, bkc = d.B.kc != 0;
     if (akc && bkc) {
-        if (ak == BD_OPK_CONV && bk == BD_OPK_DENSE) return CLS_CONV_FWD;
+        if (ak == BD_OPK_CONV && bk == BD_OPK_DENSE) return presplit_ok(d) ? CLS_CONV_FWD_WS : CLS_CONV_FWD;
         if (ak == BD_OPK_DENSE && bk == BD_OPK_DENSE) return CLS_GEMM_NT;
     } else if (akc && !bkc) {
-        if (ak == BD_OPK_TCONV && bk == BD_OPK_WGT) return CLS_CONV_DGRAD;
+        if (ak == BD_OPK_TCONV && bk == BD_OPK_WGT) return presplit_ok(d) ? CLS_CONV_DGRAD_WS : CLS_CONV_DGRAD;
         if (ak == BD_OPK_DENSE && bk == BD_OPK_DENSE) return CLS_GEMM_NN;
     } else if (!akc && !bkc) {
         if (ak == BD_OPK_DENSE && bk == BD_OPK_CONV) return CLS_CONV_WGRAD;
@@ -1027,7 +1148,7 @@ static Cls classify(const bd_igemm_desc& d, bool fast) {
 // ds_read_b64_tr_b16 fragment reads)
 template <int T, bool TR, class LA, class LB>
 static void launch1(const IGemmParams& p, dim3 grid, hipStream_t st) {
-    if (TR) hipLaunchKernelGGL((igemm_bf16x3_kernel<T, T, LA, LB>), grid, dim3(256), 0, st, p);
+    if constexpr (TR) hipLaunchKernelGGL((igemm_bf16x3_kernel<T, T, LA, LB>), grid, dim3(256), 0, st, p);
     else hipLaunchKernelGGL((igemm_kernel<T, T, LA, LB>), grid, dim3(256), 0, st, p);
 }
 
@@ -1040,6 +1161,12 @@ static void launch_tile(const IGemmParams& p, const bd_igemm_desc& d, Cls cls, d
         case CLS_GEMM_NN: launch1<T, TR, DenseKC<T>, DenseRC<T, false>>(p, grid, st); return;
         case CLS_CONV_WGRAD: launch1<T, TR, DenseRC<T, false>, ConvRC<T, false>>(p, grid, st); return;
         case CLS_GEMM_TN: launch1<T, TR, DenseRC<T, false>, DenseRC<T, false>>(p, grid, st); return;
+        case CLS_CONV_FWD_WS:
+            if constexpr (TR) { launch1<T, true, ConvKC<T>, WgtKCs<T>>(p, grid, st); return; }
+            break;
+        case CLS_CONV_DGRAD_WS:
+            if constexpr (TR) { launch1<T, true, TConvKC<T>, WgtRCs<T>>(p, grid, st); return; }
+            break;
         default: break;
     }
     const bool akc = d.A.kc != 0, bkc = d.B.kc != 0;
@@ -1120,6 +1247,16 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
 
 }  // namespace bd
 
+extern "C" int bd_split_bf16(const float* src, int64_t n, uint16_t* hi, uint16_t* lo, bd_stream_t stream) {
+    BD_CHECK(src && hi && lo && n > 0 && (n & 7) == 0, BD_ERR_INVALID, "bd_split_bf16: bad args (n %% 8 must be 0)");
+    BD_CHECK(bd::aligned16(src) && bd::aligned16(hi) && bd::aligned16(lo), BD_ERR_UNSUPPORTED, "bd_split_bf16: pointers must be 16B aligned");
+    const long long n8 = n / 8;
+    long long nb = bd::cdiv(n8, 256);
+    if (nb > 4096) nb = 4096;
+    hipLaunchKernelGGL(bd::split_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, bd::S(stream), src, n8, hi, lo);
+    BD_LAUNCH_CHECK("split_bf16");
+    return BD_OK;
+}
 extern "C" size_t bd_igemm_workspace_bytes(const bd_igemm_desc* d) { return d ? bd::igemm_workspace_bytes(*d) : 0; }
 extern "C" int bd_igemm(const bd_igemm_desc* d, bd_stream_t stream) {
     BD_CHECK(d != nullptr, BD_ERR_INVALID, "bd_igemm: null descriptor");

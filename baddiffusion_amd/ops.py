@@ -203,7 +203,8 @@ def _conv_out_hw(Hs, Ws, stride, pad_t, pad_l, ups, pad_b=None, pad_r=None):
     return (Hi + pad_t + pad_b - 3) // stride + 1, (Wi + pad_l + pad_r - 3) // stride + 1
 
 
-def conv3x3_fwd(x, w, bias=None, stride=1, pad=1, ups=0, asym=False, rowbias=None, residual=None, out_scale=1.0, mode=0):
+def conv3x3_fwd(x, w, bias=None, stride=1, pad=1, ups=0, asym=False, rowbias=None, residual=None, out_scale=1.0, mode=0,
+                w_split=None):
     """x [B,Hs,Ws,Cin] NHWC ; w [Cout,3,3,Cin].  asym => F.pad(0,1,0,1) + stride-2 conv with padding 0."""
     lib = L.load(); _need_cuda(x, w, bias, rowbias, residual)
     B, Hs, Ws, Cin = x.shape
@@ -217,11 +218,22 @@ def conv3x3_fwd(x, w, bias=None, stride=1, pad=1, ups=0, asym=False, rowbias=Non
                       ld_rowbias=rowbias.stride(0) if rowbias is not None else 0, residual=L.ptr(residual),
                       ldr=_ld(residual) if residual is not None else 0, out_scale=out_scale, y=L.ptr(y), ldy=Cout,
                       workspace=L.ptr(ws), workspace_bytes=ws.numel(), mode=mode)
+    if w_split is not None:   # pre-split bf16 planes of w (split_bf16): the weight operand is staged without VALU work
+        d.w_hi, d.w_lo = L.ptr(w_split[0]), L.ptr(w_split[1])
     L.check(lib.bd_conv3x3_fwd(C.byref(d), L.stream()), "bd_conv3x3_fwd")
     return y
 
 
-def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False, mode=0):
+def split_bf16(x):
+    """(hi, lo) bf16 planes (int16 tensors) of an fp32 tensor: the split the bf16x3 kernels apply on the fly."""
+    lib = L.load(); _need_cuda(x)
+    x = x.contiguous()
+    hi = torch.empty(x.shape, dtype=torch.int16, device=x.device); lo = torch.empty_like(hi)
+    L.check(lib.bd_split_bf16(L.ptr(x), x.numel(), L.ptr(hi), L.ptr(lo), L.stream()), "bd_split_bf16")
+    return hi, lo
+
+
+def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False, mode=0, w_split=None):
     """Returns dx over the conv's own input grid [B, Hs<<ups, Ws<<ups, Cin]."""
     lib = L.load(); _need_cuda(dy, w)
     B, Hs, Ws, Cin = x_shape
@@ -233,6 +245,8 @@ def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False, mode=0):
     d = L.ConvDgradDesc(B=B, Hs=Hs, Ws=Ws, Cin=Cin, Cout=Cout, stride=stride, pad_t=pt, pad_l=pl, ups=ups, Ho=Ho, Wo=Wo,
                         dy=L.ptr(dy), lddy=_ld(dy), w=L.ptr(w), dx=L.ptr(dx), lddx=Cin, accumulate=0,
                         workspace=L.ptr(ws), workspace_bytes=ws.numel(), mode=mode)
+    if w_split is not None:
+        d.w_hi, d.w_lo = L.ptr(w_split[0]), L.ptr(w_split[1])
     L.check(lib.bd_conv3x3_dgrad(C.byref(d), L.stream()), "bd_conv3x3_dgrad")
     return dx
 

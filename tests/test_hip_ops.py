@@ -350,6 +350,35 @@ def test_conv3x3_bf16x3(ops, B, H, Cin, Cout, stride, pad, ups, asym):
     close(dw.permute(0, 3, 1, 2), wr.grad, 3e-4, 3e-4 * max(1.0, float(wr.grad.abs().max())))
 
 
+def test_split_bf16_planes(ops):
+    x = R(1, 4096) * torch.logspace(-6, 6, 4096)
+    hi, lo = ops.split_bf16(dev(x))
+    bits = x.view(torch.int32)
+    assert torch.equal(hi.cpu().int() & 0xFFFF, (bits >> 16) & 0xFFFF)            # hi = truncated bf16
+    hif = ((hi.cpu().int() & 0xFFFF) << 16).view(torch.float32); lof = ((lo.cpu().int() & 0xFFFF) << 16).view(torch.float32)
+    assert float(((hif.double() + lof.double() - x.double()).abs() / x.double().abs()).max()) < 2.0 ** -16
+    assert torch.equal(lof, (x - hif).to(torch.bfloat16).float())                 # lo = RNE bf16 of the remainder
+
+
+@pytest.mark.parametrize("B,H,Cin,Cout,stride,pad,ups,asym", [(2, 16, 128, 256, 1, 1, 0, False), (2, 16, 256, 128, 2, 0, 0, True),
+                                                              (2, 8, 128, 128, 1, 1, 1, False), (3, 8, 64, 64, 1, 1, 0, False),
+                                                              (130, 4, 256, 256, 1, 1, 0, False)])
+def test_conv3x3_presplit_weights_bit_identical(ops, B, H, Cin, Cout, stride, pad, ups, asym):
+    """weights handed over as bf16 hi/lo planes (bd_split_bf16, once per step) give bit-identical results to the
+    on-the-fly split of the same kernel family"""
+    x = dev(R(1, B, H, H, Cin)); w = dev(R(2, Cout, 3, 3, Cin) / (3 * Cin ** 0.5)); bias = dev(R(3, Cout))
+    ws = ops.split_bf16(w)
+    y0 = ops.conv3x3_fwd(x, w, bias, stride, pad, ups, asym, mode=1)
+    y1 = ops.conv3x3_fwd(x, w, bias, stride, pad, ups, asym, mode=1, w_split=ws)
+    assert torch.equal(y0, y1)
+    dy = dev(R(4, *y0.shape))
+    d0 = ops.conv3x3_dgrad(dy, w, (B, H, H, Cin), stride, pad, ups, asym, mode=1)
+    d1 = ops.conv3x3_dgrad(dy, w, (B, H, H, Cin), stride, pad, ups, asym, mode=1, w_split=ws)
+    assert torch.equal(d0, d1)
+    # exact mode ignores the planes
+    assert torch.equal(ops.conv3x3_fwd(x, w, bias, stride, pad, ups, asym, mode=0, w_split=ws), ops.conv3x3_fwd(x, w, bias, stride, pad, ups, asym, mode=0))
+
+
 @pytest.mark.parametrize("mode", [0, 1])
 @pytest.mark.parametrize("M,N,K,ksplit", [(128, 256, 4096, 0), (384, 128, 512, 1), (64, 64, 96, 1), (132, 72, 1000, 0), (256, 1152, 131072, 0)])
 def test_gemm_fused_colsum(ops, M, N, K, ksplit, mode):
