@@ -57,7 +57,7 @@ class GnBwdDesc(C.Structure):
 class Operand(C.Structure):
     _fields_ = [("kind", i32), ("kc", i32), ("p", vp), ("ld", i64), ("bs_outer", i64), ("bs_inner", i64),
                 ("C", i32), ("Hs", i32), ("Ws", i32), ("Ho", i32), ("Wo", i32), ("stride", i32),
-                ("pad_t", i32), ("pad_l", i32), ("ups", i32), ("hi", vp), ("lo", vp)]
+                ("pad_t", i32), ("pad_l", i32), ("ups", i32), ("split", vp)]
 
 
 class IgemmDesc(C.Structure):
@@ -76,14 +76,14 @@ class ConvFwdDesc(C.Structure):
                 ("pad_t", i32), ("pad_l", i32), ("ups", i32), ("Ho", i32), ("Wo", i32),
                 ("x", vp), ("ldx", i64), ("w", vp), ("bias", vp), ("rowbias", vp), ("ld_rowbias", i64),
                 ("residual", vp), ("ldr", i64), ("out_scale", f32), ("y", vp), ("ldy", i64),
-                ("workspace", vp), ("workspace_bytes", sz), ("mode", i32), ("w_hi", vp), ("w_lo", vp)]
+                ("workspace", vp), ("workspace_bytes", sz), ("mode", i32), ("w_split", vp)]
 
 
 class ConvDgradDesc(C.Structure):
     _fields_ = [("B", i32), ("Hs", i32), ("Ws", i32), ("Cin", i32), ("Cout", i32), ("stride", i32),
                 ("pad_t", i32), ("pad_l", i32), ("ups", i32), ("Ho", i32), ("Wo", i32),
                 ("dy", vp), ("lddy", i64), ("w", vp), ("dx", vp), ("lddx", i64), ("accumulate", i32),
-                ("workspace", vp), ("workspace_bytes", sz), ("mode", i32), ("w_hi", vp), ("w_lo", vp)]
+                ("workspace", vp), ("workspace_bytes", sz), ("mode", i32), ("w_split", vp)]
 
 
 class ConvWgradDesc(C.Structure):
@@ -119,7 +119,7 @@ SIGNATURES = {
     "bd_gn_bwd": (i32, [C.POINTER(GnBwdDesc), vp]),
     "bd_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),
     "bd_igemm": (i32, [C.POINTER(IgemmDesc), vp]),
-    "bd_split_bf16": (i32, [vp, i64, vp, vp, vp]),
+    "bd_split_bf16": (i32, [vp, i64, vp, vp]),
     "bd_conv3x3_fwd": (i32, [C.POINTER(ConvFwdDesc), vp]),
     "bd_conv3x3_dgrad": (i32, [C.POINTER(ConvDgradDesc), vp]),
     "bd_conv3x3_wgrad": (i32, [C.POINTER(ConvWgradDesc), vp]),

@@ -26,7 +26,7 @@ int conv3x3_fwd(const bd_conv3x3_fwd_desc& d, hipStream_t st) {
     g.A.kind = BD_OPK_CONV; g.A.kc = 1; g.A.p = d.x; g.A.ld = d.ldx;
     g.A.C = d.Cin; g.A.Hs = d.Hs; g.A.Ws = d.Ws; g.A.Ho = d.Ho; g.A.Wo = d.Wo;
     g.A.stride = d.stride; g.A.pad_t = d.pad_t; g.A.pad_l = d.pad_l; g.A.ups = d.ups;
-    g.B.kind = BD_OPK_DENSE; g.B.kc = 1; g.B.p = d.w; g.B.ld = 9ll * d.Cin; g.B.C = d.Cin; g.B.hi = d.w_hi; g.B.lo = d.w_lo;
+    g.B.kind = BD_OPK_DENSE; g.B.kc = 1; g.B.p = d.w; g.B.ld = 9ll * d.Cin; g.B.C = d.Cin; g.B.split = d.w_split;
     g.M = d.B * d.Ho * d.Wo; g.N = d.Cout; g.K = 9 * d.Cin;
     g.batch_outer = g.batch_inner = 1;
     g.C = d.y; g.ldc = d.ldy;
@@ -46,7 +46,7 @@ int conv3x3_dgrad(const bd_conv3x3_dgrad_desc& d, hipStream_t st) {
     g.A.kind = BD_OPK_TCONV; g.A.kc = 1; g.A.p = d.dy; g.A.ld = d.lddy;
     g.A.C = d.Cout; g.A.Hs = d.Ho; g.A.Ws = d.Wo; g.A.Ho = Hi; g.A.Wo = Wi;
     g.A.stride = d.stride; g.A.pad_t = d.pad_t; g.A.pad_l = d.pad_l; g.A.ups = 0;
-    g.B.kind = BD_OPK_WGT; g.B.kc = 0; g.B.p = d.w; g.B.ld = d.Cin; g.B.C = d.Cout; g.B.hi = d.w_hi; g.B.lo = d.w_lo;
+    g.B.kind = BD_OPK_WGT; g.B.kc = 0; g.B.p = d.w; g.B.ld = d.Cin; g.B.C = d.Cout; g.B.split = d.w_split;
     g.M = d.B * Hi * Wi; g.N = d.Cin; g.K = 9 * d.Cout;
     g.batch_outer = g.batch_inner = 1;
     g.C = d.dx; g.ldc = d.lddx;

@@ -19,6 +19,7 @@
 // conv_out (Cout = 3), odd GEMM sizes.  Replaces aten::convolution(_backward), addmm/mm/bmm/baddbmm
 // of the reference's UNet.
 #include "common.h"
+#include <cstdint>
 #include <cstdlib>
 
 namespace bd {
@@ -43,7 +44,7 @@ constexpr int LDK = BK + 4;  // KC row stride (floats): 16B-aligned rows, confli
 
 struct Opnd {
     const float* p;
-    const unsigned short *hi, *lo;   // pre-split bf16 planes of the same operand (or null)
+    const unsigned short* split;     // pre-split copy of the same buffer (bd_split_bf16 blocked layout) or null
     long long ld;
     int kind, vec;
     int C, Hs, Ws, Ho, Wo, stride, pad_t, pad_l, ups;
@@ -402,105 +403,100 @@ struct WgtRC : RCStore<R, TR> {
     }
 };
 
-// ---- pre-split weights: bf16 hi / lo planes written once per step by bd_split_bf16 (same indexing as the fp32 buffer).
-// A thread moves 8 k-values (KC) or 8 rows (RC) of one plane per 16-byte load straight into the LDS plane: no VALU
-// work at all for this operand.  v[0..NU) = hi units, v[NU..2NU) = lo units (raw bits carried in float4).
+// ---- pre-split weights (bd_split_bf16, once per forward).  Blocked layout: the 32 k-values (KC) / 32 rows (RC) of a
+// chunk are one 128-byte line, 64 B of bf16 hi then 64 B of lo, at split + 2*e for the fp32 element index e of the block
+// start.  A thread moves 16 bytes (8 values of one plane) straight into the LDS plane: no VALU work for this operand,
+// full-line global reads like the fp32 source, and the lane -> (row, plane) maps below make every 16-lane group of a
+// ds_write_b128 sweep all 64 banks once.
 __device__ __forceinline__ float4 ldb8_if(const unsigned short* p, bool ok) {   // 8 bf16 as raw bits in a float4
     const v4f t = *(gptr4)(ok ? (const void*)p : (const void*)kZero16);
     return make_float4(t.x, t.y, t.z, t.w);
 }
 
-// row handled by thread quad g = tid / 4 of the pre-split KC loaders: 16 consecutive lanes write rows r, r+4, r+8, r+12,
-// whose 64-byte pieces (row stride 80 B) tile one 256-byte bank sweep -> conflict-free ds_write_b128
-__device__ __forceinline__ int wrow(int tid) {
-    const int g = tid >> 2;
-    return (g & ~15) | ((g & 3) << 2) | ((g >> 2) & 3);
-}
-
-// forward-conv weights, rows = co, K order of ConvKC (channel block outer, tap inner)
+// forward-conv weights, rows = co, K order of ConvKC (channel block outer, tap inner).  Per wave instruction: 8 rows x
+// (hi, lo); quad q = lane/4: plane = (q>>2)&1, row = 4*(q&3) + (q>>3) (+2 for odd waves, +16 per wave pair, +32 per pass):
+// a 16-lane group writes rows r, r+4, r+8, r+12 of one plane (row stride 80 B -> 4 x 64 B tile 256 B of banks).
 template <int R>
 struct WgtKCs {
-    static constexpr int NI = R / 32, NU = R / 64;
+    static constexpr int NI = R / 32;
     static constexpr bool kKC = true;
-    const unsigned short *ph[NU], *pl[NU];
-    bool ok[NU];
+    const unsigned short* ptr[NI];   // split + 2*(row*ld) + plane*32 + k8
+    bool ok[NI];
     int tap, c0;
+    __device__ __forceinline__ static int row_of(int tid) {
+        const int q = (tid & 63) >> 2, w = tid >> 6;
+        return 16 * (w >> 1) + 2 * (w & 1) + 4 * (q & 3) + (q >> 3);
+    }
+    __device__ __forceinline__ static int plane_of(int tid) { return (tid >> 4) & 1; }
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
         const int k8 = (tid & 3) * 8;
         const int chunk = kbase / BK;
         tap = chunk % 9;
         c0 = (chunk / 9) * BK;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int r = row0 + wrow(tid) + 64 * u;
-            ok[u] = r < o.rows;
-            ph[u] = o.hi + (long long)r * o.ld + k8;
-            pl[u] = o.lo + (long long)r * o.ld + k8;
+        for (int i = 0; i < NI; ++i) {
+            const int r = row0 + row_of(tid) + 32 * i;
+            ok[i] = r < o.rows;
+            ptr[i] = o.split + 2 * ((long long)r * o.ld) + plane_of(tid) * 32 + k8;
         }
     }
     __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
-        const int off = tap * o.C + c0;
+        const int off = 2 * (tap * o.C + c0);
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            v[u] = ldb8_if(ph[u] + off, ok[u] && c0 < o.C);
-            v[NU + u] = ldb8_if(pl[u] + off, ok[u] && c0 < o.C);
-        }
+        for (int i = 0; i < NI; ++i) v[i] = ldb8_if(ptr[i] + off, ok[i] && c0 < o.C);
     }
     __device__ __forceinline__ void advance(const Opnd&) {
         if (++tap == 9) { tap = 0; c0 += BK; }
     }
     __device__ __forceinline__ static void store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]) {
+        unsigned short* pl = plane_of(tid) ? sl : sh;
         const int k8 = (tid & 3) * 8;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int o = (wrow(tid) + 64 * u) * LDH + k8;
-            *reinterpret_cast<float4*>(sh + o) = v[u];
-            *reinterpret_cast<float4*>(sl + o) = v[NU + u];
-        }
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(pl + (row_of(tid) + 32 * i) * LDH + k8) = v[i];
     }
 };
 
-// weights seen from dgrad (rows = ci contiguous, k = (tap, co)), LDS image [k][R + 32] like RCStore
+// weights seen from dgrad (rows = ci contiguous, k = (tap, co)), LDS image [k][R + 32] like RCStore.  A k row of the
+// tile is R/32 blocks = R*4 contiguous bytes; lane l of a 32-lane half: plane = l>>4 (R = 128), block = (l>>2)&3,
+// 8-row piece = l&3; the two halves of a wave take two k rows.  16 lanes = one plane, 256 contiguous LDS bytes.
 template <int R>
 struct WgtRCs {
-    static constexpr int NI = R / 32, NU = R / 64;
-    static constexpr int UPR = R / 8;          // 16-byte units per k row
-    static constexpr int KS = 256 / UPR;       // k rows covered per pass
+    static constexpr int NI = R / 32;
+    static constexpr int NBLK = R / 32;            // 32-row blocks per k row
+    static constexpr int LPK = 8 * NBLK;           // lanes per k row (hi + lo)
+    static constexpr int KS = 256 / LPK;           // k rows per pass
+    static constexpr int NP = BK / KS;             // passes (== NI)
     static constexpr bool kKC = false;
-    const unsigned short *ph, *pl;
+    const unsigned short* ptr;
     long long step;
     int tap, c0;
     bool ok;
+    __device__ __forceinline__ static int plane_of(int tid) { return ((tid % LPK) / (4 * NBLK)) & 1; }
+    __device__ __forceinline__ static int r8_of(int tid) { return (((tid % LPK) >> 2) % NBLK) * 32 + (tid & 3) * 8; }
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
-        const int r8 = (tid % UPR) * 8, k0 = tid / UPR;
-        ok = row0 + r8 < o.rows;
+        static_assert(NP == NI, "register budget");
+        const int k0 = tid / LPK;
+        ok = row0 + r8_of(tid) < o.rows;
         const int chunk = kbase / BK;
         tap = chunk % 9;
         c0 = (chunk / 9) * BK;
-        const long long base = (row0 + r8) + (long long)k0 * 9 * o.ld;
-        ph = o.hi + base;
-        pl = o.lo + base;
-        step = (long long)KS * 9 * o.ld;
+        const int blk = ((tid % LPK) >> 2) % NBLK;
+        ptr = o.split + 2 * ((long long)row0 + (long long)k0 * 9 * o.ld) + blk * 64 + plane_of(tid) * 32 + (tid & 3) * 8;
+        step = 2 * (long long)KS * 9 * o.ld;
     }
     __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
-        const long long q = ((long long)c0 * 9 + tap) * o.ld;
+        const long long q = 2 * (((long long)c0 * 9 + tap) * o.ld);
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            v[u] = ldb8_if(ph + q + step * u, ok && c0 < o.C);
-            v[NU + u] = ldb8_if(pl + q + step * u, ok && c0 < o.C);
-        }
+        for (int i = 0; i < NI; ++i) v[i] = ldb8_if(ptr + q + step * i, ok && c0 < o.C);
     }
     __device__ __forceinline__ void advance(const Opnd&) {
         if (++tap == 9) { tap = 0; c0 += BK; }
     }
     __device__ __forceinline__ static void store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]) {
-        const int r8 = (tid % UPR) * 8, k0 = tid / UPR;
+        unsigned short* pl = plane_of(tid) ? sl : sh;
+        const int k0 = tid / LPK;
 #pragma unroll
-        for (int u = 0; u < NU; ++u) {
-            const int o = (k0 + KS * u) * (R + 32) + r8;
-            *reinterpret_cast<float4*>(sh + o) = v[u];
-            *reinterpret_cast<float4*>(sl + o) = v[NU + u];
-        }
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(pl + (k0 + KS * i) * (R + 32) + r8_of(tid)) = v[i];
     }
 };
 
@@ -976,13 +972,14 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16x3_kernel(IGemmParams p) {
     epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi, wg.zz);
 }
 
-// the on-the-fly split, applied once to a whole buffer (weights): 8 elements per thread
-__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ src, long long n8, unsigned short* __restrict__ hi,
-                                                       unsigned short* __restrict__ lo) {
+// the on-the-fly split, applied once to a whole buffer (weights): 8 elements per thread, blocked output layout
+// (element e: hi at (e/32)*64 + e%32, lo 32 further)
+__global__ __launch_bounds__(256) void split_bf16_kernel(const float* __restrict__ src, long long n8, unsigned short* __restrict__ out) {
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < n8; i += (long long)gridDim.x * 256) {
         const float4 a = ld4(src + 8 * i), b = ld4(src + 8 * i + 4);
-        *reinterpret_cast<uint4*>(hi + 8 * i) = make_uint4(pack_hi(a.x, a.y), pack_hi(a.z, a.w), pack_hi(b.x, b.y), pack_hi(b.z, b.w));
-        *reinterpret_cast<uint4*>(lo + 8 * i) = make_uint4(pack_lo(a.x, a.y), pack_lo(a.z, a.w), pack_lo(b.x, b.y), pack_lo(b.z, b.w));
+        unsigned short* o = out + (i >> 2) * 64 + (i & 3) * 8;
+        *reinterpret_cast<uint4*>(o) = make_uint4(pack_hi(a.x, a.y), pack_hi(a.z, a.w), pack_hi(b.x, b.y), pack_hi(b.z, b.w));
+        *reinterpret_cast<uint4*>(o + 32) = make_uint4(pack_lo(a.x, a.y), pack_lo(a.z, a.w), pack_lo(b.x, b.y), pack_lo(b.z, b.w));
     }
 }
 
@@ -1070,7 +1067,7 @@ static int ilog2_exact(int v) {
 
 static Opnd make_opnd(const bd_operand& o, int rows, int K) {
     Opnd r;
-    r.p = o.p; r.hi = o.hi; r.lo = o.lo; r.ld = o.ld; r.kind = o.kind; r.vec = operand_vec_ok(o, rows, K) ? 1 : 0;
+    r.p = o.p; r.split = o.split; r.ld = o.ld; r.kind = o.kind; r.vec = operand_vec_ok(o, rows, K) ? 1 : 0;
     r.C = o.C > 0 ? o.C : 1; r.Hs = o.Hs; r.Ws = o.Ws; r.Ho = o.Ho > 0 ? o.Ho : 1; r.Wo = o.Wo > 0 ? o.Wo : 1;
     r.stride = o.stride > 0 ? o.stride : 1; r.pad_t = o.pad_t; r.pad_l = o.pad_l; r.ups = o.ups; r.rows = rows;
     const int lw = ilog2_exact(r.Wo), lh = ilog2_exact(r.Ho);
@@ -1123,8 +1120,10 @@ static const char* kClsName[] = {"generic", "conv_fwd", "conv_dgrad", "conv_wgra
 
 static bool presplit_ok(const bd_igemm_desc& d) {
     const bd_operand& o = d.B;
-    return d.mode == BD_MODE_BF16X3 && o.hi && o.lo && aligned16(o.hi) && aligned16(o.lo) && (o.ld & 7) == 0 && (d.N & 7) == 0 &&
-           d.batch_outer * d.batch_inner == 1;
+    // whole 32-element blocks: block-aligned base (the caller passes split + 2*e for a base element e % 32 == 0),
+    // ld % 32 == 0 (rows start on blocks), channel count % 32 == 0, N % 32 == 0 (RC rows come in blocks)
+    return d.mode == BD_MODE_BF16X3 && o.split && ((uintptr_t)o.split & 127) == 0 && (o.ld & 31) == 0 && (o.C & 31) == 0 &&
+           (d.N & 31) == 0 && d.batch_outer * d.batch_inner == 1;
 }
 
 static Cls classify(const bd_igemm_desc& d, bool fast) {
@@ -1247,13 +1246,13 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
 
 }  // namespace bd
 
-extern "C" int bd_split_bf16(const float* src, int64_t n, uint16_t* hi, uint16_t* lo, bd_stream_t stream) {
-    BD_CHECK(src && hi && lo && n > 0 && (n & 7) == 0, BD_ERR_INVALID, "bd_split_bf16: bad args (n %% 8 must be 0)");
-    BD_CHECK(bd::aligned16(src) && bd::aligned16(hi) && bd::aligned16(lo), BD_ERR_UNSUPPORTED, "bd_split_bf16: pointers must be 16B aligned");
+extern "C" int bd_split_bf16(const float* src, int64_t n, uint16_t* out, bd_stream_t stream) {
+    BD_CHECK(src && out && n > 0 && (n & 31) == 0, BD_ERR_INVALID, "bd_split_bf16: bad args (n %% 32 must be 0)");
+    BD_CHECK(bd::aligned16(src) && bd::aligned16(out), BD_ERR_UNSUPPORTED, "bd_split_bf16: pointers must be 16B aligned");
     const long long n8 = n / 8;
     long long nb = bd::cdiv(n8, 256);
     if (nb > 4096) nb = 4096;
-    hipLaunchKernelGGL(bd::split_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, bd::S(stream), src, n8, hi, lo);
+    hipLaunchKernelGGL(bd::split_bf16_kernel, dim3((unsigned)nb), dim3(256), 0, bd::S(stream), src, n8, out);
     BD_LAUNCH_CHECK("split_bf16");
     return BD_OK;
 }

@@ -59,7 +59,7 @@ struct Ctx {
     float* out = nullptr; int64_t ldo = 0;
     const float* dout = nullptr; int64_t lddo = 0;
     char* opws = nullptr; size_t opws_bytes = 0; size_t opws_need = 0;
-    const uint16_t* w_hi = nullptr; const uint16_t* w_lo = nullptr;   // pre-split weights (BF16X3), same offsets as params
+    const uint16_t* w_split = nullptr;   // pre-split weights (BF16X3, bd_split_bf16 layout): element e of params <-> 2*e here
     std::vector<char> ginit;
 };
 
@@ -114,7 +114,7 @@ struct bd_unet {
         int64_t n = 1; int i = 0;
         for (auto s : shape) { p.shape[i++] = s; n *= s; }
         for (; i < 4; ++i) p.shape[i] = 1;
-        nparams = (nparams + 7) / 8 * 8;  // 32-byte aligned start (16 B for the fp32 loads, 16 B for the bf16 planes)
+        nparams = (nparams + 31) / 32 * 32;  // 128-byte aligned start: float4 loads, and whole 32-element blocks of the split copy
         p.off = nparams;
         nparams += n;
         params.push_back(p);
@@ -227,13 +227,13 @@ struct bd_unet {
     }
     int conv_f(Ctx& c, bd_conv3x3_fwd_desc& d) const {
         d.workspace = c.opws; d.workspace_bytes = c.opws_bytes; d.mode = cfg.compute_mode;
-        if (c.w_hi && !c.dry) { d.w_hi = c.w_hi + (d.w - c.params); d.w_lo = c.w_lo + (d.w - c.params); }
+        if (c.w_split && !c.dry) d.w_split = c.w_split + 2 * (d.w - c.params);
         if (c.dry) { note_conv(c); return BD_OK; }
         return conv3x3_fwd(d, c.st);
     }
     int conv_d(Ctx& c, bd_conv3x3_dgrad_desc& d) const {
         d.workspace = c.opws; d.workspace_bytes = c.opws_bytes; d.mode = cfg.compute_mode;
-        if (c.w_hi && !c.dry) { d.w_hi = c.w_hi + (d.w - c.params); d.w_lo = c.w_lo + (d.w - c.params); }
+        if (c.w_split && !c.dry) d.w_split = c.w_split + 2 * (d.w - c.params);
         if (c.dry) { note_conv(c); return BD_OK; }
         return conv3x3_dgrad(d, c.st);
     }
@@ -269,7 +269,7 @@ void bd_unet::node_time_embed() {
     const int64_t pw2 = add_param("time_embedding.linear_2.weight", {T, T});
     const int64_t pb2 = add_param("time_embedding.linear_2.bias", {T});
     // batched time_emb_proj of every resnet: one [sumC, T] weight, one [sumC] bias (aliases registered per resnet)
-    nparams = (nparams + 7) / 8 * 8;
+    nparams = (nparams + 31) / 32 * 32;
     p_tw = nparams; nparams += (int64_t)sumC * T;
     p_tb = nparams; nparams += sumC;
     segs[cur_seg].hi = nparams;
@@ -829,9 +829,9 @@ extern "C" int bd_unet_param_info(const bd_unet* u, int i, const char** name, in
     if (layout) *layout = p.layout;
     return BD_OK;
 }
-// pre-split weight planes (hi then lo, nparams rounded down to 8 elements each) live behind the op workspace
-static size_t wsplit_plane_elems(const bd_unet* u) { return (size_t)(u->nparams / 8 * 8); }
-static size_t wsplit_bytes(const bd_unet* u) { return align_up(wsplit_plane_elems(u) * sizeof(uint16_t), 256) * 2; }
+// the pre-split copy of the weights (2 uint16 per parameter, whole 32-element blocks) lives behind the op workspace
+static size_t wsplit_elems(const bd_unet* u) { return (size_t)(u->nparams / 32 * 32); }
+static size_t wsplit_bytes(const bd_unet* u) { return align_up(wsplit_elems(u) * 2 * sizeof(uint16_t), 256); }
 
 extern "C" size_t bd_unet_workspace_bytes(bd_unet* u, int B, int training) {
     if (!u || B <= 0) return 0;
@@ -852,9 +852,7 @@ static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, si
     c.opws = reinterpret_cast<char*>(workspace) + align_up(fl, 256);
     c.opws_bytes = u->opws_bytes;
     if (u->cfg.compute_mode == BD_MODE_BF16X3) {
-        char* base = c.opws + align_up(u->opws_bytes, 256);
-        c.w_hi = reinterpret_cast<const uint16_t*>(base);
-        c.w_lo = reinterpret_cast<const uint16_t*>(base + wsplit_bytes(u) / 2);
+        c.w_split = reinterpret_cast<const uint16_t*>(c.opws + align_up(u->opws_bytes, 256));
     }
     c.ginit.assign(u->bufs.size(), 0);
     return BD_OK;
@@ -869,9 +867,8 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
     BD_CHECK(ldx >= u->cfg.in_channels && ldo >= u->cfg.out_channels, BD_ERR_INVALID, "bd_unet_forward: ld < channels");
     BD_CHECK(aligned16(params), BD_ERR_INVALID, "bd_unet_forward: params must be 16-byte aligned");
     c.params = params; c.x = x; c.ldx = ldx; c.t = t; c.t_stride = t_stride; c.out = out; c.ldo = ldo; c.st = S(stream);
-    if (c.w_hi)   // split the weights once; forward convs and (same workspace) the backward dgrads read the planes
-        BD_TRY(bd_split_bf16(params, (int64_t)wsplit_plane_elems(u), const_cast<uint16_t*>(c.w_hi), const_cast<uint16_t*>(c.w_lo),
-                             stream));
+    if (c.w_split)   // split the weights once; forward convs and (same workspace) the backward dgrads read the copy
+        BD_TRY(bd_split_bf16(params, (int64_t)wsplit_elems(u), const_cast<uint16_t*>(c.w_split), stream));
     for (auto& f : u->fwd) BD_TRY(f(c));
     return BD_OK;
 }

@@ -218,19 +218,20 @@ def conv3x3_fwd(x, w, bias=None, stride=1, pad=1, ups=0, asym=False, rowbias=Non
                       ld_rowbias=rowbias.stride(0) if rowbias is not None else 0, residual=L.ptr(residual),
                       ldr=_ld(residual) if residual is not None else 0, out_scale=out_scale, y=L.ptr(y), ldy=Cout,
                       workspace=L.ptr(ws), workspace_bytes=ws.numel(), mode=mode)
-    if w_split is not None:   # pre-split bf16 planes of w (split_bf16): the weight operand is staged without VALU work
-        d.w_hi, d.w_lo = L.ptr(w_split[0]), L.ptr(w_split[1])
+    if w_split is not None:   # w already split (split_bf16): the weight operand is staged without VALU work
+        d.w_split = L.ptr(w_split)
     L.check(lib.bd_conv3x3_fwd(C.byref(d), L.stream()), "bd_conv3x3_fwd")
     return y
 
 
 def split_bf16(x):
-    """(hi, lo) bf16 planes (int16 tensors) of an fp32 tensor: the split the bf16x3 kernels apply on the fly."""
+    """The bf16 hi/lo split the bf16x3 kernels apply on the fly, as one int16 tensor [numel/32, 2, 32]
+    (block, hi|lo, element): include/bd_hip.h bd_split_bf16."""
     lib = L.load(); _need_cuda(x)
     x = x.contiguous()
-    hi = torch.empty(x.shape, dtype=torch.int16, device=x.device); lo = torch.empty_like(hi)
-    L.check(lib.bd_split_bf16(L.ptr(x), x.numel(), L.ptr(hi), L.ptr(lo), L.stream()), "bd_split_bf16")
-    return hi, lo
+    out = torch.empty(x.numel() // 32, 2, 32, dtype=torch.int16, device=x.device)
+    L.check(lib.bd_split_bf16(L.ptr(x), x.numel(), L.ptr(out), L.stream()), "bd_split_bf16")
+    return out
 
 
 def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False, mode=0, w_split=None):
@@ -246,7 +247,7 @@ def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False, mode=0, w_
                         dy=L.ptr(dy), lddy=_ld(dy), w=L.ptr(w), dx=L.ptr(dx), lddx=Cin, accumulate=0,
                         workspace=L.ptr(ws), workspace_bytes=ws.numel(), mode=mode)
     if w_split is not None:
-        d.w_hi, d.w_lo = L.ptr(w_split[0]), L.ptr(w_split[1])
+        d.w_split = L.ptr(w_split)
     L.check(lib.bd_conv3x3_dgrad(C.byref(d), L.stream()), "bd_conv3x3_dgrad")
     return dx
 

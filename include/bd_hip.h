@@ -177,10 +177,10 @@ typedef struct {
     const float* p; int64_t ld;
     int64_t bs_outer, bs_inner;   /* batch strides (elements)                                   */
     int C, Hs, Ws, Ho, Wo, stride, pad_t, pad_l, ups;   /* conv geometry (CONV/TCONV/WGT)       */
-    const uint16_t* hi; const uint16_t* lo;   /* optional, BD_MODE_BF16X3 only: the same operand already split
-                                                 into bf16 planes by bd_split_bf16 (same indexing and ld as p);
-                                                 used where the engine has a loader for it (weights of conv
-                                                 fwd / dgrad), ignored otherwise -- p must always be valid  */
+    const uint16_t* split;   /* optional, BD_MODE_BF16X3 only: the same buffer already split into bf16 hi/lo by
+                                bd_split_bf16 (blocked layout below; element e of p <-> e of split); used where the
+                                engine has a loader for it (weights of conv fwd / dgrad), ignored otherwise -- p must
+                                always be valid                                                               */
 } bd_operand;
 typedef struct {
     bd_operand A, B;
@@ -200,9 +200,11 @@ typedef struct {
                                                 wgrad, A = dY^T); needs DENSE row-contiguous A, batch 1 */
 } bd_igemm_desc;
 size_t bd_igemm_workspace_bytes(const bd_igemm_desc* d);
-/* hi[i] = bf16 truncation of src[i], lo[i] = bf16 RNE of (src[i] - hi[i]): exactly the split the BF16X3 kernels apply
- * on the fly.  n % 8 == 0, 16-byte aligned pointers.  Run once per optimizer step over the flat weight buffer.  */
-int bd_split_bf16(const float* src, int64_t n, uint16_t* hi, uint16_t* lo, bd_stream_t stream);
+/* Split an fp32 buffer into bf16 hi/lo exactly as the BF16X3 kernels do on the fly: hi = bf16 truncation of x,
+ * lo = bf16 RNE of (x - hi).  Blocked layout, 2n uint16: for element e, hi at out[(e/32)*64 + e%32] and lo 32 entries
+ * further -- one 32-element K chunk of a row is one 128-byte line (64 B hi | 64 B lo), as wide as its fp32 source.
+ * n % 32 == 0, 16-byte aligned pointers.  Run once per forward over the flat weight buffer (bd_unet_forward).   */
+int bd_split_bf16(const float* src, int64_t n, uint16_t* out, bd_stream_t stream);
 int bd_igemm(const bd_igemm_desc* d, bd_stream_t stream);
 
 /* Convenience wrappers over bd_igemm (all NHWC(ld), weights [Cout][3][3][Cin]).
@@ -222,7 +224,7 @@ typedef struct {
     float* y; int64_t ldy;
     void* workspace; size_t workspace_bytes;
     int mode;                                   /* bd_compute_mode */
-    const uint16_t* w_hi; const uint16_t* w_lo; /* optional pre-split planes of w (bd_split_bf16)       */
+    const uint16_t* w_split;                    /* optional: w already split by bd_split_bf16           */
 } bd_conv3x3_fwd_desc;
 int bd_conv3x3_fwd(const bd_conv3x3_fwd_desc* d, bd_stream_t stream);
 
@@ -233,7 +235,7 @@ typedef struct {
     float* dx; int64_t lddx; int accumulate;   /* dx over the (virtual, upsampled) input grid   */
     void* workspace; size_t workspace_bytes;
     int mode;                                   /* bd_compute_mode */
-    const uint16_t* w_hi; const uint16_t* w_lo; /* optional pre-split planes of w (bd_split_bf16)       */
+    const uint16_t* w_split;                    /* optional: w already split by bd_split_bf16           */
 } bd_conv3x3_dgrad_desc;
 int bd_conv3x3_dgrad(const bd_conv3x3_dgrad_desc* d, bd_stream_t stream);
 

@@ -352,7 +352,8 @@ def test_conv3x3_bf16x3(ops, B, H, Cin, Cout, stride, pad, ups, asym):
 
 def test_split_bf16_planes(ops):
     x = R(1, 4096) * torch.logspace(-6, 6, 4096)
-    hi, lo = ops.split_bf16(dev(x))
+    sp = ops.split_bf16(dev(x))
+    hi, lo = sp[:, 0].reshape(-1), sp[:, 1].reshape(-1)     # blocked layout [block, hi|lo, 32]
     bits = x.view(torch.int32)
     assert torch.equal(hi.cpu().int() & 0xFFFF, (bits >> 16) & 0xFFFF)            # hi = truncated bf16
     hif = ((hi.cpu().int() & 0xFFFF) << 16).view(torch.float32); lof = ((lo.cpu().int() & 0xFFFF) << 16).view(torch.float32)
