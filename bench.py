@@ -19,6 +19,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 import torch.distributed as dist
 
@@ -133,14 +134,63 @@ def cpu_baseline(seconds_budget=40.0):
                       f"budget {seconds_budget:.0f} s)"}
 
 
+def bench_sampling(args, world, rank, dev):
+    """SURVEY 8(d) sampling metric: the full DDIM-50 / DDPM-1000 loop (UNet forward + scheduler step per timestep) over one
+    chunk of --batch initial noises per GPU; chains are independent, ranks shard the rows, no collective (8e)."""
+    from baddiffusion_amd.model import KNOWN_TOPOLOGIES
+    from baddiffusion_amd.pipelines import DDIMPipeline, DDPMPipeline
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.unet import UNet2DModel
+    model = UNet2DModel(**KNOWN_TOPOLOGIES["google/ddpm-cifar10-32"], compute_mode=args.mode).to(dev)
+    n = args.batch if args.batch > 0 else 512
+    ddim = args.workload == "ddim50"
+    steps = 50 if ddim else 1000
+    pipe = (DDIMPipeline if ddim else DDPMPipeline)(model, DDPMScheduler(num_train_timesteps=1000))
+    pipe.set_progress_bar_config(disable=True) if hasattr(pipe, "set_progress_bar_config") else None
+    init = torch.randn(n, 3, 32, 32, generator=torch.Generator().manual_seed(rank)).to(dev)
+    gen = torch.Generator(device=dev).manual_seed(1 + rank)
+    pipe(batch_size=n, init=init[:min(n, 64)], generator=gen, num_inference_steps=min(steps, 5), output_type=None)   # warm-up
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    out = pipe(batch_size=n, init=init, generator=gen, num_inference_steps=steps, output_type=None)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+        dist.destroy_process_group()
+    if rank == 0:
+        img = out.images
+        gf = 12.444 * steps                               # GFLOP per sample (BASELINE.md section 2)
+        print(json.dumps({
+            "metric": f"{'DDIM 50' if ddim else 'DDPM 1000'}-step samples/sec (32x32 UNet, DDPM-CIFAR10-32 topology)",
+            "value": world * n / dt, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": 5,
+            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if args.mode == "f32" else "f32 (split-bf16 hi+lo products, fp32 accumulate)",
+            "data": "synthetic (seeded N(0,1) init, seeded default-init weights)",
+            "config": {"workload": f"BASELINE configs[4]-style sampling: {steps}-step {'DDIM (eta 0)' if ddim else 'DDPM'} loop, "
+                                   f"{n} samples per GPU in one chunk, images to float NHWC at the end, no PNG I/O",
+                       "global_batch": world * n, "parallelism": f"replicas x{world} (rows sharded, no collective)"},
+            "seconds_per_loop": dt, "step_tflops": gf * n * world / dt / 1e3,
+            "frac_of_fp32_mfma_peak": gf * n / dt / 1e3 / FP32_MFMA_PEAK_TFLOPS,
+            "images_finite": bool(np.isfinite(np.asarray(img)).all())}))
+    return 0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 128 for cifar, 4 for celeba)")
-    ap.add_argument("--workload", default="cifar", choices=["cifar", "celeba"],
-                    help="cifar = BASELINE configs[1] (the metric); celeba = the 256x256 DDPM-CELEBA-HQ-256 topology (side measurement)")
+    ap.add_argument("--workload", default="cifar", choices=["cifar", "celeba", "ddim50", "ddpm1000"],
+                    help="cifar = BASELINE configs[1] (the metric); celeba = the 256x256 DDPM-CELEBA-HQ-256 topology; "
+                         "ddim50 / ddpm1000 = CIFAR sampling loops (samples/s, --batch samples per GPU, --steps ignored) -- side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--mode", default=os.environ.get("BD_COMPUTE_MODE", "bf16x3"), choices=["f32", "bf16x3"],
@@ -176,6 +226,8 @@ def main():
     # DDPM-CIFAR10-32 topology, torch default init with seed 0 (no hub weights offline)
     torch.manual_seed(0)
     from baddiffusion_amd.model import KNOWN_TOPOLOGIES
+    if args.workload in ("ddim50", "ddpm1000"):
+        return bench_sampling(args, world, rank, dev)
     celeba = args.workload == "celeba"      # BASELINE configs[3] topology (256x256, 113.7 M params), a side measurement
     topo = KNOWN_TOPOLOGIES["google/ddpm-ema-celebahq-256" if celeba else "google/ddpm-cifar10-32"]
     S_IMG = topo["sample_size"]
