@@ -21,6 +21,7 @@ SOURCES = [  # (file, extra flags)
     ("groupnorm.hip", []),
     ("igemm.hip", []),
     ("conv.cpp", ["-x", "hip"]),
+    ("conv_thin.hip", []),
     ("unet_plan.cpp", ["-x", "hip"]),
     ("prof.cpp", ["-x", "hip"]),
 ]

@@ -55,9 +55,15 @@ int conv3x3_dgrad(const bd_conv3x3_dgrad_desc& d, hipStream_t st) {
     return igemm_launch(g, st);
 }
 
+int conv3x3_wgrad_thin(const bd_conv3x3_wgrad_desc& d, hipStream_t st);   // conv_thin.hip
+
 int conv3x3_wgrad(const bd_conv3x3_wgrad_desc& d, hipStream_t st) {
     BD_TRY(conv_geom_check("conv3x3_wgrad", d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.stride, d.ups, d.Ho, d.Wo));
     BD_CHECK(d.x && d.dy && d.dw, BD_ERR_INVALID, "conv3x3_wgrad: null pointer");
+    {   // 3-channel conv_in / conv_out: direct streaming kernels instead of a 90 %-padded MFMA tile
+        const int thin = conv3x3_wgrad_thin(d, st);
+        if (thin != 0) return thin < 0 ? thin : (int)BD_OK;
+    }
     bd_igemm_desc g = {};
     g.A.kind = BD_OPK_DENSE; g.A.kc = 0; g.A.p = d.dy; g.A.ld = d.lddy;
     g.B.kind = BD_OPK_CONV; g.B.kc = 0; g.B.p = d.x; g.B.ld = d.ldx;

@@ -31,7 +31,7 @@ def workspace(nbytes, device, tag="default"):
 
 def _ld(t):
     """leading dimension (elements between rows) of a [..., C] tensor whose last dim is contiguous."""
-    assert t.stride(-1) == 1
+    assert t.size(-1) == 1 or t.stride(-1) == 1     # (the stride of a size-1 dimension is arbitrary)
     return t.stride(-2) if t.dim() >= 2 else t.shape[-1]
 
 

@@ -217,6 +217,8 @@ CONV_CASES = [  # B, H, Cin, Cout, stride, pad, ups, asym
     (2, 8, 128, 128, 2, 1, 0, False), (2, 4, 128, 128, 1, 1, 1, False), (2, 16, 3, 128, 1, 1, 0, False),
     (2, 16, 128, 3, 1, 1, 0, False), (1, 4, 512, 256, 1, 1, 0, False), (2, 9, 36, 20, 1, 1, 0, False),
     (130, 4, 64, 64, 1, 1, 0, False),
+    # thin convs (3 or 1 channels on one side, 128-multiples on the other): direct wgrad kernels (conv_thin.hip)
+    (3, 10, 3, 256, 1, 1, 0, False), (1, 40, 256, 3, 1, 1, 0, False), (2, 12, 1, 128, 1, 1, 0, False), (5, 32, 3, 128, 1, 1, 0, False),
 ]
 
 
