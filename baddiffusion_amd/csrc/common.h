@@ -27,6 +27,15 @@ void set_error(const char* fmt, ...);
         }                                                                             \
     } while (0)
 
+#define BD_HIP_TRY(expr)                                                                   \
+    do {                                                                                   \
+        hipError_t e__ = (expr);                                                           \
+        if (e__ != hipSuccess) {                                                           \
+            ::bd::set_error("%s failed: %s", #expr, hipGetErrorString(e__));               \
+            return BD_ERR_LAUNCH;                                                          \
+        }                                                                                  \
+    } while (0)
+
 #define BD_TRY(expr)                  \
     do {                              \
         int s__ = (expr);             \

@@ -59,6 +59,11 @@ struct Ctx {
     float* out = nullptr; int64_t ldo = 0;
     const float* dout = nullptr; int64_t lddo = 0;
     char* opws = nullptr; size_t opws_bytes = 0; size_t opws_need = 0;
+    // weight-gradient side stream (backward only): wgrad GEMMs feed nothing but the optimizer, so they run on a second
+    // stream next to the dgrad / GroupNorm chain that the rest of backward waits for; forked per launch, joined at the
+    // end of every node (scratch buffers are reused by the next node).  Null = everything on `st`.
+    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+    char* opws2 = nullptr; bool w_pending = false;
     const uint16_t* w_split = nullptr;   // pre-split weights (BF16X3, bd_split_bf16 layout): element e of params <-> 2*e here
     std::vector<char> ginit;
 };
@@ -71,6 +76,9 @@ using namespace bd;
 
 struct bd_unet {
     bd_unet_config cfg;
+    hipStream_t aux_stream = nullptr;              // created on the first backward (plan creation stays host-only)
+    hipEvent_t aux_ev_fork = nullptr, aux_ev_join = nullptr;
+    int aux_enabled = 1;
     std::vector<Buf> bufs;
     std::vector<Param> params;
     int64_t nparams = 0;
@@ -142,6 +150,22 @@ struct bd_unet {
     float* BP(Ctx& c, int b) const { return c.ws + bufs[b].off; }
     static int64_t rows(const Ctx& c, const View& v) { return (int64_t)c.B * v.H * v.W; }
 
+    // enqueue a weight-gradient launch on the side stream (after everything enqueued on c.st so far)
+    template <class F>
+    int on_aux(Ctx& c, F&& launch) const {
+        if (!c.st2 || c.dry) return launch(c.st, c.opws);
+        BD_HIP_TRY(hipEventRecord(c.ev_fork, c.st));
+        BD_HIP_TRY(hipStreamWaitEvent(c.st2, c.ev_fork, 0));
+        c.w_pending = true;
+        return launch(c.st2, c.opws2);
+    }
+    static int aux_join(Ctx& c) {
+        if (!c.w_pending) return BD_OK;
+        BD_HIP_TRY(hipEventRecord(c.ev_join, c.st2));
+        BD_HIP_TRY(hipStreamWaitEvent(c.st, c.ev_join, 0));
+        c.w_pending = false;
+        return BD_OK;
+    }
     int igemm(Ctx& c, bd_igemm_desc& g) const {
         g.workspace = c.opws; g.workspace_bytes = c.opws_bytes; g.mode = cfg.compute_mode;
         if (c.dry) {
@@ -181,7 +205,9 @@ struct bd_unet {
         g.A = dense(dY, lddy, 0); g.B = dense(X, ldx, 0);
         g.M = N; g.N = K; g.K = M; g.batch_outer = g.batch_inner = 1;
         g.C = dW; g.ldc = K; g.alpha = 1.f; g.out_scale = 1.f; g.a_colsum = db;
-        return igemm(c, g);
+        if (c.dry) return igemm(c, g);
+        g.workspace_bytes = c.opws_bytes; g.mode = cfg.compute_mode;
+        return on_aux(c, [&](hipStream_t st, char* ws) { g.workspace = ws; return igemm_launch(g, st); });
     }
     int colsum(Ctx& c, const float* x, int64_t ldx, int64_t nrows, int N, int64_t rpg, float* out, int64_t ldo) const {
         if (c.dry) return BD_OK;
@@ -240,7 +266,7 @@ struct bd_unet {
     int conv_w(Ctx& c, bd_conv3x3_wgrad_desc& d) const {
         d.workspace = c.opws; d.workspace_bytes = c.opws_bytes; d.mode = cfg.compute_mode;
         if (c.dry) { note_conv(c); return BD_OK; }
-        return conv3x3_wgrad(d, c.st);
+        return on_aux(c, [&](hipStream_t st, char* ws) { d.workspace = ws; return conv3x3_wgrad(d, st); });
     }
     static void note_conv(Ctx& c) {
         size_t n = bd_conv3x3_workspace_bytes(0, 0, 0, 0, 0, 0, 0, 0);
@@ -810,7 +836,21 @@ extern "C" int bd_unet_create(const bd_unet_config* cfg, bd_unet** out) {
     *out = u;
     return BD_OK;
 }
-extern "C" void bd_unet_destroy(bd_unet* u) { delete u; }
+extern "C" void bd_unet_destroy(bd_unet* u) {
+    if (!u) return;
+    if (u->aux_stream) {
+        (void)hipStreamSynchronize(u->aux_stream);
+        (void)hipEventDestroy(u->aux_ev_fork);
+        (void)hipEventDestroy(u->aux_ev_join);
+        (void)hipStreamDestroy(u->aux_stream);
+    }
+    delete u;
+}
+extern "C" int bd_unet_set_aux_stream(bd_unet* u, int enabled) {
+    BD_CHECK(u, BD_ERR_INVALID, "bd_unet_set_aux_stream: null plan");
+    u->aux_enabled = enabled ? 1 : 0;
+    return BD_OK;
+}
 extern "C" int bd_unet_set_compute_mode(bd_unet* u, int mode) {
     BD_CHECK(u && (mode == BD_MODE_F32 || mode == BD_MODE_BF16X3), BD_ERR_INVALID, "bd_unet_set_compute_mode: bad arguments");
     u->cfg.compute_mode = mode;
@@ -837,7 +877,7 @@ extern "C" size_t bd_unet_workspace_bytes(bd_unet* u, int B, int training) {
     if (!u || B <= 0) return 0;
     u->layout(B, training);
     return (size_t)(u->value_floats + u->grad_floats + u->scratch_floats) * sizeof(float) + u->opws_bytes + 256 +
-           wsplit_bytes(u);
+           wsplit_bytes(u) + (training ? align_up(u->opws_bytes, 256) : 0);   // + the side stream's op workspace
 }
 
 static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, size_t workspace_bytes) {
@@ -854,6 +894,7 @@ static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, si
     if (u->cfg.compute_mode == BD_MODE_BF16X3) {
         c.w_split = reinterpret_cast<const uint16_t*>(c.opws + align_up(u->opws_bytes, 256));
     }
+    c.opws2 = c.opws + align_up(u->opws_bytes, 256) + wsplit_bytes(u);
     c.ginit.assign(u->bufs.size(), 0);
     return BD_OK;
 }
@@ -891,6 +932,16 @@ extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float*
     BD_CHECK(seg >= -1 && seg < (int)u->segs.size(), BD_ERR_INVALID, "bd_unet_backward: segment %d out of range", seg);
     c.params = params; c.grads = grads; c.dout = dout; c.lddo = lddo; c.st = S(stream);
     c.x = x; c.ldx = ldx;   // conv_in wgrad re-reads the forward input
+    if (u->aux_enabled) {
+        if (!u->aux_stream) {
+            int lo = 0, hi = 0;
+            BD_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lowest priority: the dgrad chain is the critical path
+            BD_HIP_TRY(hipStreamCreateWithPriority(&u->aux_stream, hipStreamNonBlocking, lo));
+            BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_fork, hipEventDisableTiming));
+            BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join, hipEventDisableTiming));
+        }
+        c.st2 = u->aux_stream; c.ev_fork = u->aux_ev_fork; c.ev_join = u->aux_ev_join;
+    }
     // grad-init flags must reflect everything executed before this segment: replay them (host-only)
     for (auto it = u->bwd.rbegin(); it != u->bwd.rend(); ++it) {
         if (seg >= 0 && it->seg > seg) break;
@@ -900,6 +951,7 @@ extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float*
         int s = it->fn(c);
         c.dry = keep;
         if (s != BD_OK) return s;
+        if (run) BD_TRY(bd_unet::aux_join(c));   // the next node reuses the scratch buffers the wgrads read
     }
     if (seg >= 0) {
         if (ready_lo) *ready_lo = u->segs[seg].lo;

@@ -156,6 +156,8 @@ class UNet2DModel(nn.Module):
             L.check(lib.bd_unet_param_info(h, i, C.byref(name), C.byref(off), C.byref(rank), shp, C.byref(lay)))
             self._table[name.value.decode()] = (off.value, tuple(shp[: rank.value]), lay.value)
         self.num_flat = lib.bd_unet_num_params(h)
+        if os.environ.get("BD_AUX_STREAM", "1") == "0":
+            lib.bd_unet_set_aux_stream(h, 0)
         self.flat = nn.Parameter(torch.zeros(self.num_flat))
         self._segments = None
         self._ws_pool = {}
@@ -174,6 +176,11 @@ class UNet2DModel(nn.Module):
         """'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16, ~2^-16 relative per product, 3 MFMAs on the bf16 pipe)."""
         L.check(self._lib.bd_unet_set_compute_mode(self._plan, COMPUTE_MODES[mode]), "bd_unet_set_compute_mode")
         self.compute_mode = mode
+        return self
+
+    def set_aux_stream(self, enabled=True):
+        """weight-gradient GEMMs of backward on the plan's second stream (default on); BD_AUX_STREAM=0 turns it off."""
+        L.check(self._lib.bd_unet_set_aux_stream(self._plan, int(bool(enabled))), "bd_unet_set_aux_stream")
         return self
 
     def _logical_view(self, flat, key):

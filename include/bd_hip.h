@@ -328,6 +328,9 @@ int bd_unet_backward(bd_unet* u, int B, const float* params, const float* x, int
 /* backward split in `bd_unet_num_segments` contiguous-in-time segments so the caller can overlap a
  * gradient all-reduce with the rest of backward: after segment s, grads in
  * [seg_lo[s], seg_hi[s]) (elements) are final. */
+/* Backward runs the weight-gradient GEMMs on a second, low-priority stream owned by the plan (forked from / joined to
+ * `stream` with events, once per node -- still hipGraph-capturable and free of host synchronisation).  0 disables it. */
+int bd_unet_set_aux_stream(bd_unet* u, int enabled);
 int bd_unet_num_segments(const bd_unet* u);
 int bd_unet_segment_range(const bd_unet* u, int seg, int64_t* lo, int64_t* hi);   /* host-only query */
 int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float* params, const float* x, int64_t ldx,
