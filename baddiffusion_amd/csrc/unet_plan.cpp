@@ -60,10 +60,11 @@ struct Ctx {
     const float* dout = nullptr; int64_t lddo = 0;
     char* opws = nullptr; size_t opws_bytes = 0; size_t opws_need = 0;
     // weight-gradient side stream (backward only): wgrad GEMMs feed nothing but the optimizer, so they run on a second
-    // stream next to the dgrad / GroupNorm chain that the rest of backward waits for; forked per launch, joined at the
-    // end of every node (scratch buffers are reused by the next node).  Null = everything on `st`.
-    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-    char* opws2 = nullptr; bool w_pending = false;
+    // stream next to the dgrad / GroupNorm chain that the rest of backward waits for.  Forked per launch; the scratch
+    // arena alternates between nodes (group parity), so node k's wgrads may still run during node k+1 and are joined
+    // before node k+2 reuses their arena (and at the end of every backward call).  Null = everything on `st`.
+    hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
+    char* opws2 = nullptr; int par = 0; bool launched = false, pend[2] = {false, false};
     const uint16_t* w_split = nullptr;   // pre-split weights (BF16X3, bd_split_bf16 layout): element e of params <-> 2*e here
     std::vector<char> ginit;
 };
@@ -77,13 +78,13 @@ using namespace bd;
 struct bd_unet {
     bd_unet_config cfg;
     hipStream_t aux_stream = nullptr;              // created on the first backward (plan creation stays host-only)
-    hipEvent_t aux_ev_fork = nullptr, aux_ev_join = nullptr;
+    hipEvent_t aux_ev_fork = nullptr, aux_ev_join[2] = {nullptr, nullptr};
     int aux_enabled = 1;
     std::vector<Buf> bufs;
     std::vector<Param> params;
     int64_t nparams = 0;
     std::vector<Step> fwd;
-    struct BStep { Step fn; int seg; };
+    struct BStep { Step fn; int seg; int group; };
     std::vector<BStep> bwd;  // in FORWARD emission order; executed reversed
     struct Seg { int64_t lo, hi; };
     std::vector<Seg> segs;   // indexed by segment id (backward order)
@@ -142,7 +143,7 @@ struct bd_unet {
         params.push_back(p);
     }
     void F(Step s) { fwd.push_back(std::move(s)); }
-    void Bk(Step s) { bwd.push_back({std::move(s), cur_seg}); }
+    void Bk(Step s) { bwd.push_back({std::move(s), cur_seg, cur_group}); }
 
     // ---------------------------------------------------------------- run-time helpers
     float* VP(Ctx& c, const View& v) const { return c.ws + bufs[v.buf].off + v.coff; }
@@ -156,14 +157,21 @@ struct bd_unet {
         if (!c.st2 || c.dry) return launch(c.st, c.opws);
         BD_HIP_TRY(hipEventRecord(c.ev_fork, c.st));
         BD_HIP_TRY(hipStreamWaitEvent(c.st2, c.ev_fork, 0));
-        c.w_pending = true;
+        c.launched = true;
         return launch(c.st2, c.opws2);
     }
-    static int aux_join(Ctx& c) {
-        if (!c.w_pending) return BD_OK;
-        BD_HIP_TRY(hipEventRecord(c.ev_join, c.st2));
-        BD_HIP_TRY(hipStreamWaitEvent(c.st, c.ev_join, 0));
-        c.w_pending = false;
+    // before a node of scratch parity p starts: wgrads of the previous node with that parity must be done
+    static int aux_wait(Ctx& c, int p) {
+        if (!c.pend[p]) return BD_OK;
+        BD_HIP_TRY(hipStreamWaitEvent(c.st, c.ev_join[p], 0));
+        c.pend[p] = false;
+        return BD_OK;
+    }
+    // after a node: mark the completion point of the wgrads it enqueued
+    static int aux_mark(Ctx& c, int p) {
+        if (!c.launched) return BD_OK;
+        BD_HIP_TRY(hipEventRecord(c.ev_join[p], c.st2));
+        c.pend[p] = true; c.launched = false;
         return BD_OK;
     }
     int igemm(Ctx& c, bd_igemm_desc& g) const {
@@ -790,15 +798,17 @@ void bd_unet::layout(int B, int training) {
     grad_floats = training ? g : 0;
     const int64_t base = value_floats + grad_floats;
     int64_t smax = 0;
-    {
+    for (int pass = 0; pass < 2; ++pass) {   // two arenas, chosen by node (group) parity: see Ctx::st2
         int cur = -1; int64_t s = 0;
         for (auto& b : bufs) if (b.region == R_SCRATCH) {
             if (b.group != cur) { cur = b.group; s = 0; }
-            b.off = base + s; s += al(b.per_sample * B + b.fixed);
-            if (s > smax) smax = s;
+            const int64_t n = al(b.per_sample * B + b.fixed);
+            if (pass == 0) { if (s + n > smax) smax = s + n; }
+            else b.off = base + (b.group & 1) * smax + s;
+            s += n;
         }
     }
-    scratch_floats = training ? smax : 0;
+    scratch_floats = training ? 2 * smax : 0;
     // op workspace: dry-run every step
     Ctx c;
     c.dry = true; c.B = B; c.ws = nullptr; c.ginit.assign(bufs.size(), 0);
@@ -841,7 +851,8 @@ extern "C" void bd_unet_destroy(bd_unet* u) {
     if (u->aux_stream) {
         (void)hipStreamSynchronize(u->aux_stream);
         (void)hipEventDestroy(u->aux_ev_fork);
-        (void)hipEventDestroy(u->aux_ev_join);
+        (void)hipEventDestroy(u->aux_ev_join[0]);
+        (void)hipEventDestroy(u->aux_ev_join[1]);
         (void)hipStreamDestroy(u->aux_stream);
     }
     delete u;
@@ -938,9 +949,10 @@ extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float*
             BD_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lowest priority: the dgrad chain is the critical path
             BD_HIP_TRY(hipStreamCreateWithPriority(&u->aux_stream, hipStreamNonBlocking, lo));
             BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_fork, hipEventDisableTiming));
-            BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join, hipEventDisableTiming));
+            BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join[0], hipEventDisableTiming));
+            BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join[1], hipEventDisableTiming));
         }
-        c.st2 = u->aux_stream; c.ev_fork = u->aux_ev_fork; c.ev_join = u->aux_ev_join;
+        c.st2 = u->aux_stream; c.ev_fork = u->aux_ev_fork; c.ev_join[0] = u->aux_ev_join[0]; c.ev_join[1] = u->aux_ev_join[1];
     }
     // grad-init flags must reflect everything executed before this segment: replay them (host-only)
     for (auto it = u->bwd.rbegin(); it != u->bwd.rend(); ++it) {
@@ -948,11 +960,15 @@ extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float*
         const bool run = seg < 0 || it->seg == seg;
         const bool keep = c.dry;
         c.dry = !run;           // earlier segments: flags only
+        const int par = it->group & 1;
+        if (run) BD_TRY(bd_unet::aux_wait(c, par));   // this node reuses the scratch arena of parity `par`
         int s = it->fn(c);
         c.dry = keep;
         if (s != BD_OK) return s;
-        if (run) BD_TRY(bd_unet::aux_join(c));   // the next node reuses the scratch buffers the wgrads read
+        if (run) BD_TRY(bd_unet::aux_mark(c, par));
     }
+    BD_TRY(bd_unet::aux_wait(c, 0));   // every weight gradient of this call is ordered before what the caller enqueues next
+    BD_TRY(bd_unet::aux_wait(c, 1));
     if (seg >= 0) {
         if (ready_lo) *ready_lo = u->segs[seg].lo;
         if (ready_hi) *ready_hi = u->segs[seg].hi;
