@@ -179,6 +179,41 @@ def test_celeba_full_resolution_modes_agree(bd):
     assert relerr(res["bf16x3"][1], res["f32"][1]) < 1e-3
 
 
+def test_forward_backward_hipgraph_capture(bd):
+    """the C ABI only enqueues on the given stream (and, in backward, on the plan's side stream forked / joined with
+    events): a whole forward + backward is capturable in a HIP graph and replays to the same bits as the eager run"""
+    unet, ops = bd
+    cfg = C.SMALL_CFGS["small"]
+    m = make_model(unet, cfg, 7)
+    x = torch.randn(2, 16, 16, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    t = torch.tensor([10, 900]).cuda()
+    dout = torch.randn(2, 16, 16, 3, generator=torch.Generator().manual_seed(2)).cuda()
+    ws = torch.empty(m.workspace_bytes(2, True), dtype=torch.uint8, device="cuda")
+    out_e = torch.empty(2, 16, 16, 3, device="cuda"); g_e = torch.zeros(m.num_flat, device="cuda")
+    out_g = torch.empty_like(out_e); g_g = torch.zeros_like(g_e)
+    from baddiffusion_amd import _lib as L
+    lib = L.load()
+
+    def run(out, grads):
+        L.check(lib.bd_unet_forward(m._plan, 2, 1, m.flat.data_ptr(), x.data_ptr(), 3, t.data_ptr(), 1, out.data_ptr(), 3,
+                                    ws.data_ptr(), ws.numel(), L.stream()), "fwd")
+        L.check(lib.bd_unet_backward(m._plan, 2, m.flat.data_ptr(), x.data_ptr(), 3, dout.data_ptr(), 3, grads.data_ptr(),
+                                     ws.data_ptr(), ws.numel(), L.stream()), "bwd")
+
+    run(out_e, g_e)                      # eager (also creates the plan's side stream outside of the capture)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        run(out_g, g_g)
+    out_g.zero_(); g_g.fill_(123.0)   # padding elements between tensors are never written
+    graph.replay()
+    torch.cuda.synchronize()
+    assert torch.equal(out_g, out_e)
+    written = g_g != 123.0
+    assert int(written.sum()) >= m.num_flat - 64 * len(m.state_dict())   # everything but alignment padding was rewritten
+    assert torch.equal(g_g[written], g_e[written])
+
+
 def test_backward_segments_equal_whole(bd):
     """bd_unet_backward_segment over all segments == bd_unet_backward (the DP overlap path)."""
     unet, ops = bd
