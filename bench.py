@@ -295,6 +295,30 @@ def main():
     final_loss = float(loss)
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
 
+    def read_classes():
+        cl = []
+        for c in range(lib.bd_prof_num_classes()):
+            name = ctypes.c_char_p(); n = ctypes.c_int64(); tms = ctypes.c_double(); fl = ctypes.c_double(); by = ctypes.c_double()
+            lib.bd_prof_get(c, ctypes.byref(name), ctypes.byref(n), ctypes.byref(tms), ctypes.byref(fl), ctypes.byref(by))
+            cl.append({"kernel": name.value.decode(), "launches": n.value, "ms": tms.value, "flops": fl.value, "bytes": by.value})
+        cl.sort(key=lambda c: -c["ms"])
+        return cl
+
+    classes, classes_iso = [], []
+    if not args.no_prof:
+        classes = read_classes()
+        # In the timed region the weight-gradient GEMMs share the chip with the dgrad / GroupNorm chain (side stream), so
+        # their per-launch durations there include that sharing.  Two extra UNTIMED steps with the side stream off give
+        # the kernels' stand-alone durations (every rank runs them: the DP collectives must stay matched).
+        lib.bd_unet_set_aux_stream(model._plan, 0)
+        lib.bd_prof_reset(); lib.bd_prof_enable(1)
+        for i in range(2):
+            step(args.warmup + args.steps + i)
+        lib.bd_prof_enable(0)
+        barrier()
+        classes_iso = read_classes()
+        lib.bd_unet_set_aux_stream(model._plan, 1)
+
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
@@ -320,12 +344,6 @@ def main():
                "step_frac_of_fp32_mfma_peak": gflop_img * B / (ms * 1e-3) / 1e3 / FP32_MFMA_PEAK_TFLOPS,
                "step_frac_of_hbm_roofline": hbm_floor_ms / ms}
         if not args.no_prof:
-            classes = []
-            for c in range(lib.bd_prof_num_classes()):
-                name = ctypes.c_char_p(); n = ctypes.c_int64(); tms = ctypes.c_double(); fl = ctypes.c_double(); by = ctypes.c_double()
-                lib.bd_prof_get(c, ctypes.byref(name), ctypes.byref(n), ctypes.byref(tms), ctypes.byref(fl), ctypes.byref(by))
-                classes.append({"kernel": name.value.decode(), "launches": n.value, "ms": tms.value, "flops": fl.value, "bytes": by.value})
-            classes.sort(key=lambda c: -c["ms"])
             if classes:
                 d = classes[0]
                 ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
@@ -343,6 +361,12 @@ def main():
                                    "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                                    "alg_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
                                    "share_of_step": d["ms"] / prof_steps / ms}
+                iso = next((c for c in classes_iso if c["kernel"] == d["kernel"]), None)
+                if iso:   # the same kernel class with the side stream off (stand-alone launch durations, untimed steps)
+                    ai = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
+                    out["roofline"]["standalone"] = {"achieved": ai, "frac": ai / peak, "avg_launch_us": iso["ms"] * 1e3 / iso["launches"],
+                                                     "note": "2 extra untimed steps with bd_unet_set_aux_stream(0): no overlap with other kernels"}
+                out["kernel_classes_standalone"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in classes_iso]
                 out["kernel_classes"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in classes]
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores) ...")
