@@ -507,7 +507,9 @@ struct ConvRC : RCStore<R, TR> {
     static constexpr int KS = RCMap<R, TR>::KSTEP;
     static constexpr bool kKC = false;
     int kh, kw, ci, pix, Kp;
-    bool ok;
+    bool ok, same;
+    const float* ptr;      // "same" geometry: address of input pixel (pix + dtap), channel ci
+    long long step, adv;   // KS * ld, BK * ld
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int K) {
         const int r4 = RCMap<R, TR>::r4(tid), k0 = RCMap<R, TR>::kfirst(tid);
         const int r = row0 + r4;
@@ -518,8 +520,25 @@ struct ConvRC : RCStore<R, TR> {
         ok = r < o.rows;
         pix = kbase + k0;
         Kp = K;
+        // stride-1 "same" convolutions (all but the 6 resampling layers): the input pixel of output pixel p and this
+        // thread's tap is p + const, so the address is one running pointer -- no integer multiplies in the loop
+        same = o.stride == 1 && o.ups == 0 && o.Ho == o.Hs && o.Wo == o.Ws;
+        ptr = o.p + ((long long)pix + (long long)(kh - o.pad_t) * o.Ws + (kw - o.pad_l)) * o.ld + ci;
+        step = (long long)KS * o.ld;
+        adv = (long long)BK * o.ld;
     }
     __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
+        if (same) {
+#pragma unroll
+            for (int i = 0; i < NI; ++i) {
+                const int p = pix + KS * i;
+                int b, y, x;
+                decode_pixel(o, p, b, y, x);
+                const bool okk = ok && p < Kp && (unsigned)(y + kh - o.pad_t) < (unsigned)o.Hs && (unsigned)(x + kw - o.pad_l) < (unsigned)o.Ws;
+                v[i] = ld4_if(ptr + step * i, okk, o.p);
+            }
+            return;
+        }
         const int He = o.Hs << o.ups, We = o.Ws << o.ups;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
@@ -532,7 +551,7 @@ struct ConvRC : RCStore<R, TR> {
             v[i] = ld4_if(o.p + off, okk, o.p);
         }
     }
-    __device__ __forceinline__ void advance(const Opnd&) { pix += BK; }
+    __device__ __forceinline__ void advance(const Opnd&) { pix += BK; ptr += adv; }
 };
 
 // =================================================================================================
