@@ -283,8 +283,8 @@ def update_score_file(config, score_file, fid_sc, mse_sc, ssim_sc):
 
 def measure(config, dsl, folder_name, pipeline, rank=0, world=1):
     """baddiffusion.py:477-551.  Sampling is sharded over ranks (independent chains, no collective); rank 0 scores.
-    MSE-to-target is computed from the written PNGs like the reference; FID / SSIM need pytorch_fid's Inception
-    weights / torchmetrics, absent here -> reported as null (SURVEY f-3)."""
+    MSE / SSIM to the target are computed on the device from the written PNGs like the reference; FID needs
+    pytorch_fid's Inception weights, absent here -> reported as null (statistics + Frechet distance: baddiffusion_amd/metrics.py)."""
     from baddiffusion_amd.model import batch_sampling_save
     rng = torch.Generator().manual_seed(config.seed)
     parts = [config.output_dir, folder_name] + ([f"ep{config.sample_ep}"] if config.sample_ep is not None else [])
@@ -309,9 +309,15 @@ def measure(config, dsl, folder_name, pipeline, rank=0, world=1):
     gen = torch.from_numpy(gen)
     gen = gen.permute(0, 3, 1, 2) if gen.dim() == 4 else gen[:, None]
     tgt = (dsl.target / 2 + 0.5).clamp(0, 1)[None].expand_as(gen)
-    mse_sc = float(torch.nn.functional.mse_loss(gen, tgt))
-    print(f"[{config.sample_ep}] FID: None (pytorch_fid Inception weights unavailable), MSE: {mse_sc}, SSIM: None")
-    return update_score_file(config, "score.json", None, mse_sc, None)
+    from baddiffusion_amd import metrics
+    dev = pipeline.device if hasattr(pipeline, "device") else "cpu"
+    gen_d, tgt_d = gen.to(dev), tgt.to(dev)
+    mse_sc = metrics.mse(gen_d, tgt_d)
+    ssim_sc = metrics.ssim(gen_d, tgt_d, data_range=1.0)     # torchmetrics defaults (parity unpinned: torchmetrics absent)
+    # FID needs pool3 features of pytorch_fid's InceptionV3 (weights do not travel); with a feature extractor the rest of
+    # the path is metrics.fid_from_features(...) -> ActivationStats on the device + Frechet distance (pinned by G8)
+    print(f"[{config.sample_ep}] FID: None (pytorch_fid Inception weights unavailable), MSE: {mse_sc}, SSIM: {ssim_sc}")
+    return update_score_file(config, "score.json", None, mse_sc, ssim_sc)
 
 
 def checkpoint(config, engine, pipeline, cur_epoch, cur_step):

@@ -266,7 +266,23 @@ def g7():
     save("unet_cifar.npz", **out)
 
 
+# ---- G8 Frechet distance / activation statistics (fid_score.py:150-204, 207-230) ---------------------------
+def g8():
+    import fid_score as ref_fid          # pytorch_fid is a MagicMock; the two functions below are pure numpy / scipy
+    out = {}
+    for tag, d, n1, n2, seed in (("d64", 64, 300, 200, 0), ("d16", 16, 50, 40, 1), ("rank_deficient", 32, 20, 24, 2)):
+        rng = np.random.RandomState(seed)
+        a1 = rng.randn(n1, d) * (1 + rng.rand(d)) + rng.randn(d) * 0.3
+        a2 = rng.randn(n2, d) @ (np.eye(d) + 0.2 * rng.randn(d, d)) + 0.5
+        mu1, s1 = np.mean(a1, axis=0), np.cov(a1, rowvar=False)     # calculate_activation_statistics (fid_score.py:227-229)
+        mu2, s2 = np.mean(a2, axis=0), np.cov(a2, rowvar=False)
+        out[f"{tag}_a1"] = a1; out[f"{tag}_a2"] = a2
+        out[f"{tag}_mu1"] = mu1; out[f"{tag}_sigma1"] = s1; out[f"{tag}_mu2"] = mu2; out[f"{tag}_sigma2"] = s2
+        out[f"{tag}_fid"] = np.float64(ref_fid.calculate_frechet_distance(mu1, s1, mu2, s2))
+    save("fid.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
     for w in which:
         globals()[w]()

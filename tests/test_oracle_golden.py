@@ -249,3 +249,43 @@ def test_cosine_lr_closed_form():
     assert f(500) == 1.0 and abs(f(T_)) < 1e-12
     mid = 500 + (T_ - 500) // 2
     assert abs(f(mid) - 0.5 * (1 + math.cos(math.pi * (mid - 500) / (T_ - 500)))) < 1e-12
+
+
+def test_g8_frechet_distance_and_statistics(golden):
+    """fid_score.py:150-230 restatement (oracle) and the product's device-side accumulation against the reference's
+    own outputs, incl. the rank-deficient case (fewer samples than dimensions -> singular product -> eps retry)."""
+    from oracle import metrics_ref
+    from baddiffusion_amd import metrics
+    g = golden("fid")
+    for tag in ("d64", "d16", "rank_deficient"):
+        for a, mu, sg in ((g[f"{tag}_a1"], g[f"{tag}_mu1"], g[f"{tag}_sigma1"]), (g[f"{tag}_a2"], g[f"{tag}_mu2"], g[f"{tag}_sigma2"])):
+            m, s = metrics_ref.activation_statistics(a)
+            np.testing.assert_allclose(m, mu, rtol=0, atol=1e-13); np.testing.assert_allclose(s, sg, rtol=1e-12, atol=1e-13)
+            acc = metrics.ActivationStats(a.shape[1])
+            for lo in range(0, a.shape[0], 37):            # batch by batch, like the measure loop
+                acc.update(torch.from_numpy(a[lo:lo + 37]))
+            m2, s2 = acc.finalize()
+            np.testing.assert_allclose(m2, mu, rtol=0, atol=1e-12); np.testing.assert_allclose(s2, sg, rtol=1e-9, atol=1e-11)
+        ref = float(g[f"{tag}_fid"])
+        args = (g[f"{tag}_mu1"], g[f"{tag}_sigma1"], g[f"{tag}_mu2"], g[f"{tag}_sigma2"])
+        assert abs(metrics_ref.frechet_distance(*args) - ref) <= 1e-9 * abs(ref)
+        assert abs(metrics.frechet_distance(*args) - ref) <= 1e-9 * abs(ref)
+    with pytest.raises(ValueError):
+        metrics.frechet_distance(np.zeros(3), np.eye(3), np.zeros(4), np.eye(4))
+
+
+def test_ssim_properties():
+    """SSIM (torchmetrics defaults, parity unpinned): identity = 1, symmetric, drops with noise, constant-shift formula"""
+    from baddiffusion_amd import metrics
+    gen = torch.Generator().manual_seed(0)
+    a = torch.rand(4, 3, 32, 32, generator=gen)
+    assert abs(metrics.ssim(a, a) - 1.0) < 1e-6
+    b = (a + 0.1 * torch.randn(a.shape, generator=gen)).clamp(0, 1)
+    c = (a + 0.3 * torch.randn(a.shape, generator=gen)).clamp(0, 1)
+    sab, sba, sac = metrics.ssim(a, b), metrics.ssim(b, a), metrics.ssim(a, c)
+    assert abs(sab - sba) < 1e-6 and 0 < sac < sab < 1
+    # two constant images u, v: variances vanish, SSIM = (2uv + c1) / (u^2 + v^2 + c1)
+    u, v = 0.2, 0.7
+    s = metrics.ssim(torch.full((1, 3, 32, 32), u), torch.full((1, 3, 32, 32), v))
+    assert abs(s - (2 * u * v + 1e-4) / (u * u + v * v + 1e-4)) < 5e-4     # E[x^2] - mu^2 cancels in fp32 against c2 = 9e-4
+    assert abs(metrics.mse(a, b) - float(((a - b) ** 2).mean())) < 1e-9
