@@ -12,7 +12,7 @@ Reference call sites: baddiffusion.py:536-547 (`nn.MSELoss`, `StructuralSimilari
 """
 import numpy as np
 import torch
-import torch.nn.functional as F
+import torch.nn.functional as F   # F.pad only
 
 
 def mse(a, b):
@@ -34,12 +34,19 @@ def ssim(preds, target, data_range=1.0, kernel_size=11, sigma=1.5, k1=0.01, k2=0
     C = p.shape[1]
     c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
     g = _gauss1d(kernel_size, sigma, p.device, p.dtype)
-    kern = (g[:, None] * g[None, :]).expand(C, 1, kernel_size, kernel_size).contiguous()
     pad = (kernel_size - 1) // 2
     p = F.pad(p, (pad, pad, pad, pad), mode="reflect")
     t = F.pad(t, (pad, pad, pad, pad), mode="reflect")
     stack = torch.cat((p, t, p * p, t * t, p * t))
-    out = F.conv2d(stack, kern, groups=C)
+    # the 11x11 window is separable (g g^T): "valid" filtering = two banded matrix products, rows then columns
+    def band(n_out):
+        m = torch.zeros(n_out, n_out + kernel_size - 1, device=p.device, dtype=p.dtype)
+        idx = torch.arange(n_out, device=p.device)
+        for j in range(kernel_size):
+            m[idx, idx + j] = g[j]
+        return m
+    H, W = preds.shape[-2:]
+    out = torch.einsum("ih,nchw,jw->ncij", band(H), stack, band(W))
     mp, mt, pp, tt, pt = out.split(preds.shape[0])
     sp, st, spt = pp - mp * mp, tt - mt * mt, pt - mp * mt
     full = ((2 * mp * mt + c1) * (2 * spt + c2)) / ((mp * mp + mt * mt + c1) * (sp + st + c2))
