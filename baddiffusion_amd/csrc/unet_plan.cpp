@@ -50,6 +50,8 @@ struct Param {
 struct Ctx {
     bool dry = false;
     int B = 0;
+    int64_t s0 = 0;   // sample offset of this context inside the batch the workspace is laid out for
+    int LB = 0;       // that batch (B of the call); B <= LB is the number of samples this context processes
     float* ws = nullptr;
     const float* params = nullptr;
     float* grads = nullptr;
@@ -146,9 +148,16 @@ struct bd_unet {
     void Bk(Step s) { bwd.push_back({std::move(s), cur_seg, cur_group}); }
 
     // ---------------------------------------------------------------- run-time helpers
-    float* VP(Ctx& c, const View& v) const { return c.ws + bufs[v.buf].off + v.coff; }
-    float* GP(Ctx& c, const View& v) const { return c.ws + bufs[bufs[v.buf].gbuf].off + v.coff; }
-    float* BP(Ctx& c, int b) const { return c.ws + bufs[b].off; }
+    // c.s0 = first sample of this context (forward runs the two halves of the batch as two concurrent pipelines)
+    float* VP(Ctx& c, const View& v) const { return c.ws + bufs[v.buf].off + c.s0 * bufs[v.buf].per_sample + v.coff; }
+    float* GP(Ctx& c, const View& v) const {
+        const Buf& g = bufs[bufs[v.buf].gbuf];
+        return c.ws + g.off + c.s0 * g.per_sample + v.coff;
+    }
+    float* BP(Ctx& c, int b) const { return c.ws + bufs[b].off + c.s0 * bufs[b].per_sample; }
+    // GroupNorm statistics buffer = [LB][G] means followed by [LB][G] rstds (batch-major, so not a per-sample slab)
+    float* MEANP(Ctx& c, int b, int G) const { return c.ws + bufs[b].off + c.s0 * G; }
+    float* RSTDP(Ctx& c, int b, int G) const { return c.ws + bufs[b].off + ((int64_t)c.LB + c.s0) * G; }
     static int64_t rows(const Ctx& c, const View& v) { return (int64_t)c.B * v.H * v.W; }
 
     // enqueue a weight-gradient launch on the side stream (after everything enqueued on c.st so far)
@@ -233,7 +242,7 @@ struct bd_unet {
         bd_gn_fwd_desc d = {};
         d.B = c.B; d.HW = x.H * x.W; d.C = x.C; d.G = cfg.norm_num_groups; d.eps = cfg.norm_eps; d.silu = silu;
         d.x = VP(c, x); d.ldx = x.ld; d.gamma = c.params + pg; d.beta = c.params + pb; d.y = y; d.ldy = ldy;
-        d.mean = BP(c, stats_buf); d.rstd = d.mean + (int64_t)c.B * d.G;
+        d.mean = MEANP(c, stats_buf, d.G); d.rstd = RSTDP(c, stats_buf, d.G);
         d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
         if (c.dry) {
             size_t n = bd_gn_workspace_bytes(c.B, x.C);
@@ -246,7 +255,7 @@ struct bd_unet {
         bd_gn_bwd_desc d = {};
         d.B = c.B; d.HW = x.H * x.W; d.C = x.C; d.G = cfg.norm_num_groups; d.silu = silu;
         d.x = VP(c, x); d.ldx = x.ld; d.gamma = c.params + pg; d.beta = c.params + pb;
-        d.mean = BP(c, stats_buf); d.rstd = d.mean + (int64_t)c.B * d.G;
+        d.mean = MEANP(c, stats_buf, d.G); d.rstd = RSTDP(c, stats_buf, d.G);
         d.dy = dy; d.lddy = lddy; d.dx = GP(c, x); d.lddx = x.ld;
         d.accumulate_dx = c.ginit[x.buf];
         c.ginit[x.buf] = 1;
@@ -423,7 +432,7 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             bd_gn_bwd_desc d = {};
             d.B = c.B; d.HW = HW; d.C = Cout; d.G = G; d.silu = 1;
             d.x = BP(c, b_h1); d.ldx = Cout; d.gamma = c.params + pn2w; d.beta = c.params + pn2b;
-            d.mean = BP(c, b_st2); d.rstd = d.mean + (int64_t)c.B * G;
+            d.mean = MEANP(c, b_st2, G); d.rstd = RSTDP(c, b_st2, G);
             d.dy = BP(c, b_da2); d.lddy = Cout; d.dx = BP(c, b_dh1); d.lddx = Cout; d.accumulate_dx = 0;
             d.dgamma = c.grads + pn2w; d.dbeta = c.grads + pn2b;
             d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
@@ -888,7 +897,7 @@ extern "C" size_t bd_unet_workspace_bytes(bd_unet* u, int B, int training) {
     if (!u || B <= 0) return 0;
     u->layout(B, training);
     return (size_t)(u->value_floats + u->grad_floats + u->scratch_floats) * sizeof(float) + u->opws_bytes + 256 +
-           wsplit_bytes(u) + (training ? align_up(u->opws_bytes, 256) : 0);   // + the side stream's op workspace
+           wsplit_bytes(u) + align_up(u->opws_bytes, 256);   // + the side stream's op workspace
 }
 
 static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, size_t workspace_bytes) {
@@ -897,7 +906,7 @@ static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, si
     const size_t need = bd_unet_workspace_bytes(u, B, training);
     BD_CHECK(workspace && workspace_bytes >= need, BD_ERR_WORKSPACE, "bd_unet: workspace %zu < %zu bytes", workspace_bytes, need);
     BD_CHECK(aligned16(workspace), BD_ERR_INVALID, "bd_unet: workspace must be 16-byte aligned");
-    c.B = B;
+    c.B = B; c.LB = B;
     c.ws = reinterpret_cast<float*>(workspace);
     const size_t fl = (size_t)(u->value_floats + u->grad_floats + u->scratch_floats) * sizeof(float);
     c.opws = reinterpret_cast<char*>(workspace) + align_up(fl, 256);
@@ -907,6 +916,18 @@ static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, si
     }
     c.opws2 = c.opws + align_up(u->opws_bytes, 256) + wsplit_bytes(u);
     c.ginit.assign(u->bufs.size(), 0);
+    return BD_OK;
+}
+
+// the plan's side stream and its events, created on first use (plan creation stays host-only)
+static int unet_aux_init(bd_unet* u) {
+    if (u->aux_stream) return BD_OK;
+    int lo = 0, hi = 0;
+    BD_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lowest priority: in backward the dgrad chain is the critical path
+    BD_HIP_TRY(hipStreamCreateWithPriority(&u->aux_stream, hipStreamNonBlocking, lo));
+    BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_fork, hipEventDisableTiming));
+    BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join[0], hipEventDisableTiming));
+    BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join[1], hipEventDisableTiming));
     return BD_OK;
 }
 
@@ -921,7 +942,29 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
     c.params = params; c.x = x; c.ldx = ldx; c.t = t; c.t_stride = t_stride; c.out = out; c.ldo = ldo; c.st = S(stream);
     if (c.w_split)   // split the weights once; forward convs and (same workspace) the backward dgrads read the copy
         BD_TRY(bd_split_bf16(params, (int64_t)wsplit_elems(u), const_cast<uint16_t*>(c.w_split), stream));
-    for (auto& f : u->fwd) BD_TRY(f(c));
+    if (!u->aux_enabled || B < 32) {
+        for (auto& f : u->fwd) BD_TRY(f(c));
+        return BD_OK;
+    }
+    // Samples are independent all the way through the network (GroupNorm is per sample), so the batch runs as two
+    // half-batch pipelines on the caller's stream and the plan's side stream, node by node: the prologues / epilogues
+    // / small kernels of one half overlap the main loops of the other (+4 % on the CIFAR forward).  Same buffers, same
+    // layout as a single pass -- backward does not know the difference.
+    BD_TRY(unet_aux_init(u));
+    Ctx c2 = c;
+    const int Bh = B / 2;
+    const int64_t hw = (int64_t)u->cfg.sample_size * u->cfg.sample_size;
+    c.B = Bh;
+    c2.B = B - Bh; c2.s0 = Bh; c2.st = u->aux_stream; c2.opws = c.opws2;
+    c2.x = x + (int64_t)Bh * hw * ldx; c2.t = t + (int64_t)Bh * t_stride; c2.out = out + (int64_t)Bh * hw * ldo;
+    BD_HIP_TRY(hipEventRecord(u->aux_ev_fork, c.st));
+    BD_HIP_TRY(hipStreamWaitEvent(c2.st, u->aux_ev_fork, 0));
+    for (auto& f : u->fwd) {
+        BD_TRY(f(c));
+        BD_TRY(f(c2));
+    }
+    BD_HIP_TRY(hipEventRecord(u->aux_ev_join[0], c2.st));
+    BD_HIP_TRY(hipStreamWaitEvent(c.st, u->aux_ev_join[0], 0));
     return BD_OK;
 }
 
@@ -944,14 +987,7 @@ extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float*
     c.params = params; c.grads = grads; c.dout = dout; c.lddo = lddo; c.st = S(stream);
     c.x = x; c.ldx = ldx;   // conv_in wgrad re-reads the forward input
     if (u->aux_enabled) {
-        if (!u->aux_stream) {
-            int lo = 0, hi = 0;
-            BD_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lowest priority: the dgrad chain is the critical path
-            BD_HIP_TRY(hipStreamCreateWithPriority(&u->aux_stream, hipStreamNonBlocking, lo));
-            BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_fork, hipEventDisableTiming));
-            BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join[0], hipEventDisableTiming));
-            BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join[1], hipEventDisableTiming));
-        }
+        BD_TRY(unet_aux_init(u));
         c.st2 = u->aux_stream; c.ev_fork = u->aux_ev_fork; c.ev_join[0] = u->aux_ev_join[0]; c.ev_join[1] = u->aux_ev_join[1];
     }
     // grad-init flags must reflect everything executed before this segment: replay them (host-only)
