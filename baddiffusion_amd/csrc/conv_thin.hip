@@ -179,12 +179,17 @@ __global__ __launch_bounds__(1024) void thin_reduce_kernel(const float* __restri
     }
 }
 
+static bool thin_in_shape(const bd_conv3x3_wgrad_desc& d) { return (d.Cin == 3 || d.Cin == 1) && d.Cout % 128 == 0; }
+static bool thin_out_shape(const bd_conv3x3_wgrad_desc& d) { return (d.Cout == 3 || d.Cout == 1) && d.Cin % 128 == 0; }
+// shapes these kernels take (they also produce the bias gradient d.db for ANY Cout, unlike the igemm fusion)
+bool conv3x3_wgrad_is_thin(const bd_conv3x3_wgrad_desc& d) {
+    return d.stride == 1 && d.ups == 0 && d.Ho == d.Hs && d.Wo == d.Ws && (thin_in_shape(d) || thin_out_shape(d));
+}
+
 // returns 1 when it handled the call, 0 when the shape belongs to the igemm path, < 0 on error
 int conv3x3_wgrad_thin(const bd_conv3x3_wgrad_desc& d, hipStream_t st) {
-    if (d.stride != 1 || d.ups != 0 || d.Ho != d.Hs || d.Wo != d.Ws) return 0;
-    const bool thin_in = (d.Cin == 3 || d.Cin == 1) && d.Cout % 128 == 0;
-    const bool thin_out = (d.Cout == 3 || d.Cout == 1) && d.Cin % 128 == 0;
-    if (!thin_in && !thin_out) return 0;
+    if (!conv3x3_wgrad_is_thin(d)) return 0;
+    const bool thin_in = thin_in_shape(d);
     ThinGeom g;
     g.B = d.B; g.H = d.Hs; g.W = d.Ws; g.pad_t = d.pad_t; g.pad_l = d.pad_l;
     g.pixels = (long long)d.B * d.Hs * d.Ws;

@@ -84,22 +84,34 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, long long ldx, int 
     }
 }
 
-// ---- forward finalize: (mean, rstd)[b][g] from the S fixed-order partials (fp64); one block per sample
+// ---- forward finalize: (mean, rstd)[b][g] from the S partials (fp64, fixed order: 8 interleaved phases per group, then
+// the phases); one block per sample, 8 threads per group so that 128 pixel splits do not serialise on 32 threads
 __global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(const double* __restrict__ part, int G, int S, double n, float eps,
                                                             float* __restrict__ mean, float* __restrict__ rstd) {
+    __shared__ double red[256][2];
     const int b = blockIdx.x;
-    for (int g = threadIdx.x; g < G; g += 256) {
+    const int ph = threadIdx.x & 7;
+    for (int g0 = 0; g0 < G; g0 += 32) {
+        const int g = g0 + (threadIdx.x >> 3);
         double a = 0.0, c2 = 0.0;
-        for (int sp = 0; sp < S; ++sp) {
-            const double* p = part + (((long long)b * S + sp) * G + g) * 2;
-            a += p[0];
-            c2 += p[1];
+        if (g < G)
+            for (int sp = ph; sp < S; sp += 8) {
+                const double* p = part + (((long long)b * S + sp) * G + g) * 2;
+                a += p[0];
+                c2 += p[1];
+            }
+        red[threadIdx.x][0] = a; red[threadIdx.x][1] = c2;
+        __syncthreads();
+        if (ph == 0 && g < G) {
+            a = 0.0; c2 = 0.0;
+            for (int k = 0; k < 8; ++k) { a += red[threadIdx.x + k][0]; c2 += red[threadIdx.x + k][1]; }
+            const double mu = a / n;
+            double var = c2 / n - mu * mu;
+            if (var < 0.0) var = 0.0;
+            mean[b * G + g] = (float)mu;
+            rstd[b * G + g] = (float)(1.0 / sqrt(var + (double)eps));
         }
-        const double mu = a / n;
-        double var = c2 / n - mu * mu;
-        if (var < 0.0) var = 0.0;
-        mean[b * G + g] = (float)mu;
-        rstd[b * G + g] = (float)(1.0 / sqrt(var + (double)eps));
+        __syncthreads();
     }
 }
 
@@ -225,21 +237,31 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
                                                             float inv_n, float* __restrict__ ds /* [B][G][2] */,
                                                             float* __restrict__ dx_colsum, long long ld_colsum) {
     extern __shared__ float sg[];  // [G][2]
+    __shared__ double red[256][2];
     const int b = blockIdx.x;
     const int cpg = C / G;
-    for (int g = threadIdx.x; g < G; g += 256) {
+    const int ph = threadIdx.x & 7;           // 8 threads per group: interleaved split phases, folded in a fixed order
+    for (int g0 = 0; g0 < G; g0 += 32) {
+        const int g = g0 + (threadIdx.x >> 3);
         double a = 0.0, e = 0.0;
-        for (int sp = 0; sp < S; ++sp)
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-                const float* p = part + ((long long)b * S + sp) * 3 * C + c;
-                e += (double)p[0] * gamma[c];
-                a += (double)p[C] * gamma[c];
-            }
-        sg[2 * g] = (float)a; sg[2 * g + 1] = (float)e;
-        ds[((long long)b * G + g) * 2] = (float)a;
-        ds[((long long)b * G + g) * 2 + 1] = (float)e;
+        if (g < G)
+            for (int sp = ph; sp < S; sp += 8)
+                for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
+                    const float* p = part + ((long long)b * S + sp) * 3 * C + c;
+                    e += (double)p[0] * gamma[c];
+                    a += (double)p[C] * gamma[c];
+                }
+        red[threadIdx.x][0] = a; red[threadIdx.x][1] = e;
+        __syncthreads();
+        if (ph == 0 && g < G) {
+            a = 0.0; e = 0.0;
+            for (int k = 0; k < 8; ++k) { a += red[threadIdx.x + k][0]; e += red[threadIdx.x + k][1]; }
+            sg[2 * g] = (float)a; sg[2 * g + 1] = (float)e;
+            ds[((long long)b * G + g) * 2] = (float)a;
+            ds[((long long)b * G + g) * 2 + 1] = (float)e;
+        }
+        __syncthreads();
     }
-    __syncthreads();
     if (dx_colsum) {
         for (int c = threadIdx.x; c < C; c += 256) {
             float a = 0.f, h = 0.f;

@@ -24,6 +24,7 @@ namespace bd {
 int conv3x3_fwd(const bd_conv3x3_fwd_desc& d, hipStream_t st);
 int conv3x3_dgrad(const bd_conv3x3_dgrad_desc& d, hipStream_t st);
 int conv3x3_wgrad(const bd_conv3x3_wgrad_desc& d, hipStream_t st);
+bool conv3x3_wgrad_is_thin(const bd_conv3x3_wgrad_desc& d);
 
 struct View {
     int buf = -1;   // value buffer id
@@ -636,10 +637,11 @@ void bd_unet::node_conv_out(const View& x) {
         return conv_f(c, d);
     });
     Bk([=](Ctx& c) {
-        BD_TRY(bias_grad(c, c.dout, c.lddo, H * W, Co, b_bs, c.grads + pb));
         bd_conv3x3_wgrad_desc w = {};
         w.B = c.B; w.Hs = H; w.Ws = W; w.Cin = C; w.Cout = Co; w.stride = 1; w.pad_t = 1; w.pad_l = 1; w.Ho = H; w.Wo = W;
         w.x = BP(c, b_a); w.ldx = C; w.dy = c.dout; w.lddy = c.lddo; w.dw = c.grads + pw;
+        if (conv3x3_wgrad_is_thin(w)) w.db = c.grads + pb;                    // the direct kernel sums dy on the way
+        else BD_TRY(bias_grad(c, c.dout, c.lddo, H * W, Co, b_bs, c.grads + pb));   // Cout = 3: no igemm row-sum fusion
         BD_TRY(conv_w(c, w));
         bd_conv3x3_dgrad_desc g = {};
         g.B = c.B; g.Hs = H; g.Ws = W; g.Cin = C; g.Cout = Co; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.Ho = H; g.Wo = W;
