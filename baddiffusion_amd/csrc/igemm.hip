@@ -114,30 +114,24 @@ __device__ __forceinline__ void decode_pixel(const Opnd& o, int pix, int& b, int
 // KC: tile [R rows][32 k]; thread t owns float4 column k4 = (t&7)*4 of rows (t>>3) + 32*i.
 // RC: tile [32 k][R rows]; thread t owns float4 at rows r4 = (t % (R/4))*4, k = t/(R/4) + KS*i.
 // =================================================================================================
-template <int R>
+template <int R, int NT = 256>
 struct KCStore {
-    static constexpr int NI = R / 32;
+    static constexpr int NI = R * 8 / NT;
     __device__ __forceinline__ static void store(float* s, int tid, const float4 (&v)[NI]) {
         const int k4 = (tid & 7) * 4;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + (krow(tid) + 32 * i) * LDK + k4) = v[i];
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + (krow(tid) + (NT / 8) * i) * LDK + k4) = v[i];
     }
     __device__ __forceinline__ static void store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]);
 };
 // RC thread map: every thread owns the float4 of rows r4..r4+3 at NI values of k, k_i = kfirst + KSTEP*i.
-//   TR = false (fp32 LDS image [k][rows]):  r4 = (t % (R/4))*4, kfirst = t / (R/4), KSTEP = 1024/R
-//   TR = true  (bf16 LDS image [rows][k], split-bf16 mode): the NI k values are ADJACENT so that a thread can
-//              transpose its 4 x NI block in registers and write NI bf16 of one row with a single ds_write:
-//              kfirst = 4*(t%8) (+2*(t/128) for R = 64), r4 = ((t/8) % (R/4))*4, KSTEP = 1.  A wave instruction
-//              still touches 8 k-rows x 128 contiguous bytes (8 full cache lines).
-template <int R, bool TR>
+//   r4 = (t % (R/4))*4, kfirst = t / (R/4), KSTEP = NT*4/R   (NT = threads of the workgroup: 256 or 512)
+template <int R, int NT>
 struct RCMap {
-    static constexpr int NI = R / 32;
-    static constexpr int KSTEP = TR ? 1 : 1024 / R;
-    __device__ __forceinline__ static int r4(int t) { return TR ? ((t >> 3) % (R / 4)) * 4 : (t % (R / 4)) * 4; }
-    __device__ __forceinline__ static int kfirst(int t) {
-        return TR ? 4 * (t & 7) + (R == 64 ? 2 * (t >> 7) : 0) : t / (R / 4);
-    }
+    static constexpr int NI = R * 8 / NT;          // float4 per thread per chunk
+    static constexpr int KSTEP = NT * 4 / R;       // k rows covered per pass
+    __device__ __forceinline__ static int r4(int t) { return (t % (R / 4)) * 4; }
+    __device__ __forceinline__ static int kfirst(int t) { return t / (R / 4); }
 };
 
 constexpr int LDH = BK + 8;  // bf16 row stride of the split-bf16 LDS planes: 80 B (conflict-free b128 reads, b64 writes)
@@ -153,21 +147,21 @@ __device__ __forceinline__ unsigned pack_lo(float a, float b) {   // RNE(x - tru
     return __builtin_bit_cast(unsigned, t);
 }
 
-template <int R, bool TR>
+template <int R, int NT>
 struct RCStore {
-    static constexpr int NI = R / 32;
+    static constexpr int NI = R * 8 / NT;
     __device__ __forceinline__ static void store(float* s, int tid, const float4 (&v)[NI]) {
-        const int r4 = RCMap<R, TR>::r4(tid), k0 = RCMap<R, TR>::kfirst(tid);
+        const int r4 = RCMap<R, NT>::r4(tid), k0 = RCMap<R, NT>::kfirst(tid);
 #pragma unroll
-        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + (k0 + RCMap<R, TR>::KSTEP * i) * (R + 4) + r4) = v[i];
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(s + (k0 + RCMap<R, NT>::KSTEP * i) * (R + 4) + r4) = v[i];
     }
     // split-bf16 planes, row-contiguous image [k][R + 32] bf16 (the global loads stay fully coalesced); the MFMA
     // fragments are gathered from it with ds_read_b64_tr_b16 (hardware 4x4 transpose), see rc_frag()
     __device__ __forceinline__ static void store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]) {
-        const int r4 = RCMap<R, TR>::r4(tid), k0 = RCMap<R, TR>::kfirst(tid);
+        const int r4 = RCMap<R, NT>::r4(tid), k0 = RCMap<R, NT>::kfirst(tid);
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int o = (k0 + RCMap<R, TR>::KSTEP * i) * (R + 32) + r4;
+            const int o = (k0 + RCMap<R, NT>::KSTEP * i) * (R + 32) + r4;
             *reinterpret_cast<uint2*>(sh + o) = make_uint2(pack_hi(v[i].x, v[i].y), pack_hi(v[i].z, v[i].w));
             *reinterpret_cast<uint2*>(sl + o) = make_uint2(pack_lo(v[i].x, v[i].y), pack_lo(v[i].z, v[i].w));
         }
@@ -192,20 +186,20 @@ __device__ __forceinline__ bf16x8 rc_frag(const unsigned short* plane, int rowti
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int R>
-__device__ __forceinline__ void KCStore<R>::store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]) {
+template <int R, int NT>
+__device__ __forceinline__ void KCStore<R, NT>::store_split(unsigned short* sh, unsigned short* sl, int tid, const float4 (&v)[NI]) {
     const int k4 = (tid & 7) * 4;
 #pragma unroll
     for (int i = 0; i < NI; ++i) {
-        const int o = (krow(tid) + 32 * i) * LDH + k4;
+        const int o = (krow(tid) + (NT / 8) * i) * LDH + k4;
         *reinterpret_cast<uint2*>(sh + o) = make_uint2(pack_hi(v[i].x, v[i].y), pack_hi(v[i].z, v[i].w));
         *reinterpret_cast<uint2*>(sl + o) = make_uint2(pack_lo(v[i].x, v[i].y), pack_lo(v[i].z, v[i].w));
     }
 }
 
-template <int R>
-struct DenseKC : KCStore<R> {
-    static constexpr int NI = R / 32;
+template <int R, int NT = 256>
+struct DenseKC : KCStore<R, NT> {
+    static constexpr int NI = R * 8 / NT;
     static constexpr bool kKC = true;
     const float* ptr[NI];
     bool ok[NI];
@@ -215,7 +209,7 @@ struct DenseKC : KCStore<R> {
         krem = K - kbase - k4;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = row0 + krow(tid) + 32 * i;
+            const int r = row0 + krow(tid) + (NT / 8) * i;
             ok[i] = r < o.rows;
             ptr[i] = o.p + (long long)r * o.ld + kbase + k4;
         }
@@ -232,9 +226,9 @@ struct DenseKC : KCStore<R> {
 };
 
 // conv gather, forward direction: rows = output pixels, k = tap*C + c, C % 32 == 0 (tap uniform per chunk)
-template <int R>
-struct ConvKC : KCStore<R> {
-    static constexpr int NI = R / 32;
+template <int R, int NT = 256>
+struct ConvKC : KCStore<R, NT> {
+    static constexpr int NI = R * 8 / NT;
     static constexpr bool kKC = true;
     const float* base[NI];  // image base + k4
     int y0[NI], x0[NI];
@@ -248,7 +242,7 @@ struct ConvKC : KCStore<R> {
         kw = tap - kh * 3;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = row0 + krow(tid) + 32 * i;
+            const int r = row0 + krow(tid) + (NT / 8) * i;
             int b, y, x;
             decode_pixel(o, r, b, y, x);
             base[i] = o.p + (long long)b * o.Hs * o.Ws * o.ld + k4;
@@ -275,9 +269,9 @@ struct ConvKC : KCStore<R> {
 };
 
 // forward-conv weights W[co][tap][ci] (ld = 9*C) walked in ConvKC's K order (channel block outer, tap inner)
-template <int R>
-struct WgtKC : KCStore<R> {
-    static constexpr int NI = R / 32;
+template <int R, int NT = 256>
+struct WgtKC : KCStore<R, NT> {
+    static constexpr int NI = R * 8 / NT;
     static constexpr bool kKC = true;
     const float* ptr[NI];
     bool ok[NI];
@@ -289,7 +283,7 @@ struct WgtKC : KCStore<R> {
         c0 = (chunk / 9) * BK;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = row0 + krow(tid) + 32 * i;
+            const int r = row0 + krow(tid) + (NT / 8) * i;
             ok[i] = r < o.rows;
             ptr[i] = o.p + (long long)r * o.ld + k4;
         }
@@ -305,9 +299,9 @@ struct WgtKC : KCStore<R> {
 };
 
 // conv gather, data-gradient direction: rows = input pixels, k = tap*C + c over dY (C = Cout, C % 32 == 0)
-template <int R>
-struct TConvKC : KCStore<R> {
-    static constexpr int NI = R / 32;
+template <int R, int NT = 256>
+struct TConvKC : KCStore<R, NT> {
+    static constexpr int NI = R * 8 / NT;
     static constexpr bool kKC = true;
     const float* base[NI];
     int y0[NI], x0[NI];
@@ -321,7 +315,7 @@ struct TConvKC : KCStore<R> {
         kw = tap - kh * 3;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = row0 + krow(tid) + 32 * i;
+            const int r = row0 + krow(tid) + (NT / 8) * i;
             int b, y, x;
             decode_pixel(o, r, b, y, x);
             base[i] = o.p + (long long)b * o.Hs * o.Ws * o.ld + k4;
@@ -348,17 +342,17 @@ struct TConvKC : KCStore<R> {
     }
 };
 
-template <int R, bool TR>
-struct DenseRC : RCStore<R, TR> {
-    static constexpr int NI = R / 32;
-    static constexpr int KS = RCMap<R, TR>::KSTEP;
+template <int R, int NT>
+struct DenseRC : RCStore<R, NT> {
+    static constexpr int NI = R * 8 / NT;
+    static constexpr int KS = RCMap<R, NT>::KSTEP;
     static constexpr bool kKC = false;
     const float* ptr;  // p + row + (kbase + k0)*ld
     long long step;    // KS * ld
     int krem;          // K - (kbase + k0)
     bool ok;
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int K) {
-        const int r4 = RCMap<R, TR>::r4(tid), k0 = RCMap<R, TR>::kfirst(tid);
+        const int r4 = RCMap<R, NT>::r4(tid), k0 = RCMap<R, NT>::kfirst(tid);
         ok = row0 + r4 < o.rows;
         ptr = o.p + (row0 + r4) + (long long)(kbase + k0) * o.ld;
         step = (long long)KS * o.ld;
@@ -375,17 +369,17 @@ struct DenseRC : RCStore<R, TR> {
 };
 
 // weights seen from dgrad: rows = ci, k = tap*C + co (C = Cout, C % 32 == 0): W[(co*9 + tap)*ld + ci]
-template <int R, bool TR>
-struct WgtRC : RCStore<R, TR> {
-    static constexpr int NI = R / 32;
-    static constexpr int KS = RCMap<R, TR>::KSTEP;
+template <int R, int NT>
+struct WgtRC : RCStore<R, NT> {
+    static constexpr int NI = R * 8 / NT;
+    static constexpr int KS = RCMap<R, NT>::KSTEP;
     static constexpr bool kKC = false;
     const float* ptr;  // p + row + k0*9*ld
     long long step;    // KS*9*ld
     int tap, c0;
     bool ok;
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
-        const int r4 = RCMap<R, TR>::r4(tid), k0 = RCMap<R, TR>::kfirst(tid);
+        const int r4 = RCMap<R, NT>::r4(tid), k0 = RCMap<R, NT>::kfirst(tid);
         ok = row0 + r4 < o.rows;
         const int chunk = kbase / BK;      // same K order as TConvKC: channel block outer, tap inner
         tap = chunk % 9;
@@ -416,9 +410,9 @@ __device__ __forceinline__ float4 ldb8_if(const unsigned short* p, bool ok) {   
 // forward-conv weights, rows = co, K order of ConvKC (channel block outer, tap inner).  Per wave instruction: 8 rows x
 // (hi, lo); quad q = lane/4: plane = (q>>2)&1, row = 4*(q&3) + (q>>3) (+2 for odd waves, +16 per wave pair, +32 per pass):
 // a 16-lane group writes rows r, r+4, r+8, r+12 of one plane (row stride 80 B -> 4 x 64 B tile 256 B of banks).
-template <int R>
+template <int R, int NT = 256>
 struct WgtKCs {
-    static constexpr int NI = R / 32;
+    static constexpr int NI = R * 8 / NT;
     static constexpr bool kKC = true;
     const unsigned short* ptr[NI];   // split + 2*(row*ld) + plane*32 + k8
     bool ok[NI];
@@ -435,7 +429,7 @@ struct WgtKCs {
         c0 = (chunk / 9) * BK;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = row0 + row_of(tid) + 32 * i;
+            const int r = row0 + row_of(tid) + (NT / 8) * i;
             ok[i] = r < o.rows;
             ptr[i] = o.split + 2 * ((long long)r * o.ld) + plane_of(tid) * 32 + k8;
         }
@@ -452,19 +446,19 @@ struct WgtKCs {
         unsigned short* pl = plane_of(tid) ? sl : sh;
         const int k8 = (tid & 3) * 8;
 #pragma unroll
-        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(pl + (row_of(tid) + 32 * i) * LDH + k8) = v[i];
+        for (int i = 0; i < NI; ++i) *reinterpret_cast<float4*>(pl + (row_of(tid) + (NT / 8) * i) * LDH + k8) = v[i];
     }
 };
 
 // weights seen from dgrad (rows = ci contiguous, k = (tap, co)), LDS image [k][R + 32] like RCStore.  A k row of the
 // tile is R/32 blocks = R*4 contiguous bytes; lane l of a 32-lane half: plane = l>>4 (R = 128), block = (l>>2)&3,
 // 8-row piece = l&3; the two halves of a wave take two k rows.  16 lanes = one plane, 256 contiguous LDS bytes.
-template <int R>
+template <int R, int NT = 256>
 struct WgtRCs {
-    static constexpr int NI = R / 32;
+    static constexpr int NI = R * 8 / NT;
     static constexpr int NBLK = R / 32;            // 32-row blocks per k row
     static constexpr int LPK = 8 * NBLK;           // lanes per k row (hi + lo)
-    static constexpr int KS = 256 / LPK;           // k rows per pass
+    static constexpr int KS = NT / LPK;            // k rows per pass
     static constexpr int NP = BK / KS;             // passes (== NI)
     static constexpr bool kKC = false;
     const unsigned short* ptr;
@@ -501,17 +495,17 @@ struct WgtRCs {
 };
 
 // conv gather, weight-gradient direction: rows = tap*C + ci (fixed per thread), k = output pixels
-template <int R, bool TR>
-struct ConvRC : RCStore<R, TR> {
-    static constexpr int NI = R / 32;
-    static constexpr int KS = RCMap<R, TR>::KSTEP;
+template <int R, int NT>
+struct ConvRC : RCStore<R, NT> {
+    static constexpr int NI = R * 8 / NT;
+    static constexpr int KS = RCMap<R, NT>::KSTEP;
     static constexpr bool kKC = false;
     int kh, kw, ci, pix, Kp;
     bool ok, same;
     const float* ptr;      // "same" geometry: address of input pixel (pix + dtap), channel ci
     long long step, adv;   // KS * ld, BK * ld
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int K) {
-        const int r4 = RCMap<R, TR>::r4(tid), k0 = RCMap<R, TR>::kfirst(tid);
+        const int r4 = RCMap<R, NT>::r4(tid), k0 = RCMap<R, NT>::kfirst(tid);
         const int r = row0 + r4;
         const int tap = r / o.C;
         ci = r - tap * o.C;
@@ -557,9 +551,9 @@ struct ConvRC : RCStore<R, TR> {
 // =================================================================================================
 // GENERIC loaders (any kind / alignment; per-element address math).
 // =================================================================================================
-template <int R>
-struct GenericKC : KCStore<R> {
-    static constexpr int NI = R / 32;
+template <int R, int NT = 256>
+struct GenericKC : KCStore<R, NT> {
+    static constexpr int NI = R * 8 / NT;
     static constexpr bool kKC = true;
     long long base[NI];
     int yb[NI], xb[NI];
@@ -568,7 +562,7 @@ struct GenericKC : KCStore<R> {
         k4 = (tid & 7) * 4; kbase = kb; K = K_;
 #pragma unroll
         for (int i = 0; i < NI; ++i) {
-            const int r = row0 + krow(tid) + 32 * i;
+            const int r = row0 + krow(tid) + (NT / 8) * i;
             const bool ok = r < o.rows;
             if (o.kind == BD_OPK_DENSE) {
                 base[i] = (long long)r * o.ld;
@@ -629,17 +623,17 @@ struct GenericKC : KCStore<R> {
     __device__ __forceinline__ void advance(const Opnd&) { kbase += BK; }
 };
 
-template <int R, bool TR>
-struct GenericRC : RCStore<R, TR> {
-    static constexpr int NI = R / 32;
-    static constexpr int KS = RCMap<R, TR>::KSTEP;
+template <int R, int NT>
+struct GenericRC : RCStore<R, NT> {
+    static constexpr int NI = R * 8 / NT;
+    static constexpr int KS = RCMap<R, NT>::KSTEP;
     static constexpr bool kKC = false;
     int k0, row, kbase, K;
     int kh[4], kw[4], ci[4];
     bool rok[4];
     __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kb, int K_) {
-        const int r4 = RCMap<R, TR>::r4(tid);
-        k0 = RCMap<R, TR>::kfirst(tid);
+        const int r4 = RCMap<R, NT>::r4(tid);
+        k0 = RCMap<R, NT>::kfirst(tid);
         row = row0 + r4; kbase = kb; K = K_;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -752,10 +746,10 @@ __device__ __forceinline__ void epilogue(const IGemmParams& p, floatx16 (&acc)[T
 // Every RC A value passes through the registers of exactly one thread of every n-tile's workgroup; the tn == 0
 // workgroups add theirs up (thread-fixed row quad r4, k phases kfirst + KSTEP*i), fold the k phases through LDS in a
 // fixed order and emit out[m] (or one split-K partial row).  No extra memory traffic, deterministic.
-template <int BM>
+template <int BM, int NT>
 __device__ __forceinline__ void colsum_tail(const IGemmParams& p, float* red, float4 cs, int tid, int m0, int zz) {
-    constexpr int NPH = 1024 / BM;   // k phases = 256 threads / (BM/4) row quads
-    *reinterpret_cast<float4*>(red + RCMap<BM, false>::kfirst(tid) * BM + RCMap<BM, false>::r4(tid)) = cs;
+    constexpr int NPH = NT * 4 / BM;   // k phases = NT threads / (BM/4) row quads
+    *reinterpret_cast<float4*>(red + RCMap<BM, NT>::kfirst(tid) * BM + RCMap<BM, NT>::r4(tid)) = cs;
     __syncthreads();
     if (tid < BM && m0 + tid < p.M) {
         float v = 0.f;
@@ -866,7 +860,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
         __syncthreads();
     }
 
-    if (do_cs) colsum_tail<BM>(p, sA, cs, tid, m0, wg.zz);
+    if (do_cs) colsum_tail<BM, 256>(p, sA, cs, tid, m0, wg.zz);
     epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi, wg.zz);
 }
 
@@ -874,9 +868,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 // split-bf16 kernel: same tiling / staging, but the register -> LDS store splits every fp32 value ONCE into
 // hi + lo bf16 planes ([rows][32 + 8] bf16 each, RC operands transposed in registers on the way), and the
 // K loop issues hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) from ds_read_b128 fragments.
-template <int BM, int BN, class LA, class LB>
-__global__ __launch_bounds__(256, 2) void igemm_bf16x3_kernel(IGemmParams p) {
-    constexpr int WM = BM / 2, WN = BN / 2, TM = WM / 32, TN = WN / 32;
+template <int BM, int BN, class LA, class LB, int NT>
+__global__ __launch_bounds__(NT, NT / 128) void igemm_bf16x3_kernel(IGemmParams p) {   // (threads, min waves per SIMD)
+    // waves: (NT/128) x 2 over the tile; 256 threads -> 64x64 per wave (2 workgroups = 2 waves per SIMD), 512 threads ->
+    // 32x64 per wave: half the accumulators and half the staging registers per thread, 4 waves per SIMD
+    constexpr int WAVES_M = NT / 128;
+    constexpr int WM = BM / WAVES_M, WN = BN / 2, TM = WM / 32, TN = WN / 32;
     constexpr bool A_KC = LA::kKC, B_KC = LB::kKC;
     constexpr int A_SZ = A_KC ? BM * LDH : BK * (BM + 32), B_SZ = B_KC ? BN * LDH : BK * (BN + 32);
     __shared__ __attribute__((aligned(16))) unsigned short sAh[A_SZ];
@@ -920,7 +917,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16x3_kernel(IGemmParams p) {
     // is refilled with chunk c+2, whose loads then have two MFMA sections to land.  The loads are unconditional
     // (predicated by address, ld4_if) and there is no branch in the loop body, so the compiler waits with exact
     // vmcnt(N) instead of vmcnt(0).  Chunks past c_end are loaded and never used (in-range addresses or masked off).
-    float4 ra0[BM / 32], rb0[BN / 32], ra1[BM / 32], rb1[BN / 32];
+    float4 ra0[LA::NI], rb0[LB::NI], ra1[LA::NI], rb1[LB::NI];
     la.load(A, ra0);
     lb.load(B, rb0);
     la.advance(A);
@@ -929,10 +926,10 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16x3_kernel(IGemmParams p) {
     lb.load(B, rb1);
     const bool do_cs = !A_KC && p.a_colsum != nullptr && wg.tn == 0;
     float4 cs = zero4();
-    auto step = [&](float4 (&ua)[BM / 32], float4 (&ub)[BN / 32]) {
+    auto step = [&](float4 (&ua)[LA::NI], float4 (&ub)[LB::NI]) {
         if (do_cs) {
 #pragma unroll
-            for (int i = 0; i < BM / 32; ++i) add4(cs, ua[i]);
+            for (int i = 0; i < LA::NI; ++i) add4(cs, ua[i]);
         }
         LA::store_split(sAh, sAl, tid, ua);
         LB::store_split(sBh, sBl, tid, ub);
@@ -987,7 +984,7 @@ __global__ __launch_bounds__(256, 2) void igemm_bf16x3_kernel(IGemmParams p) {
         step(ra1, rb1);
     }
     if (c < c_end) step(ra0, rb0);
-    if (do_cs) colsum_tail<BM>(p, reinterpret_cast<float*>(sAh), cs, tid, m0, wg.zz);
+    if (do_cs) colsum_tail<BM, NT>(p, reinterpret_cast<float*>(sAh), cs, tid, m0, wg.zz);
     epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi, wg.zz);
 }
 
@@ -1164,34 +1161,48 @@ static Cls classify(const bd_igemm_desc& d, bool fast) {
 
 // TR = true selects the split-bf16 kernel (RC operands keep the coalesced thread map; transposition happens in the
 // ds_read_b64_tr_b16 fragment reads)
-template <int T, bool TR, class LA, class LB>
+template <int T, bool TR, class LA, class LB, int NT = 256>
 static void launch1(const IGemmParams& p, dim3 grid, hipStream_t st) {
-    if constexpr (TR) hipLaunchKernelGGL((igemm_bf16x3_kernel<T, T, LA, LB>), grid, dim3(256), 0, st, p);
+    if constexpr (TR) hipLaunchKernelGGL((igemm_bf16x3_kernel<T, T, LA, LB, NT>), grid, dim3(NT), 0, st, p);
     else hipLaunchKernelGGL((igemm_kernel<T, T, LA, LB>), grid, dim3(256), 0, st, p);
+}
+
+// fast classes; NT = threads per workgroup (512 only for the split-bf16 128x128 tiles: 8 waves of 32x64)
+template <int T, bool TR, int NT>
+static bool launch_fast(const IGemmParams& p, Cls cls, dim3 grid, hipStream_t st) {
+    switch (cls) {
+        case CLS_CONV_FWD: launch1<T, TR, ConvKC<T, NT>, WgtKC<T, NT>, NT>(p, grid, st); return true;
+        case CLS_GEMM_NT: launch1<T, TR, DenseKC<T, NT>, DenseKC<T, NT>, NT>(p, grid, st); return true;
+        case CLS_CONV_DGRAD: launch1<T, TR, TConvKC<T, NT>, WgtRC<T, NT>, NT>(p, grid, st); return true;
+        case CLS_GEMM_NN: launch1<T, TR, DenseKC<T, NT>, DenseRC<T, NT>, NT>(p, grid, st); return true;
+        case CLS_CONV_WGRAD: launch1<T, TR, DenseRC<T, NT>, ConvRC<T, NT>, NT>(p, grid, st); return true;
+        case CLS_GEMM_TN: launch1<T, TR, DenseRC<T, NT>, DenseRC<T, NT>, NT>(p, grid, st); return true;
+        case CLS_CONV_FWD_WS:
+            if constexpr (TR) { launch1<T, true, ConvKC<T, NT>, WgtKCs<T, NT>, NT>(p, grid, st); return true; }
+            return false;
+        case CLS_CONV_DGRAD_WS:
+            if constexpr (TR) { launch1<T, true, TConvKC<T, NT>, WgtRCs<T, NT>, NT>(p, grid, st); return true; }
+            return false;
+        default: return false;
+    }
 }
 
 template <int T, bool TR>
 static void launch_tile(const IGemmParams& p, const bd_igemm_desc& d, Cls cls, dim3 grid, hipStream_t st) {
-    switch (cls) {
-        case CLS_CONV_FWD: launch1<T, TR, ConvKC<T>, WgtKC<T>>(p, grid, st); return;
-        case CLS_GEMM_NT: launch1<T, TR, DenseKC<T>, DenseKC<T>>(p, grid, st); return;
-        case CLS_CONV_DGRAD: launch1<T, TR, TConvKC<T>, WgtRC<T, false>>(p, grid, st); return;
-        case CLS_GEMM_NN: launch1<T, TR, DenseKC<T>, DenseRC<T, false>>(p, grid, st); return;
-        case CLS_CONV_WGRAD: launch1<T, TR, DenseRC<T, false>, ConvRC<T, false>>(p, grid, st); return;
-        case CLS_GEMM_TN: launch1<T, TR, DenseRC<T, false>, DenseRC<T, false>>(p, grid, st); return;
-        case CLS_CONV_FWD_WS:
-            if constexpr (TR) { launch1<T, true, ConvKC<T>, WgtKCs<T>>(p, grid, st); return; }
-            break;
-        case CLS_CONV_DGRAD_WS:
-            if constexpr (TR) { launch1<T, true, TConvKC<T>, WgtRCs<T>>(p, grid, st); return; }
-            break;
-        default: break;
+    // split-bf16 128x128 tiles run with 512 threads (8 waves of 32x64, 4 waves per SIMD): half the accumulators and
+    // staging registers per thread buys the occupancy that hides the split / staging work (conv fwd +7 %, dgrad +9 %,
+    // K=256 GEMMs +20..30 %).  The conv wgrad (both operands row-contiguous, the largest address state) does not fit
+    // 128 VGPRs without spilling and stays on 256 threads.  BD_IGEMM_NT=256 forces the narrow form everywhere.
+    static const bool narrow = getenv("BD_IGEMM_NT") && atoi(getenv("BD_IGEMM_NT")) == 256;
+    if constexpr (TR && T == 128) {
+        if (!narrow && cls != CLS_CONV_WGRAD && launch_fast<T, TR, 512>(p, cls, grid, st)) return;
     }
+    if (launch_fast<T, TR, 256>(p, cls, grid, st)) return;
     const bool akc = d.A.kc != 0, bkc = d.B.kc != 0;
     if (akc && bkc) launch1<T, TR, GenericKC<T>, GenericKC<T>>(p, grid, st);
-    else if (akc && !bkc) launch1<T, TR, GenericKC<T>, GenericRC<T, false>>(p, grid, st);
-    else if (!akc && !bkc) launch1<T, TR, GenericRC<T, false>, GenericRC<T, false>>(p, grid, st);
-    else launch1<T, TR, GenericRC<T, false>, GenericKC<T>>(p, grid, st);
+    else if (akc && !bkc) launch1<T, TR, GenericKC<T>, GenericRC<T, 256>>(p, grid, st);
+    else if (!akc && !bkc) launch1<T, TR, GenericRC<T, 256>, GenericRC<T, 256>>(p, grid, st);
+    else launch1<T, TR, GenericRC<T, 256>, GenericKC<T>>(p, grid, st);
 }
 
 int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
