@@ -868,7 +868,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(IGemmParams p) {
 // split-bf16 kernel: same tiling / staging, but the register -> LDS store splits every fp32 value ONCE into
 // hi + lo bf16 planes ([rows][32 + 8] bf16 each, RC operands transposed in registers on the way), and the
 // K loop issues hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16 (fp32 accumulate) from ds_read_b128 fragments.
-template <int BM, int BN, class LA, class LB, int NT>
+template <int BM, int BN, class LA, class LB, int NT, int DEPTH>
 __global__ __launch_bounds__(NT, NT / 128) void igemm_bf16x3_kernel(IGemmParams p) {   // (threads, min waves per SIMD)
     // waves: (NT/128) x 2 over the tile; 256 threads -> 64x64 per wave (2 workgroups = 2 waves per SIMD), 512 threads ->
     // 32x64 per wave: half the accumulators and half the staging registers per thread, 4 waves per SIMD
@@ -917,13 +917,17 @@ __global__ __launch_bounds__(NT, NT / 128) void igemm_bf16x3_kernel(IGemmParams 
     // is refilled with chunk c+2, whose loads then have two MFMA sections to land.  The loads are unconditional
     // (predicated by address, ld4_if) and there is no branch in the loop body, so the compiler waits with exact
     // vmcnt(N) instead of vmcnt(0).  Chunks past c_end are loaded and never used (in-range addresses or masked off).
-    float4 ra0[LA::NI], rb0[LB::NI], ra1[LA::NI], rb1[LB::NI];
+    // (DEPTH == 1: a single register set, refilled with chunk c+1 -- for the operand pairs whose address state does not
+    // leave room for two sets under the 128-VGPR budget of the 512-thread form.)
+    float4 ra0[LA::NI], rb0[LB::NI], ra1[DEPTH == 2 ? LA::NI : 1], rb1[DEPTH == 2 ? LB::NI : 1];
     la.load(A, ra0);
     lb.load(B, rb0);
-    la.advance(A);
-    lb.advance(B);
-    la.load(A, ra1);
-    lb.load(B, rb1);
+    if constexpr (DEPTH == 2) {
+        la.advance(A);
+        lb.advance(B);
+        la.load(A, ra1);
+        lb.load(B, rb1);
+    }
     const bool do_cs = !A_KC && p.a_colsum != nullptr && wg.tn == 0;
     float4 cs = zero4();
     auto step = [&](float4 (&ua)[LA::NI], float4 (&ub)[LB::NI]) {
@@ -978,12 +982,16 @@ __global__ __launch_bounds__(NT, NT / 128) void igemm_bf16x3_kernel(IGemmParams 
         }
         __syncthreads();
     };
-    int c = c_begin;
-    for (; c + 1 < c_end; c += 2) {
-        step(ra0, rb0);
-        step(ra1, rb1);
+    if constexpr (DEPTH == 2) {
+        int c = c_begin;
+        for (; c + 1 < c_end; c += 2) {
+            step(ra0, rb0);
+            step(ra1, rb1);
+        }
+        if (c < c_end) step(ra0, rb0);
+    } else {
+        for (int c = c_begin; c < c_end; ++c) step(ra0, rb0);
     }
-    if (c < c_end) step(ra0, rb0);
     if (do_cs) colsum_tail<BM, NT>(p, reinterpret_cast<float*>(sAh), cs, tid, m0, wg.zz);
     epilogue<TM, TN>(p, acc, m0 + wm * WM, n0 + wn * WN, li, h, bo, bi, wg.zz);
 }
@@ -1161,9 +1169,9 @@ static Cls classify(const bd_igemm_desc& d, bool fast) {
 
 // TR = true selects the split-bf16 kernel (RC operands keep the coalesced thread map; transposition happens in the
 // ds_read_b64_tr_b16 fragment reads)
-template <int T, bool TR, class LA, class LB, int NT = 256>
+template <int T, bool TR, class LA, class LB, int NT = 256, int DEPTH = 2>
 static void launch1(const IGemmParams& p, dim3 grid, hipStream_t st) {
-    if constexpr (TR) hipLaunchKernelGGL((igemm_bf16x3_kernel<T, T, LA, LB, NT>), grid, dim3(NT), 0, st, p);
+    if constexpr (TR) hipLaunchKernelGGL((igemm_bf16x3_kernel<T, T, LA, LB, NT, DEPTH>), grid, dim3(NT), 0, st, p);
     else hipLaunchKernelGGL((igemm_kernel<T, T, LA, LB>), grid, dim3(256), 0, st, p);
 }
 
@@ -1175,7 +1183,7 @@ static bool launch_fast(const IGemmParams& p, Cls cls, dim3 grid, hipStream_t st
         case CLS_GEMM_NT: launch1<T, TR, DenseKC<T, NT>, DenseKC<T, NT>, NT>(p, grid, st); return true;
         case CLS_CONV_DGRAD: launch1<T, TR, TConvKC<T, NT>, WgtRC<T, NT>, NT>(p, grid, st); return true;
         case CLS_GEMM_NN: launch1<T, TR, DenseKC<T, NT>, DenseRC<T, NT>, NT>(p, grid, st); return true;
-        case CLS_CONV_WGRAD: launch1<T, TR, DenseRC<T, NT>, ConvRC<T, NT>, NT>(p, grid, st); return true;
+        case CLS_CONV_WGRAD: launch1<T, TR, DenseRC<T, NT>, ConvRC<T, NT>, NT, (NT == 512 ? 1 : 2)>(p, grid, st); return true;
         case CLS_GEMM_TN: launch1<T, TR, DenseRC<T, NT>, DenseRC<T, NT>, NT>(p, grid, st); return true;
         case CLS_CONV_FWD_WS:
             if constexpr (TR) { launch1<T, true, ConvKC<T, NT>, WgtKCs<T, NT>, NT>(p, grid, st); return true; }
@@ -1191,11 +1199,11 @@ template <int T, bool TR>
 static void launch_tile(const IGemmParams& p, const bd_igemm_desc& d, Cls cls, dim3 grid, hipStream_t st) {
     // split-bf16 128x128 tiles run with 512 threads (8 waves of 32x64, 4 waves per SIMD): half the accumulators and
     // staging registers per thread buys the occupancy that hides the split / staging work (conv fwd +7 %, dgrad +9 %,
-    // K=256 GEMMs +20..30 %).  The conv wgrad (both operands row-contiguous, the largest address state) does not fit
-    // 128 VGPRs without spilling and stays on 256 threads.  BD_IGEMM_NT=256 forces the narrow form everywhere.
+    // K=256 GEMMs +20..30 %).  The conv wgrad (both operands row-contiguous, the largest address state) fits 128 VGPRs
+    // only with a single prefetch register set (DEPTH 1).  BD_IGEMM_NT=256 forces the narrow form everywhere.
     static const bool narrow = getenv("BD_IGEMM_NT") && atoi(getenv("BD_IGEMM_NT")) == 256;
     if constexpr (TR && T == 128) {
-        if (!narrow && cls != CLS_CONV_WGRAD && launch_fast<T, TR, 512>(p, cls, grid, st)) return;
+        if (!narrow && launch_fast<T, TR, 512>(p, cls, grid, st)) return;
     }
     if (launch_fast<T, TR, 256>(p, cls, grid, st)) return;
     const bool akc = d.A.kc != 0, bkc = d.B.kc != 0;
