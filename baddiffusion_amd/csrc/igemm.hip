@@ -1182,9 +1182,9 @@ static bool launch_fast(const IGemmParams& p, Cls cls, dim3 grid, hipStream_t st
         case CLS_CONV_FWD: launch1<T, TR, ConvKC<T, NT>, WgtKC<T, NT>, NT>(p, grid, st); return true;
         case CLS_GEMM_NT: launch1<T, TR, DenseKC<T, NT>, DenseKC<T, NT>, NT>(p, grid, st); return true;
         case CLS_CONV_DGRAD: launch1<T, TR, TConvKC<T, NT>, WgtRC<T, NT>, NT>(p, grid, st); return true;
-        case CLS_GEMM_NN: launch1<T, TR, DenseKC<T, NT>, DenseRC<T, NT>, NT>(p, grid, st); return true;
+        case CLS_GEMM_NN: launch1<T, TR, DenseKC<T, NT>, DenseRC<T, NT>, NT, (NT == 512 ? 1 : 2)>(p, grid, st); return true;
         case CLS_CONV_WGRAD: launch1<T, TR, DenseRC<T, NT>, ConvRC<T, NT>, NT, (NT == 512 ? 1 : 2)>(p, grid, st); return true;
-        case CLS_GEMM_TN: launch1<T, TR, DenseRC<T, NT>, DenseRC<T, NT>, NT>(p, grid, st); return true;
+        case CLS_GEMM_TN: launch1<T, TR, DenseRC<T, NT>, DenseRC<T, NT>, NT, (NT == 512 ? 1 : 2)>(p, grid, st); return true;
         case CLS_CONV_FWD_WS:
             if constexpr (TR) { launch1<T, true, ConvKC<T, NT>, WgtKCs<T, NT>, NT>(p, grid, st); return true; }
             return false;
