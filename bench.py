@@ -32,16 +32,16 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA (split-bf16 mode issues 
 HBM_PEAK_GBS = 8000.0
 
 
-_PMC_OPERANDS = {"conv_fwd": "ConvKC<{T}>, bd::WgtKC<{T}>", "conv_dgrad": "TConvKC<{T}>, bd::WgtRC<{T}, false>",
-                 "conv_wgrad": "DenseRC<{T}, false>, bd::ConvRC<{T}, false>", "gemm_nt": "DenseKC<{T}>, bd::DenseKC<{T}>",
-                 "gemm_nn": "DenseKC<{T}>, bd::DenseRC<{T}, false>", "gemm_tn": "DenseRC<{T}, false>, bd::DenseRC<{T}, false>"}
+_PMC_OPERANDS = {"conv_fwd": ("ConvKC", ("WgtKC", "WgtKCs")), "conv_dgrad": ("TConvKC", ("WgtRC", "WgtRCs")),
+                 "conv_wgrad": ("DenseRC", ("ConvRC",)), "gemm_nt": ("DenseKC", ("DenseKC",)),
+                 "gemm_nn": ("DenseKC", ("DenseRC",)), "gemm_tn": ("DenseRC", ("DenseRC",))}
 
 
 def _pmc_traffic(cls):
     """HBM-side bytes per launch of kernel class `cls` from the committed rocprofv3 PMC passes of this same command
     (scripts/pmc_bench.sh -> profiles/r01_pmc_bench_<mode>.json; FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950
-    correction for 16 B/lane reads, + WRITE_SIZE; KB -> bytes).  None when that file or kernel is absent: counters
-    cannot be collected from inside the timed process."""
+    correction for 16 B/lane reads, + WRITE_SIZE; KB -> bytes; launch-weighted over the kernel instantiations of the
+    class).  None when that file or kernel is absent: counters cannot be collected from inside the timed process."""
     import re
     m = re.match(r"igemm_(\w+?)_(\d+)(_bf16x3)?$", cls)
     if not m or m.group(1) not in _PMC_OPERANDS:
@@ -50,12 +50,16 @@ def _pmc_traffic(cls):
     path = os.path.join(ROOT, "profiles", f"r01_pmc_bench_{mode}.json")
     if not os.path.exists(path):
         return None
-    T = m.group(2)
-    want = ("igemm_bf16x3_kernel" if m.group(3) else "igemm_kernel") + f"<{T}, {T}, bd::" + _PMC_OPERANDS[m.group(1)].format(T=T)
+    la, lbs = _PMC_OPERANDS[m.group(1)]
+    kname = "igemm_bf16x3_kernel" if m.group(3) else "igemm_kernel"
+    pat = re.compile(rf"{kname}<{m.group(2)}, {m.group(2)}, bd::(\w+)<[^>]*>, bd::(\w+)<[^>]*>")
+    tot = n = 0.0
     for name, v in json.load(open(path))["kernels"].items():
-        if want in name and "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
-            return (2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0
-    return None
+        mm = pat.search(name)
+        if mm and mm.group(1) == la and mm.group(2) in lbs and "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
+            tot += (2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0 * v["launches"]
+            n += v["launches"]
+    return tot / n if n else None
 
 
 def _host_cores():
