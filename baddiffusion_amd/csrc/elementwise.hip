@@ -337,12 +337,16 @@ __global__ __launch_bounds__(TPB) void loss_kernel(const float* pred, int64_t ld
     double r = block_sum(acc, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = r;
 }
-__global__ void loss_final_kernel(const double* part, int nb, int64_t n, float* loss) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < nb; ++i) s += part[i];
-        *loss = (float)(s / (double)n);
-    }
+// second stage of the two-stage reductions: one wave, lane l sums partials l, l+64, ... and the lanes are folded with a
+// fixed shuffle tree (deterministic)
+__device__ __forceinline__ double final_sum(const double* part, int nb) {
+    double s = 0.0;
+    for (int i = threadIdx.x; i < nb; i += 64) s += part[i];
+    return wave_sum(s);
+}
+__global__ __launch_bounds__(64) void loss_final_kernel(const double* part, int nb, int64_t n, float* loss) {
+    const double s = final_sum(part, nb);
+    if (threadIdx.x == 0) *loss = (float)(s / (double)n);
 }
 
 __global__ __launch_bounds__(TPB) void sumsq_kernel(const float* g, int64_t n, double* part) {
@@ -357,12 +361,9 @@ __global__ __launch_bounds__(TPB) void sumsq_kernel(const float* g, int64_t n, d
     double r = block_sum(acc, sh);
     if (threadIdx.x == 0) part[blockIdx.x] = r;
 }
-__global__ void sumsq_final_kernel(const double* part, int nb, double* out) {
-    if (threadIdx.x == 0 && blockIdx.x == 0) {
-        double s = 0.0;
-        for (int i = 0; i < nb; ++i) s += part[i];
-        *out = s;
-    }
+__global__ __launch_bounds__(64) void sumsq_final_kernel(const double* part, int nb, double* out) {
+    const double s = final_sum(part, nb);
+    if (threadIdx.x == 0) *out = s;
 }
 
 // clip_grad_norm_(max_norm) + torch.optim.Adam (single-tensor formulas), flat buffers
