@@ -211,25 +211,26 @@ def test_two_stream_schedule_matches_single_stream(bd, B):
     assert relerr(res[0][0][idx], ref) < 1e-4
 
 
-def test_forward_backward_hipgraph_capture(bd):
+@pytest.mark.parametrize("B", [2, 40])     # 40: the forward also forks into its two half-batch pipelines
+def test_forward_backward_hipgraph_capture(bd, B):
     """the C ABI only enqueues on the given stream (and, in backward, on the plan's side stream forked / joined with
     events): a whole forward + backward is capturable in a HIP graph and replays to the same bits as the eager run"""
     unet, ops = bd
     cfg = C.SMALL_CFGS["small"]
     m = make_model(unet, cfg, 7)
-    x = torch.randn(2, 16, 16, 3, generator=torch.Generator().manual_seed(1)).cuda()
-    t = torch.tensor([10, 900]).cuda()
-    dout = torch.randn(2, 16, 16, 3, generator=torch.Generator().manual_seed(2)).cuda()
-    ws = torch.empty(m.workspace_bytes(2, True), dtype=torch.uint8, device="cuda")
-    out_e = torch.empty(2, 16, 16, 3, device="cuda"); g_e = torch.zeros(m.num_flat, device="cuda")
+    x = torch.randn(B, 16, 16, 3, generator=torch.Generator().manual_seed(1)).cuda()
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(5)).cuda()
+    dout = torch.randn(B, 16, 16, 3, generator=torch.Generator().manual_seed(2)).cuda()
+    ws = torch.empty(m.workspace_bytes(B, True), dtype=torch.uint8, device="cuda")
+    out_e = torch.empty(B, 16, 16, 3, device="cuda"); g_e = torch.zeros(m.num_flat, device="cuda")
     out_g = torch.empty_like(out_e); g_g = torch.zeros_like(g_e)
     from baddiffusion_amd import _lib as L
     lib = L.load()
 
     def run(out, grads):
-        L.check(lib.bd_unet_forward(m._plan, 2, 1, m.flat.data_ptr(), x.data_ptr(), 3, t.data_ptr(), 1, out.data_ptr(), 3,
+        L.check(lib.bd_unet_forward(m._plan, B, 1, m.flat.data_ptr(), x.data_ptr(), 3, t.data_ptr(), 1, out.data_ptr(), 3,
                                     ws.data_ptr(), ws.numel(), L.stream()), "fwd")
-        L.check(lib.bd_unet_backward(m._plan, 2, m.flat.data_ptr(), x.data_ptr(), 3, dout.data_ptr(), 3, grads.data_ptr(),
+        L.check(lib.bd_unet_backward(m._plan, B, m.flat.data_ptr(), x.data_ptr(), 3, dout.data_ptr(), 3, grads.data_ptr(),
                                      ws.data_ptr(), ws.numel(), L.stream()), "bwd")
 
     run(out_e, g_e)                      # eager (also creates the plan's side stream outside of the capture)
