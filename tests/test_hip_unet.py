@@ -156,6 +156,36 @@ def test_celeba_topology_train_step_vs_oracle(bd, mode):
     assert worst[0] < 1e-3, worst
 
 
+def test_cifar_full_batch_modes_and_schedules_agree(bd):
+    """BASELINE configs[1] at its full size (DDPM-CIFAR10-32, batch 128): the oracle would need a minute, so the check
+    is self-consistency across the independent code paths -- split-bf16 vs exact-fp32 contraction, two-stream vs
+    single-stream schedule -- plus per-sample independence (sample i of the batch == the same sample run alone)."""
+    unet, ops = bd
+    cfg = U.CIFAR10_32
+    m = make_model(unet, cfg, 0)
+    B = 128
+    x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(3)).cuda()
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(4)).cuda()
+    dout = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(5)).cuda() / (B * 3072)
+    res = {}
+    for mode, aux in (("f32", True), ("bf16x3", True), ("bf16x3", False)):
+        m.set_compute_mode(mode); m.set_aux_stream(aux)
+        m.flat.grad = None
+        out = m(x, t, return_dict=False)[0]
+        out.backward(dout)
+        assert torch.isfinite(out).all() and torch.isfinite(m.flat.grad).all()
+        res[(mode, aux)] = (out.detach().clone(), m.flat.grad.detach().clone())
+    m.set_aux_stream(True)
+    assert relerr(res[("bf16x3", True)][0], res[("f32", True)][0]) < 1e-4
+    assert relerr(res[("bf16x3", True)][1], res[("f32", True)][1]) < 1e-3
+    assert relerr(res[("bf16x3", True)][0], res[("bf16x3", False)][0]) < 5e-5
+    assert relerr(res[("bf16x3", True)][1], res[("bf16x3", False)][1]) < 2e-4
+    with torch.no_grad():
+        for i in (0, 63, 64, 127):     # both half-batch pipelines
+            alone = m(x[i:i + 1], t[i:i + 1], return_dict=False)[0]
+            assert relerr(alone, res[("bf16x3", True)][0][i:i + 1]) < 5e-5
+
+
 def test_celeba_full_resolution_modes_agree(bd):
     """the real 256x256 DDPM-CELEBA-HQ-256 network (113.7 M parameters), batch 1: forward + backward run, are finite,
     and the split-bf16 contraction agrees with the exact-fp32 one (size-independent self-consistency; the oracle
