@@ -1109,7 +1109,6 @@ static Choice choose(const bd_igemm_desc& d) {
     const int nb = d.batch_outer * d.batch_inner;
     auto tiles = [&](int t) { return cdiv(d.M, t) * cdiv(d.N, t) * nb; };
     // 128x128 tiles (32 flop per staged byte) whenever both dims allow; split K to put ~1.5 workgroups on each CU
-    // (measured sweep of the target 256..640: 384 is the optimum for the CIFAR UNet step, more splits cost partial traffic)
     c.tile = d.tile ? d.tile : ((d.M >= 128 && d.N >= 128) ? 128 : 64);
     const int nchunks = (int)cdiv(d.K, BK);
     int ks = d.ksplit;
@@ -1117,7 +1116,17 @@ static Choice choose(const bd_igemm_desc& d) {
         long long t = tiles(c.tile);
         ks = 1;
         if (t < 256) {
-            ks = (int)cdiv(384, t);
+            // ~1.5 workgroups per CU, never more than the budget (rounding the split count UP would spill a few
+            // workgroups into a second, nearly empty round).  Sweep of the budget 384 / 448 / 512 / 640 on the CIFAR
+            // step: 25.07 / 25.15 / 25.16 / 25.55 ms -- beyond ~1.5 per CU the extra partial tiles cost more than the
+            // fuller chip gains (the second stream fills idle CUs anyway).
+            static const int slots = [] {
+                int dev = 0, cus = 256;
+                if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+                return 3 * cus / 2;
+            }();
+            ks = (int)(slots / t);
+            if (ks < 1) ks = 1;
             int maxks = nchunks / 8;
             if (maxks < 1) maxks = 1;
             if (ks > maxks) ks = maxks;
