@@ -23,6 +23,9 @@
 #include <cstdlib>
 
 namespace bd {
+#ifndef WGRAD_DEPTH
+#define WGRAD_DEPTH 2
+#endif
 
 typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -49,6 +52,7 @@ struct Opnd {
     int kind, vec;
     int C, Hs, Ws, Ho, Wo, stride, pad_t, pad_l, ups;
     int rows;      // number of valid rows (M for A, N for B)
+    int rows_k;    // extent of the K dimension (RC conv gather: number of output pixels)
     int lw, lhw;   // log2(Wo), log2(Ho*Wo) when both are powers of two, else -1
 };
 
@@ -546,6 +550,42 @@ struct ConvRC : RCStore<R, NT> {
         }
     }
     __device__ __forceinline__ void advance(const Opnd&) { pix += BK; ptr += adv; }
+};
+
+// ConvRC restricted to stride-1 "same" convolutions (output grid == input grid; all but the 6 resampling layers):
+// the input pixel of output pixel p and this thread's tap is p + const, so the state is one running pointer, the pixel
+// index and the tap offsets -- few enough registers that the 512-thread wgrad keeps two prefetch sets.
+template <int R, int NT>
+struct ConvRCs : RCStore<R, NT> {
+    static constexpr int NI = RCMap<R, NT>::NI;
+    static constexpr int KS = RCMap<R, NT>::KSTEP;
+    static constexpr bool kKC = false;
+    const float* ptr;   // address of input pixel (pix + dtap), channel ci
+    int pix, dyx;       // output pixel of load 0; (kh - pad_t) in the high half, (kw - pad_l) in the low half (biased by 1)
+    bool ok;
+    __device__ __forceinline__ void init(const Opnd& o, int row0, int tid, int kbase, int) {
+        const int r4 = RCMap<R, NT>::r4(tid), k0 = RCMap<R, NT>::kfirst(tid);
+        const int r = row0 + r4;
+        const int tap = r / o.C, ci = r - tap * o.C;
+        const int kh = tap / 3, kw = tap - kh * 3;
+        ok = r < o.rows;
+        pix = kbase + k0;
+        dyx = ((kh - o.pad_t + 1) << 8) | (kw - o.pad_l + 1);
+        ptr = o.p + ((long long)pix + (long long)(kh - o.pad_t) * o.Ws + (kw - o.pad_l)) * o.ld + ci;
+    }
+    __device__ __forceinline__ void load(const Opnd& o, float4 (&v)[NI]) const {
+        const int dy = (dyx >> 8) - 1, dx = (dyx & 255) - 1;
+        const long long step = (long long)KS * o.ld;
+#pragma unroll
+        for (int i = 0; i < NI; ++i) {
+            const int p = pix + KS * i;
+            int b, y, x;
+            decode_pixel(o, p, b, y, x);
+            const bool okk = ok && p < o.rows_k && (unsigned)(y + dy) < (unsigned)o.Hs && (unsigned)(x + dx) < (unsigned)o.Ws;
+            v[i] = ld4_if(ptr + step * i, okk, o.p);
+        }
+    }
+    __device__ __forceinline__ void advance(const Opnd& o) { pix += BK; ptr += (long long)BK * o.ld; }
 };
 
 // =================================================================================================
@@ -1093,7 +1133,7 @@ static Opnd make_opnd(const bd_operand& o, int rows, int K) {
     Opnd r;
     r.p = o.p; r.split = o.split; r.ld = o.ld; r.kind = o.kind; r.vec = operand_vec_ok(o, rows, K) ? 1 : 0;
     r.C = o.C > 0 ? o.C : 1; r.Hs = o.Hs; r.Ws = o.Ws; r.Ho = o.Ho > 0 ? o.Ho : 1; r.Wo = o.Wo > 0 ? o.Wo : 1;
-    r.stride = o.stride > 0 ? o.stride : 1; r.pad_t = o.pad_t; r.pad_l = o.pad_l; r.ups = o.ups; r.rows = rows;
+    r.stride = o.stride > 0 ? o.stride : 1; r.pad_t = o.pad_t; r.pad_l = o.pad_l; r.ups = o.ups; r.rows = rows; r.rows_k = K;
     const int lw = ilog2_exact(r.Wo), lh = ilog2_exact(r.Ho);
     r.lw = (lw >= 0 && lh >= 0) ? lw : -1;
     r.lhw = (lw >= 0 && lh >= 0) ? lw + lh : -1;
@@ -1147,9 +1187,10 @@ size_t igemm_workspace_bytes(const bd_igemm_desc& d) {
 }
 
 enum Cls { CLS_GENERIC = 0, CLS_CONV_FWD, CLS_CONV_DGRAD, CLS_CONV_WGRAD, CLS_GEMM_NT, CLS_GEMM_NN, CLS_GEMM_TN,
-           CLS_CONV_FWD_WS, CLS_CONV_DGRAD_WS };   // _WS: weights (B) taken from pre-split bf16 planes
+           CLS_CONV_FWD_WS, CLS_CONV_DGRAD_WS,     // _WS: weights (B) taken from pre-split bf16 planes
+           CLS_CONV_WGRAD_SAME };                  // stride-1 same-size geometry: slim gather loader
 static const char* kClsName[] = {"generic", "conv_fwd", "conv_dgrad", "conv_wgrad", "gemm_nt", "gemm_nn", "gemm_tn",
-                                 "conv_fwd", "conv_dgrad"};
+                                 "conv_fwd", "conv_dgrad", "conv_wgrad"};
 
 static bool presplit_ok(const bd_igemm_desc& d) {
     const bd_operand& o = d.B;
@@ -1170,7 +1211,11 @@ static Cls classify(const bd_igemm_desc& d, bool fast) {
         if (ak == BD_OPK_TCONV && bk == BD_OPK_WGT) return presplit_ok(d) ? CLS_CONV_DGRAD_WS : CLS_CONV_DGRAD;
         if (ak == BD_OPK_DENSE && bk == BD_OPK_DENSE) return CLS_GEMM_NN;
     } else if (!akc && !bkc) {
-        if (ak == BD_OPK_DENSE && bk == BD_OPK_CONV) return CLS_CONV_WGRAD;
+        if (ak == BD_OPK_DENSE && bk == BD_OPK_CONV) {
+            const bd_operand& o = d.B;
+            const bool same = o.stride == 1 && o.ups == 0 && o.Ho == o.Hs && o.Wo == o.Ws && o.pad_t <= 1 && o.pad_l <= 1;
+            return same ? CLS_CONV_WGRAD_SAME : CLS_CONV_WGRAD;
+        }
         if (ak == BD_OPK_DENSE && bk == BD_OPK_DENSE) return CLS_GEMM_TN;
     }
     return CLS_GENERIC;
@@ -1193,6 +1238,7 @@ static bool launch_fast(const IGemmParams& p, Cls cls, dim3 grid, hipStream_t st
         case CLS_CONV_DGRAD: launch1<T, TR, TConvKC<T, NT>, WgtRC<T, NT>, NT>(p, grid, st); return true;
         case CLS_GEMM_NN: launch1<T, TR, DenseKC<T, NT>, DenseRC<T, NT>, NT, (NT == 512 ? 1 : 2)>(p, grid, st); return true;
         case CLS_CONV_WGRAD: launch1<T, TR, DenseRC<T, NT>, ConvRC<T, NT>, NT, (NT == 512 ? 1 : 2)>(p, grid, st); return true;
+        case CLS_CONV_WGRAD_SAME: launch1<T, TR, DenseRC<T, NT>, ConvRCs<T, NT>, NT, (NT == 512 ? 1 : 2)>(p, grid, st); return true;
         case CLS_GEMM_TN: launch1<T, TR, DenseRC<T, NT>, DenseRC<T, NT>, NT, (NT == 512 ? 1 : 2)>(p, grid, st); return true;
         case CLS_CONV_FWD_WS:
             if constexpr (TR) { launch1<T, true, ConvKC<T, NT>, WgtKCs<T, NT>, NT>(p, grid, st); return true; }
