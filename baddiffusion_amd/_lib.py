@@ -43,7 +43,8 @@ class DdimStepDesc(C.Structure):
 class GnFwdDesc(C.Structure):
     _fields_ = [("B", i32), ("HW", i32), ("C", i32), ("G", i32), ("eps", f32), ("silu", i32),
                 ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp), ("y", vp), ("ldy", i64),
-                ("mean", vp), ("rstd", vp), ("workspace", vp), ("workspace_bytes", sz)]
+                ("mean", vp), ("rstd", vp), ("workspace", vp), ("workspace_bytes", sz),
+                ("y_split", vp), ("ldys", i64)]
 
 
 class GnBwdDesc(C.Structure):
@@ -51,7 +52,7 @@ class GnBwdDesc(C.Structure):
                 ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp),
                 ("dy", vp), ("lddy", i64), ("dx", vp), ("lddx", i64), ("accumulate_dx", i32),
                 ("dgamma", vp), ("dbeta", vp), ("workspace", vp), ("workspace_bytes", sz),
-                ("dx_colsum", vp), ("ld_colsum", i64)]
+                ("dx_colsum", vp), ("ld_colsum", i64), ("dx_split", vp), ("lddxs", i64)]
 
 
 class Operand(C.Structure):
@@ -93,6 +94,12 @@ class ConvWgradDesc(C.Structure):
                 ("workspace", vp), ("workspace_bytes", sz), ("mode", i32), ("db", vp)]
 
 
+class ConvPsDesc(C.Structure):
+    _fields_ = [("B", i32), ("H", i32), ("W", i32), ("K", i32), ("N", i32), ("direction", i32),
+                ("x_split", vp), ("ldx", i64), ("w_split", vp), ("bias", vp), ("rowbias", vp), ("ld_rowbias", i64),
+                ("residual", vp), ("ldr", i64), ("out_scale", f32), ("y", vp), ("ldy", i64), ("accumulate", i32)]
+
+
 class UnetConfig(C.Structure):
     _fields_ = [("sample_size", i32), ("in_channels", i32), ("out_channels", i32), ("num_blocks", i32),
                 ("block_out_channels", i32 * 8), ("down_attn", i32 * 8), ("up_attn", i32 * 8),
@@ -120,6 +127,9 @@ SIGNATURES = {
     "bd_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),
     "bd_igemm": (i32, [C.POINTER(IgemmDesc), vp]),
     "bd_split_bf16": (i32, [vp, i64, vp, vp]),
+    "bd_split_rows": (i32, [vp, i64, i64, i32, vp, i64, vp]),
+    "bd_split_wt": (i32, [vp, i32, i32, vp, vp]),
+    "bd_conv3x3_ps": (i32, [C.POINTER(ConvPsDesc), vp]),
     "bd_conv3x3_fwd": (i32, [C.POINTER(ConvFwdDesc), vp]),
     "bd_conv3x3_dgrad": (i32, [C.POINTER(ConvDgradDesc), vp]),
     "bd_conv3x3_wgrad": (i32, [C.POINTER(ConvWgradDesc), vp]),

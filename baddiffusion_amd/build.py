@@ -20,6 +20,7 @@ SOURCES = [  # (file, extra flags)
     ("elementwise.hip", ["-ffp-contract=off"]),
     ("groupnorm.hip", []),
     ("igemm.hip", []),
+    ("conv_ps.hip", []),
     ("conv.cpp", ["-x", "hip"]),
     ("conv_thin.hip", []),
     ("unet_plan.cpp", ["-x", "hip"]),

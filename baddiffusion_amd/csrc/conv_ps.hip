@@ -1,0 +1,461 @@
+// 3x3 stride-1 "same" convolution and its data gradient on PRE-SPLIT operands, fed by LDS-DMA (gfx950).
+//
+// Same arithmetic as the split-bf16 igemm (igemm.hip: x = hi + lo, product = lo*hi + hi*lo + hi*hi on
+// v_mfma_f32_32x32x16_bf16, fp32 accumulate, K order = channel block outer / filter tap inner) and bit-identical to it,
+// but the operands arrive already split: producers (GroupNorm apply, GroupNorm backward, bd_split_rows) write the
+// bf16 hi|lo planes in the blocked layout of bd_split_bf16 -- per row, every 32-channel block is one 128-byte line,
+// 64 B of hi then 64 B of lo: the same 4 bytes per element as the fp32 tensor it replaces.  A K chunk (one tap, 32
+// channels) of an operand row is then exactly one line, and the main loop has no VALU work on the data at all:
+//   global --(global_load_lds_dwordx4, 16 B per lane, 8 lanes per row)--> LDS ring (3 stages of 256x128 + 128x128 B)
+//   LDS --(ds_read_b128, XOR-swizzled slots: conflict-free)--> MFMA fragments.
+// One workgroup = 8 waves (4 x 2) on a 256 x 128 tile (64 x 64 per wave), ONE barrier per K chunk; the DMA of chunk
+// c+2 is issued right after the barrier that retires chunk c-1's stage and is waited for with a counted vmcnt two
+// chunks later (cdna_hip_programming.md section 5, "Pipelining across barriers": raw s_barrier, never vmcnt(0) in the loop).
+// Zero padding: lanes whose tap falls outside the image read a 16-byte zero page instead (branch-free).
+//
+// data gradient of the same convolution: dx[p][ci] = sum_{tap,co} dy[p - tap][co] * W[co][tap][ci] is the same kernel
+// with the gather direction negated (sign = -1) over the TRANSPOSED weight planes Wt[ci][tap][co] (bd_split_wt).
+// Replaces aten::convolution / convolution_backward(input) of resnet.py:493,514 for the stride-1 convolutions.
+#include "common.h"
+#include <cstdlib>
+#include <type_traits>
+
+namespace bd {
+
+typedef float floatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr;
+typedef const __attribute__((address_space(1))) void* gbl_ptr;
+
+constexpr int PS_BM = 256, PS_BN = 128, PS_NT = 512, PS_STAGES = 3;
+constexpr int PS_A_BYTES = PS_BM * 128, PS_B_BYTES = PS_BN * 128, PS_STAGE_BYTES = PS_A_BYTES + PS_B_BYTES;
+constexpr int PS_LDS_BYTES = PS_STAGES * PS_STAGE_BYTES;   // 147456 of 163840
+
+struct PsParams {
+    const char* a;        // activation planes: row m at a + m*lda*4, channel block cb at + cb*128 (64 B hi | 64 B lo)
+    const char* w;        // weight planes [N][9][C]: row n, tap t, block cb at ((n*9 + t)*C + cb*32)*4
+    float* y;
+    const float* bias; const float* rowbias; const float* residual;
+    long long lda, ldy, ldr, ld_rowbias;
+    int C, H, W, lw, lhw;  // K channels ; image size (powers of two) and log2(W), log2(H*W)
+    int sign;              // +1 forward gather (x[p + tap]), -1 data-gradient gather (dy[p - tap])
+    int M, N, tiles_m, tiles_n;
+    float out_scale;
+    int accumulate;
+    unsigned short* y_split; long long ldys;   // optional second output: y in split planes (same row count, ld)
+    int ablate;            // measurement only (BD_PS_ABLATE): 1 = no steady-state DMA, 2 = no MFMA, 4 = no fragment reads
+};
+
+// bank swizzle of the 16-byte slots of a 128-byte LDS row (row stride 128 B = half a 256-byte bank row): rows r and
+// r^1 share a bank row, f spreads 16 consecutive rows over the 8 slots x 2 halves -> every ds_read_b128 lane group
+// (16 lanes = 16 different rows, same logical slot) touches each bank once.
+__device__ __forceinline__ int ps_swz(int row) { return (row >> 1) & 7; }
+
+// 16 zero bytes in the code object: the DMA source of lanes whose filter tap falls outside the image
+__device__ __attribute__((aligned(16))) const float kPsZero[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void ps_dma16(const char* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((gbl_ptr)src, (lds_ptr)lds_dst, 16, 0, 0);
+}
+
+// wait until at most N of this wave's DMAs are outstanding AND all of its LDS reads have returned, then the workgroup
+// barrier: behind it the chunk is visible to every wave and the stage read last may be refilled.  Raw s_barrier: a
+// __syncthreads() would drain the DMAs in flight (vmcnt(0)).
+template <int N>
+__device__ __forceinline__ void ps_sync() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 6) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+    else static_assert(N == 0, "unsupported vmcnt");
+    __builtin_amdgcn_s_barrier();
+}
+
+// phase boundary of the ping-pong schedule: nothing (MFMA, LDS read, DMA) is scheduled across it
+__device__ __forceinline__ void ps_phase() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// EPI bits: 1 = residual, 2 = per-sample row bias, 4 = accumulate into y
+// SCHED 0: all eight waves in lock step, one barrier per chunk.
+// SCHED 1: ping-pong.  Waves 0-3 and 4-7 (one of each per SIMD) run the same phase sequence
+//   L0 (refill DMA + fragment reads of K step 0) | C0 (12 MFMAs) | L1 (reads of step 1) | C1 (12 MFMAs), a barrier after
+//   every phase, the second group one phase behind: while one wave of a SIMD owns the matrix pipe its partner issues
+//   DMA / LDS reads (MI355X_MICROARCH.md "Two waves per SIMD").
+template <int EPI, int SCHED>
+__global__ __launch_bounds__(PS_NT, 2) void conv_ps_kernel(PsParams p) {
+    __shared__ __attribute__((aligned(128))) char smem[PS_LDS_BYTES];   // ONE LDS object (guide section 5, trap (a))
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+
+    // XCD-contiguous tile order (n fastest): tiles sharing an A panel meet in one L2 (igemm.hip wg_coord)
+    int tm, tn;
+    {
+        const unsigned L = blockIdx.x, T = gridDim.x, q = T >> 3;
+        const unsigned j = L < (q << 3) ? (L & 7) * q + (L >> 3) : L;
+        tm = j / p.tiles_n;
+        tn = j - tm * p.tiles_n;
+    }
+    const int m0 = tm * PS_BM, n0 = tn * PS_BN;
+
+    // ---- DMA state: wave w moves row groups (8 rows x 128 B = one 1-KiB instruction) w, w+8, w+16, w+24 of A and
+    // w, w+8 of B.  Lane l: row = 8*rg + l/8, physical slot l%8 <- logical slot (l%8) ^ swz(row).
+    const int dr = lane >> 3, ps = lane & 7;
+    const char* ap[4];
+    int vm[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = (wave + 8 * j) * 8 + dr;
+        const int m = m0 + r;
+        const int x = m & (p.W - 1), y = (m >> p.lw) & (p.H - 1);
+        int mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + p.sign * (t / 3 - 1), xx = x + p.sign * (t % 3 - 1);
+            if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) mask |= 1 << t;
+        }
+        vm[j] = m < p.M ? mask : 0;
+        ap[j] = p.a + (long long)m * p.lda * 4 + ((ps ^ ps_swz(r)) << 4);
+    }
+    const char* wp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave + 8 * j) * 8 + dr;
+        int n = n0 + r;
+        if (n >= p.N) n = p.N - 1;
+        wp[j] = p.w + (long long)n * 36 * p.C + ((ps ^ ps_swz(r)) << 4);
+    }
+    const int pix_bytes = (int)p.lda * 4;   // bytes between pixels (host checks (W + 1) * pix_bytes < 2^31)
+    const int nchunks = 9 * (p.C >> 5);
+
+    // chunk q -> (channel block cb, tap): K order = channel block outer, tap inner (the 9 taps share one input window)
+    // cursor of the NEXT chunk to issue, all wave-uniform: tap = 3*kh + kw, byte offsets of the tap / channel block
+    int q_kh = 0, q_kw = 0, q_bit = 1;
+    int q_aoff = -p.sign * (p.W + 1) * pix_bytes, q_woff = 0;   // tap (0,0) of block 0
+    int issued = 0;
+    auto issue = [&](char* stage) {
+        if ((p.ablate & 1) && issued >= 2) return;
+        ++issued;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) ps_dma16((vm[j] & q_bit) ? ap[j] + q_aoff : reinterpret_cast<const char*>(kPsZero), stage + (wave + 8 * j) * 1024);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ps_dma16(wp[j] + q_woff, stage + PS_A_BYTES + (wave + 8 * j) * 1024);
+        // advance: kw fastest; a full window moves on to the next 32-channel block
+        q_bit <<= 1;
+        q_woff += p.C * 4;
+        q_aoff += p.sign * pix_bytes;
+        if (++q_kw == 3) {
+            q_kw = 0;
+            q_aoff += p.sign * (p.W - 3) * pix_bytes;
+            if (++q_kh == 3) {
+                q_kh = 0; q_bit = 1;
+                q_aoff += 128 - p.sign * 3 * p.W * pix_bytes;
+                q_woff += 128 - 9 * p.C * 4;
+            }
+        }
+    };
+
+    // ---- fragment addresses: lane -> row li of a 32-row tile, k octet h; logical slot = plane*4 + step*2 + h
+    int foff[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) foff[s][pl] = li * 128 + (((pl * 4 + s * 2 + h) ^ ps_swz(li)) << 4);
+    const int abase = wm * 64 * 128, bbase = PS_A_BYTES + wn * 64 * 128;
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](const char* stage) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+            if (p.ablate & 4) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) { ah[i] = al[i] = bh[i] = bl[i] = __builtin_bit_cast(bf16x8, make_float4(1.f, 1.f, (float)s, 1.f)); }
+            } else {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(stage + abase + i * 4096 + foff[s][0]);
+                al[i] = *reinterpret_cast<const bf16x8*>(stage + abase + i * 4096 + foff[s][1]);
+                bh[i] = *reinterpret_cast<const bf16x8*>(stage + bbase + i * 4096 + foff[s][0]);
+                bl[i] = *reinterpret_cast<const bf16x8*>(stage + bbase + i * 4096 + foff[s][1]);
+            }
+            }
+            if (p.ablate & 2) {
+#pragma unroll
+                for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
+                continue;
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
+        }
+    };
+
+    char* const st0 = smem;
+    char* const st1 = smem + PS_STAGE_BYTES;
+    char* const st2 = smem + 2 * PS_STAGE_BYTES;
+
+    // prologue: chunks 0 and 1 in flight (nchunks >= 9)
+    issue(st0);
+    issue(st1);
+    // steady state, 3 chunks per trip (nchunks % 9 == 0): wait for chunk c (6 DMAs per wave and chunk, so vmcnt(6) leaves
+    // chunk c+1 in flight), barrier (chunk c visible to everyone, chunk c-1's stage free), refill that stage with chunk c+2
+    const int trips = nchunks / 3;
+    if constexpr (SCHED == 0) {
+        for (int t = 0; t + 1 < trips; ++t) {
+            ps_sync<6>(); issue(st2); compute(st0);
+            ps_sync<6>(); issue(st0); compute(st1);
+            ps_sync<6>(); issue(st1); compute(st2);
+        }
+        ps_sync<6>(); issue(st2); compute(st0);
+        ps_sync<6>(); compute(st1);
+        ps_sync<0>(); compute(st2);
+    } else {
+        // Barrier #k is the k-th s_barrier every wave executes.  Group 0 runs phase p between barriers #p-1 and #p, group 1
+        // (one extra barrier up front) between #p and #p+1.  Chunk c = phases 4c..4c+3.
+        //   visibility: every wave waits for its DMAs of chunk c+1 at the end of BOTH L1(c) and C1(c) (whichever comes
+        //     first in barrier order counts; the other is a no-op), i.e. before barrier #4c+3 -- group 0 reads chunk c+1
+        //     from #4c+3 on, group 1 from #4c+4 on;
+        //   reuse: stage(c-1) is refilled in L0(c): group 0 after #4c-1, group 1 after #4c; its last reads (L1(c-1)) were
+        //     retired with lgkmcnt(0) before #4c-2 / #4c-1.
+        const bool g1 = wave >= 4;
+        bf16x8 ah[2], al[2], bh[2], bl[2];
+        auto lread = [&](const char* stage, int s) {
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(stage + abase + i * 4096 + foff[s][0]);
+                al[i] = *reinterpret_cast<const bf16x8*>(stage + abase + i * 4096 + foff[s][1]);
+                bh[i] = *reinterpret_cast<const bf16x8*>(stage + bbase + i * 4096 + foff[s][0]);
+                bl[i] = *reinterpret_cast<const bf16x8*>(stage + bbase + i * 4096 + foff[s][1]);
+            }
+        };
+        auto mma = [&]() {
+            __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
+            __builtin_amdgcn_s_setprio(0);
+        };
+        // one chunk; MODE 0: steady state (refill + vmcnt(6)), 1: no refill, next chunk is the only one in flight (vmcnt(0)),
+        // 2: last chunk (nothing in flight; group 1 skips the final barrier)
+        auto chunk = [&](char* stage, char* refill, auto mode) {
+            constexpr int MODE = decltype(mode)::value;
+            if constexpr (MODE == 0) issue(refill);
+            lread(stage, 0);
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ps_phase();
+            mma();
+            ps_phase();
+            lread(stage, 1);
+            if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(6) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            ps_phase();
+            mma();
+            if constexpr (MODE == 0) asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if constexpr (MODE == 2) { if (!g1) ps_phase(); }
+            else ps_phase();
+        };
+        using M0 = std::integral_constant<int, 0>;
+        using M1 = std::integral_constant<int, 1>;
+        using M2 = std::integral_constant<int, 2>;
+        asm volatile("s_waitcnt vmcnt(6)" ::: "memory");
+        ps_phase();                 // barrier #-1: chunk 0 visible
+        if (g1) ps_phase();         // group 1 runs one phase behind
+        for (int t = 0; t + 1 < trips; ++t) {
+            chunk(st0, st2, M0());
+            chunk(st1, st0, M0());
+            chunk(st2, st1, M0());
+        }
+        chunk(st0, st2, M0());
+        chunk(st1, st1, M1());
+        chunk(st2, st2, M2());
+    }
+
+    // ---- epilogue: lane holds column n = li of rows (r&3) + 8*(r>>2) + 4*h of every 32x32 tile
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+    const bool full = mw + 64 <= p.M;   // wave-uniform
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = nw + q * 32 + li;
+            const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (!full && m >= p.M) continue;
+                float v = acc[i][q][r] + bn;
+                if constexpr (EPI & 2) v += p.rowbias[(long long)(m >> p.lhw) * p.ld_rowbias + n];
+                if constexpr (EPI & 1) v += p.residual[(long long)m * p.ldr + n];
+                v *= p.out_scale;
+                float* dst = p.y + (long long)m * p.ldy + n;
+                if constexpr (EPI & 4) v += *dst;
+                *dst = v;
+            }
+        }
+}
+
+// ---- producers of split planes -------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ps_pack_hi(float a, float b) {
+    return (__builtin_bit_cast(unsigned, a) >> 16) | (__builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
+}
+__device__ __forceinline__ unsigned ps_pack_lo(float a, float b) {
+    const float ra = a - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFF0000u);
+    const float rb = b - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
+    bf16x2 t;
+    t[0] = (__bf16)ra; t[1] = (__bf16)rb;
+    return __builtin_bit_cast(unsigned, t);
+}
+
+// rows x C fp32 (row stride lds) -> split planes (row stride ldd elements = 4*ldd bytes); C % 32 == 0.  8 values per thread.
+__global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, long long lds, long long rows, int C,
+                                                          unsigned short* __restrict__ dst, long long ldd) {
+    const int c8 = C >> 3;
+    const long long total = rows * c8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / c8;
+        const int j = (int)(i - r * c8);   // 8-channel group
+        const float4 a = *reinterpret_cast<const float4*>(src + r * lds + j * 8);
+        const float4 b = *reinterpret_cast<const float4*>(src + r * lds + j * 8 + 4);
+        unsigned short* o = dst + 2 * r * ldd + (j >> 2) * 64 + (j & 3) * 8;
+        *reinterpret_cast<uint4*>(o) = make_uint4(ps_pack_hi(a.x, a.y), ps_pack_hi(a.z, a.w), ps_pack_hi(b.x, b.y), ps_pack_hi(b.z, b.w));
+        *reinterpret_cast<uint4*>(o + 32) = make_uint4(ps_pack_lo(a.x, a.y), ps_pack_lo(a.z, a.w), ps_pack_lo(b.x, b.y), ps_pack_lo(b.z, b.w));
+    }
+}
+
+// conv weights W[co][tap][ci] fp32 -> split planes of the transpose Wt[ci][tap][co] (rows ci, K = (tap, co)); Cin, Cout % 32 == 0.
+// One workgroup = one (tap, 32 co x 32 ci) block through LDS.
+__global__ __launch_bounds__(256) void split_wT_kernel(const float* __restrict__ w, int Cin, int Cout, unsigned short* __restrict__ out) {
+    __shared__ float t[32][33];
+    const int cib = blockIdx.x, cob = blockIdx.y, tap = blockIdx.z;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 8 rows per pass
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = cob * 32 + ty + 8 * i;
+        t[ty + 8 * i][tx] = w[((long long)co * 9 + tap) * Cin + cib * 32 + tx];
+    }
+    __syncthreads();
+    // thread -> (ci row r = tid/8, 4 consecutive co = (tid%8)*4)
+    const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const float v0 = t[c4][r], v1 = t[c4 + 1][r], v2 = t[c4 + 2][r], v3 = t[c4 + 3][r];
+    unsigned short* o = out + 2 * (((long long)(cib * 32 + r) * 9 + tap) * Cout + cob * 32) + c4;
+    *reinterpret_cast<uint2*>(o) = make_uint2(ps_pack_hi(v0, v1), ps_pack_hi(v2, v3));
+    *reinterpret_cast<uint2*>(o + 32) = make_uint2(ps_pack_lo(v0, v1), ps_pack_lo(v2, v3));
+}
+
+static int ilog2x(int v) {
+    if (v <= 0 || (v & (v - 1))) return -1;
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}
+
+// shapes the kernel handles AND fills the chip with: a launch has tiles_m * tiles_n workgroups of one per CU and no
+// split-K, so small layers (8x8 / 4x4 images at CIFAR batch sizes) stay on the split-K igemm
+bool conv3x3_ps_supported(int B, int H, int W, int K_channels, int N_channels) {
+    if (!(ilog2x(H) >= 0 && ilog2x(W) >= 0 && K_channels % 32 == 0 && N_channels % PS_BN == 0 && K_channels >= 32)) return false;
+    const long long tiles = cdiv((long long)B * H * W, PS_BM) * (N_channels / PS_BN);
+    return tiles >= 96;
+}
+
+int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
+    BD_CHECK(d.x_split && d.w_split && d.y, BD_ERR_INVALID, "conv3x3_ps: null pointer");
+    BD_CHECK(d.B > 0 && ilog2x(d.H) >= 0 && ilog2x(d.W) >= 0, BD_ERR_UNSUPPORTED, "conv3x3_ps: H, W must be powers of two");
+    BD_CHECK(d.K > 0 && d.K % 32 == 0 && d.N > 0 && d.N % PS_BN == 0, BD_ERR_UNSUPPORTED,
+             "conv3x3_ps: K channels %% 32 and N channels %% %d must be 0 (got %d, %d)", PS_BN, d.K, d.N);
+    BD_CHECK(d.ldx % 32 == 0 && ((uintptr_t)d.x_split & 127) == 0 && ((uintptr_t)d.w_split & 127) == 0, BD_ERR_UNSUPPORTED,
+             "conv3x3_ps: split planes need ld %% 32 == 0 and 128-byte aligned bases");
+    BD_CHECK(d.direction == 1 || d.direction == -1, BD_ERR_INVALID, "conv3x3_ps: direction must be +1 or -1");
+    const long long M = (long long)d.B * d.H * d.W;
+    BD_CHECK(M < (1ll << 31), BD_ERR_UNSUPPORTED, "conv3x3_ps: pixel count overflows int32");
+    PsParams p = {};
+    p.a = reinterpret_cast<const char*>(d.x_split); p.w = reinterpret_cast<const char*>(d.w_split);
+    p.y = d.y; p.bias = d.bias; p.rowbias = d.rowbias; p.residual = d.residual;
+    p.lda = d.ldx; p.ldy = d.ldy; p.ldr = d.ldr; p.ld_rowbias = d.ld_rowbias;
+    p.C = d.K; p.H = d.H; p.W = d.W; p.lw = ilog2x(d.W); p.lhw = ilog2x(d.W) + ilog2x(d.H);
+    p.sign = d.direction; p.M = (int)M; p.N = d.N;
+    p.tiles_m = (int)cdiv(M, PS_BM); p.tiles_n = d.N / PS_BN;
+    p.out_scale = d.out_scale == 0.f ? 1.f : d.out_scale; p.accumulate = d.accumulate;
+    int rec = -1;
+    if (prof_on()) {
+        rec = prof_begin(d.direction > 0 ? "conv_ps_fwd" : "conv_ps_dgrad", 2.0 * (double)M * d.N * 9.0 * d.K,
+                         ((double)M * d.K + 9.0 * d.K * d.N + (double)M * d.N) * 4.0, st);
+    }
+    BD_CHECK((long long)(d.W + 1) * d.ldx * 4 < (1ll << 31), BD_ERR_UNSUPPORTED, "conv3x3_ps: row pitch too large");
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(PS_NT);
+    const int epi = (d.residual ? 1 : 0) | (d.rowbias ? 2 : 0) | (d.accumulate ? 4 : 0);
+    p.ablate = getenv("BD_PS_ABLATE") ? atoi(getenv("BD_PS_ABLATE")) : 0;
+    static const int sched = getenv("BD_PS_SCHED") ? atoi(getenv("BD_PS_SCHED")) : 1;
+#define PS_LAUNCH(E)                                                                              \
+    do {                                                                                          \
+        if (sched == 0) hipLaunchKernelGGL((conv_ps_kernel<E, 0>), grid, block, 0, st, p);        \
+        else hipLaunchKernelGGL((conv_ps_kernel<E, 1>), grid, block, 0, st, p);                   \
+    } while (0)
+    switch (epi) {
+        case 0: PS_LAUNCH(0); break;
+        case 1: PS_LAUNCH(1); break;
+        case 2: PS_LAUNCH(2); break;
+        case 4: PS_LAUNCH(4); break;
+        default: PS_LAUNCH(7); break;
+    }
+#undef PS_LAUNCH
+    BD_LAUNCH_CHECK("conv_ps");
+    prof_end(rec, st);
+    return BD_OK;
+}
+
+}  // namespace bd
+
+extern "C" int bd_conv3x3_ps(const bd_conv3x3_ps_desc* d, bd_stream_t s) {
+    BD_CHECK(d, BD_ERR_INVALID, "bd_conv3x3_ps: null descriptor");
+    return bd::conv3x3_ps(*d, bd::S(s));
+}
+extern "C" int bd_split_rows(const float* src, int64_t ld_src, int64_t rows, int C, uint16_t* dst, int64_t ld_dst, bd_stream_t stream) {
+    BD_CHECK(src && dst && rows > 0 && C > 0, BD_ERR_INVALID, "bd_split_rows: bad args");
+    BD_CHECK(C % 32 == 0 && ld_dst % 32 == 0 && (ld_src & 3) == 0 && bd::aligned16(src) && ((uintptr_t)dst & 127) == 0, BD_ERR_UNSUPPORTED,
+             "bd_split_rows: C, ld_dst %% 32, ld_src %% 4, 16-byte aligned src and 128-byte aligned dst required");
+    long long nb = bd::cdiv(rows * (C / 8), 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(bd::split_rows_kernel, dim3((unsigned)nb), dim3(256), 0, bd::S(stream), src, (long long)ld_src, (long long)rows, C, dst,
+                       (long long)ld_dst);
+    BD_LAUNCH_CHECK("split_rows");
+    return BD_OK;
+}
+extern "C" int bd_split_wt(const float* w, int Cin, int Cout, uint16_t* out, bd_stream_t stream) {
+    BD_CHECK(w && out && Cin > 0 && Cout > 0, BD_ERR_INVALID, "bd_split_wt: bad args");
+    BD_CHECK(Cin % 32 == 0 && Cout % 32 == 0 && ((uintptr_t)out & 127) == 0, BD_ERR_UNSUPPORTED, "bd_split_wt: Cin, Cout %% 32 and 128-byte aligned out required");
+    hipLaunchKernelGGL(bd::split_wT_kernel, dim3(Cin / 32, Cout / 32, 9), dim3(256), 0, bd::S(stream), w, Cin, Cout, out);
+    BD_LAUNCH_CHECK("split_wT");
+    return BD_OK;
+}

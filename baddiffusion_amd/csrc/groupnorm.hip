@@ -45,6 +45,26 @@ __device__ __forceinline__ float silu_grad_dev(float z) {
     return s * (1.0f + z * (1.0f - s));
 }
 
+// ---- split-plane output (bd_hip.h "split planes"): 4 consecutive channels c..c+3 of one row -> 8 B of bf16 hi and 8 B of
+// bf16 lo (hi = truncation, lo = RNE of the remainder: bit-identical to the on-the-fly split of the bf16x3 engine)
+typedef __bf16 gn_bf16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned gn_pack_hi(float a, float b) {
+    return (__builtin_bit_cast(unsigned, a) >> 16) | (__builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
+}
+__device__ __forceinline__ unsigned gn_pack_lo(float a, float b) {
+    const float ra = a - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFF0000u);
+    const float rb = b - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
+    gn_bf16x2 t;
+    t[0] = (__bf16)ra; t[1] = (__bf16)rb;
+    return __builtin_bit_cast(unsigned, t);
+}
+// row = start of the row's planes (uint16 units), c = channel of o[0] (c % 4 == 0)
+__device__ __forceinline__ void gn_store_split4(unsigned short* row, int c, const float (&o)[4]) {
+    unsigned short* q = row + (c >> 5) * 64 + (c & 31);
+    *reinterpret_cast<uint2*>(q) = make_uint2(gn_pack_hi(o[0], o[1]), gn_pack_hi(o[2], o[3]));
+    *reinterpret_cast<uint2*>(q + 32) = make_uint2(gn_pack_lo(o[0], o[1]), gn_pack_lo(o[2], o[3]));
+}
+
 // ---- forward stats: per (b, split) partial (sum, sumsq) per group, in double -----------------------
 __global__ void gn_stats_kernel(const float* __restrict__ x, long long ldx, int HW, int C, int G, int r, int S,
                                 double* __restrict__ part /* [B][S][G][2] */) {
@@ -119,7 +139,8 @@ __global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(const double* __re
 __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
                                                      long long ldy, int HW, int C, int G, const float* __restrict__ gamma,
                                                      const float* __restrict__ beta, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, int silu) {
+                                                     const float* __restrict__ rstd, int silu, unsigned short* __restrict__ ys,
+                                                     long long ldys) {
     extern __shared__ float st[];  // [G][2]
     const int b = blockIdx.y;
     for (int g = threadIdx.x; g < G; g += 256) {
@@ -144,7 +165,8 @@ __global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__
             float z = (in[j] - st[2 * g]) * st[2 * g + 1] * gg[j] + bb[j];
             o[j] = silu ? silu_dev(z) : z;
         }
-        *reinterpret_cast<float4*>(yb + pix * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (y) *reinterpret_cast<float4*>(yb + pix * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
+        if (ys) gn_store_split4(ys + 2 * ((long long)b * HW + pix) * ldys, c, o);
     }
 }
 
@@ -283,7 +305,8 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
                                                          float* __restrict__ dx, long long lddx, int HW, int C, int G,
                                                          const float* __restrict__ ds, const float* __restrict__ gamma,
                                                          const float* __restrict__ beta, const float* __restrict__ mean,
-                                                         const float* __restrict__ rstd, float inv_n, int silu, int acc) {
+                                                         const float* __restrict__ rstd, float inv_n, int silu, int acc,
+                                                         unsigned short* __restrict__ dxs, long long lddxs) {
     extern __shared__ float st[];  // [G][4] = mean, rstd, s1, s2
     const int b = blockIdx.y;
     const int q = C / 4, cpg = C / G;
@@ -315,12 +338,15 @@ __global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restri
             if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
             o[j] = rs * (dz * gg[j] - (s1 + xh * s2) * inv_n);
         }
-        float4* dst = reinterpret_cast<float4*>(ob + pix * lddx + c);
-        if (acc) {
-            const float4 e = *dst;
-            o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
+        if (dx) {
+            float4* dst = reinterpret_cast<float4*>(ob + pix * lddx + c);
+            if (acc) {
+                const float4 e = *dst;
+                o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
+            }
+            *dst = make_float4(o[0], o[1], o[2], o[3]);
         }
-        *dst = make_float4(o[0], o[1], o[2], o[3]);
+        if (dxs) gn_store_split4(dxs + 2 * ((long long)b * HW + pix) * lddxs, c, o);
     }
 }
 
@@ -379,7 +405,8 @@ __global__ __launch_bounds__(NT) void gn_fwd_res_kernel(const float* __restrict_
                                                        long long ldy, int HW, int C, int G, int cb, int q, int R, int E,
                                                        float eps, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ mean,
-                                                       float* __restrict__ rstd, int silu) {
+                                                       float* __restrict__ rstd, int silu, unsigned short* __restrict__ ys,
+                                                       long long ldys) {
     __shared__ float sh[2 * 4 * NT];   // [R][cb][2], R*cb <= 4*NT
     __shared__ float st[2 * 256];    // per group of the block: mean, rstd
     const int t = threadIdx.x;
@@ -444,7 +471,8 @@ __global__ __launch_bounds__(NT) void gn_fwd_res_kernel(const float* __restrict_
                 const float z = (in[j] - mu[j]) * rs[j] * gg[j] + bb[j];
                 o[j] = silu ? silu_dev(z) : z;
             }
-            *reinterpret_cast<float4*>(yb + (long long)p * ldy) = make_float4(o[0], o[1], o[2], o[3]);
+            if (y) *reinterpret_cast<float4*>(yb + (long long)p * ldy) = make_float4(o[0], o[1], o[2], o[3]);
+            if (ys) gn_store_split4(ys + 2 * ((long long)b * HW + p) * ldys, c0 + cq * 4, o);
         }
     }
 }
@@ -459,7 +487,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_res_kernel(const float* __restrict_
                                                        const float* __restrict__ gamma, const float* __restrict__ beta,
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        int silu, int acc, float* __restrict__ part,
-                                                       float* __restrict__ dx_colsum, long long ld_colsum) {
+                                                       float* __restrict__ dx_colsum, long long ld_colsum,
+                                                       unsigned short* __restrict__ dxs, long long lddxs) {
     __shared__ float sh[3 * 4 * NT];   // [R][cb][3]: sum dz, sum dz*xhat, sum xhat
     __shared__ float ch[3 * 4 * NT];   // [cb][3] channel totals (cb <= 4*NT)
     __shared__ float sg[2 * 256];    // per group: s1, s2
@@ -558,12 +587,15 @@ __global__ __launch_bounds__(NT) void gn_bwd_res_kernel(const float* __restrict_
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = rs[j] * (d[j] * gg[j] - (g1[j] + h[j] * g2[j]) * inv_n);
-            float4* dst = reinterpret_cast<float4*>(ob + (long long)p * lddx);
-            if (acc) {
-                const float4 e = *dst;
-                o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
+            if (dx) {
+                float4* dst = reinterpret_cast<float4*>(ob + (long long)p * lddx);
+                if (acc) {
+                    const float4 e = *dst;
+                    o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
+                }
+                *dst = make_float4(o[0], o[1], o[2], o[3]);
             }
-            *dst = make_float4(o[0], o[1], o[2], o[3]);
+            if (dxs) gn_store_split4(dxs + 2 * ((long long)b * HW + p) * lddxs, c0 + cq * 4, o);
         }
     }
 }
@@ -593,16 +625,18 @@ extern "C" size_t bd_gn_workspace_bytes(int B, int C) {
 extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
     BD_CHECK(d, BD_ERR_INVALID, "bd_gn_fwd: null descriptor");
     BD_TRY(gn_common_checks("bd_gn_fwd", d->B, d->HW, d->C, d->G, d->x, d->ldx));
-    BD_CHECK(d->gamma && d->beta && d->y && d->mean && d->rstd && d->workspace, BD_ERR_INVALID, "bd_gn_fwd: null pointer");
+    BD_CHECK(d->gamma && d->beta && (d->y || d->y_split) && d->mean && d->rstd && d->workspace, BD_ERR_INVALID, "bd_gn_fwd: null pointer");
     BD_CHECK((d->ldy & 3) == 0 && aligned16(d->y) && aligned16(d->gamma) && aligned16(d->beta), BD_ERR_UNSUPPORTED,
              "bd_gn_fwd: y/gamma/beta must be 16B aligned, ldy multiple of 4");
+    BD_CHECK(!d->y_split || (d->C % 32 == 0 && d->ldys % 32 == 0 && ((uintptr_t)d->y_split & 127) == 0), BD_ERR_UNSUPPORTED,
+             "bd_gn_fwd: y_split needs C %% 32 == 0, ldys %% 32 == 0 and a 128-byte aligned base");
     GnRes rp;
     if (gn_resident_plan(d->B, d->HW, d->C, d->G, rp)) {
         const dim3 grid((unsigned)rp.nblk * (unsigned)d->B);
 #define BD_GN_FWD_RES(EM, NT)                                                                                              \
     hipLaunchKernelGGL((gn_fwd_res_kernel<EM, NT>), grid, dim3(NT), 0, S(stream), d->x, (long long)d->ldx, d->y,             \
                        (long long)d->ldy, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->eps, d->gamma, d->beta, d->mean,       \
-                       d->rstd, d->silu)
+                       d->rstd, d->silu, d->y_split, (long long)d->ldys)
         if (rp.nt == 512) BD_GN_FWD_RES(GN_RES_EMAX, 512);
         else if (rp.E <= 4) BD_GN_FWD_RES(4, 256);
         else BD_GN_FWD_RES(GN_RES_EMAX, 256);
@@ -628,7 +662,7 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
                            (double)d->HW * (d->C / d->G), d->eps, d->mean, d->rstd);
         hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nbx, d->B), dim3(256), (size_t)d->G * 2 * sizeof(float), S(stream), d->x,
                            (long long)d->ldx, d->y, (long long)d->ldy, d->HW, d->C, d->G, d->gamma, d->beta, d->mean, d->rstd,
-                           d->silu);
+                           d->silu, d->y_split, (long long)d->ldys);
     }
     BD_LAUNCH_CHECK("gn_apply");
     return BD_OK;
@@ -637,8 +671,11 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
 extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
     BD_CHECK(d, BD_ERR_INVALID, "bd_gn_bwd: null descriptor");
     BD_TRY(gn_common_checks("bd_gn_bwd", d->B, d->HW, d->C, d->G, d->x, d->ldx));
-    BD_CHECK(d->gamma && d->beta && d->mean && d->rstd && d->dy && d->dx && d->dgamma && d->dbeta && d->workspace,
+    BD_CHECK(d->gamma && d->beta && d->mean && d->rstd && d->dy && (d->dx || d->dx_split) && d->dgamma && d->dbeta && d->workspace,
              BD_ERR_INVALID, "bd_gn_bwd: null pointer");
+    BD_CHECK(!d->dx_split || (d->C % 32 == 0 && d->lddxs % 32 == 0 && ((uintptr_t)d->dx_split & 127) == 0), BD_ERR_UNSUPPORTED,
+             "bd_gn_bwd: dx_split needs C %% 32 == 0, lddxs %% 32 == 0 and a 128-byte aligned base");
+    BD_CHECK(d->dx || !d->accumulate_dx, BD_ERR_INVALID, "bd_gn_bwd: accumulate_dx needs dx");
     BD_CHECK((d->lddy & 3) == 0 && (d->lddx & 3) == 0 && aligned16(d->dy) && aligned16(d->dx) && aligned16(d->gamma) &&
                  aligned16(d->beta), BD_ERR_UNSUPPORTED, "bd_gn_bwd: pointers must be 16B aligned, ld multiples of 4");
     BD_CHECK(!(d->dx_colsum && d->accumulate_dx), BD_ERR_INVALID, "bd_gn_bwd: dx_colsum is the column sum of the written dx");
@@ -651,7 +688,8 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
 #define BD_GN_BWD_RES(EM, NT)                                                                                              \
     hipLaunchKernelGGL((gn_bwd_res_kernel<EM, NT>), grid, dim3(NT), 0, S(stream), d->x, (long long)d->ldx, d->dy,            \
                        (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->gamma,     \
-                       d->beta, d->mean, d->rstd, d->silu, d->accumulate_dx, part_r, d->dx_colsum, (long long)d->ld_colsum)
+                       d->beta, d->mean, d->rstd, d->silu, d->accumulate_dx, part_r, d->dx_colsum, (long long)d->ld_colsum, \
+                       d->dx_split, (long long)d->lddxs)
         if (rp.nt == 512) BD_GN_BWD_RES(GN_RES_EMAX, 512);
         else if (rp.E <= 4) BD_GN_BWD_RES(4, 256);
         else BD_GN_BWD_RES(GN_RES_EMAX, 256);
@@ -687,7 +725,7 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
                            d->C, d->G, S_, d->gamma, d->rstd, inv_n, ds, d->dx_colsum, (long long)d->ld_colsum);
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)nbx, d->B), dim3(256), (size_t)d->G * 4 * sizeof(float), S(stream), d->x,
                            (long long)d->ldx, d->dy, (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, ds, d->gamma,
-                           d->beta, d->mean, d->rstd, inv_n, d->silu, d->accumulate_dx);
+                           d->beta, d->mean, d->rstd, inv_n, d->silu, d->accumulate_dx, d->dx_split, (long long)d->lddxs);
     }
     BD_LAUNCH_CHECK("gn_bwd_apply");
     return BD_OK;

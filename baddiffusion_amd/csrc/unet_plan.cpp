@@ -18,6 +18,7 @@
 #include <string>
 #include <vector>
 #include <cmath>
+#include <cstdlib>
 
 namespace bd {
 
@@ -25,6 +26,8 @@ int conv3x3_fwd(const bd_conv3x3_fwd_desc& d, hipStream_t st);
 int conv3x3_dgrad(const bd_conv3x3_dgrad_desc& d, hipStream_t st);
 int conv3x3_wgrad(const bd_conv3x3_wgrad_desc& d, hipStream_t st);
 bool conv3x3_wgrad_is_thin(const bd_conv3x3_wgrad_desc& d);
+int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st);                         // conv_ps.hip
+bool conv3x3_ps_supported(int B, int H, int W, int K_channels, int N_channels);
 
 struct View {
     int buf = -1;   // value buffer id
@@ -50,6 +53,7 @@ struct Param {
 
 struct Ctx {
     bool dry = false;
+    bool training = true;   // forward only: keep what backward needs
     int B = 0;
     int64_t s0 = 0;   // sample offset of this context inside the batch the workspace is laid out for
     int LB = 0;       // that batch (B of the call); B <= LB is the number of samples this context processes
@@ -286,6 +290,21 @@ struct bd_unet {
         if (c.dry) { note_conv(c); return BD_OK; }
         return on_aux(c, [&](hipStream_t st, char* ws) { d.workspace = ws; return conv3x3_wgrad(d, st); });
     }
+    // pre-split / LDS-DMA convolution (conv_ps.hip) for the stride-1 3x3 convs whose operands the producers can emit as
+    // split planes: BF16X3 mode only (same arithmetic, bit-identical), shapes per conv3x3_ps_supported
+    bool ps_ok(const Ctx& c, int H, int W, int K, int N) const {
+        static const bool off = getenv("BD_CONV_PS") && atoi(getenv("BD_CONV_PS")) == 0;
+        return !off && cfg.compute_mode == BD_MODE_BF16X3 && (c.dry || c.w_split) && conv3x3_ps_supported(c.B, H, W, K, N);
+    }
+    static uint16_t* U16(float* p) { return reinterpret_cast<uint16_t*>(p); }
+    int conv_p(Ctx& c, bd_conv3x3_ps_desc& d) const {
+        if (c.dry) return BD_OK;
+        return conv3x3_ps(d, c.st);
+    }
+    int split_rows(Ctx& c, const float* src, int64_t ld, int64_t nrows, int C, float* dst) const {
+        if (c.dry) return BD_OK;
+        return bd_split_rows(src, ld, nrows, C, U16(dst), C, (bd_stream_t)c.st);
+    }
     static void note_conv(Ctx& c) {
         size_t n = bd_conv3x3_workspace_bytes(0, 0, 0, 0, 0, 0, 0, 0);
         if (n > c.opws_need) c.opws_need = n;
@@ -383,6 +402,8 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
     }
     const int b_a1 = new_buf((int64_t)HW * Cin, 0, R_VALUE), b_h1 = new_buf((int64_t)HW * Cout, 0, R_VALUE);
     const int b_a2 = new_buf((int64_t)HW * Cout, 0, R_VALUE);
+    // split-plane twins of a1 / a2 (operands of the LDS-DMA convolutions; 4 B per element like fp32)
+    const int b_a1s = new_buf((int64_t)HW * Cin, 0, R_VALUE), b_a2s = new_buf((int64_t)HW * Cout, 0, R_VALUE);
     const int G = cfg.norm_num_groups;
     const int b_st1 = new_buf(2 * G, 0, R_VALUE), b_st2 = new_buf(2 * G, 0, R_VALUE);
     View h1v; h1v.buf = b_h1; h1v.coff = 0; h1v.C = Cout; h1v.ld = Cout; h1v.H = H; h1v.W = W;
@@ -390,22 +411,62 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
     const int b_dys = scale != 1.f ? scratch((int64_t)HW * Cout) : -1;
     const int b_bs = scratch(Cout), b_da2 = scratch((int64_t)HW * Cout), b_dh1 = scratch((int64_t)HW * Cout);
     const int b_da1 = scratch((int64_t)HW * Cin);
+    // backward operands of the LDS-DMA data gradients: dy / dh1 as split planes, transposed weight planes
+    const int b_dyS = scratch((int64_t)HW * Cout), b_dh1S = scratch((int64_t)HW * Cout);
+    const int b_wT2 = scratch(0, (int64_t)9 * Cout * Cout), b_wT1 = scratch(0, (int64_t)9 * Cin * Cout);
     const float inv = 1.f / scale;
     const int sumC_ = sumC;
 
     F([=](Ctx& c) {
-        BD_TRY(gn_fwd(c, x, pn1w, pn1b, BP(c, b_a1), Cin, b_st1, 1));
-        bd_conv3x3_fwd_desc d = {};
-        d.B = c.B; d.Hs = H; d.Ws = W; d.Cin = Cin; d.Cout = Cout; d.stride = 1; d.pad_t = 1; d.pad_l = 1; d.Ho = H; d.Wo = W;
-        d.x = BP(c, b_a1); d.ldx = Cin; d.w = c.params + pc1w; d.bias = c.params + pc1b;
-        d.rowbias = BP(c, b_tproj) + toff; d.ld_rowbias = sumC_; d.out_scale = 1.f;
-        d.y = BP(c, b_h1); d.ldy = Cout;
-        BD_TRY(conv_f(c, d));
-        BD_TRY(gn_fwd(c, h1v, pn2w, pn2b, BP(c, b_a2), Cout, b_st2, 1));
+        const bool ps1 = ps_ok(c, H, W, Cin, Cout), ps2 = ps_ok(c, H, W, Cout, Cout);
+        if (ps1) {
+            bd_gn_fwd_desc g = {};
+            g.B = c.B; g.HW = HW; g.C = Cin; g.G = G; g.eps = cfg.norm_eps; g.silu = 1;
+            g.x = VP(c, x); g.ldx = x.ld; g.gamma = c.params + pn1w; g.beta = c.params + pn1b;
+            g.y = c.training ? BP(c, b_a1) : nullptr; g.ldy = Cin;     // fp32 copy: operand of the weight gradient
+            g.y_split = U16(BP(c, b_a1s)); g.ldys = Cin;
+            g.mean = MEANP(c, b_st1, G); g.rstd = RSTDP(c, b_st1, G);
+            g.workspace = c.opws; g.workspace_bytes = c.opws_bytes;
+            if (!c.dry) BD_TRY(bd_gn_fwd(&g, (bd_stream_t)c.st));
+            bd_conv3x3_ps_desc d = {};
+            d.B = c.B; d.H = H; d.W = W; d.K = Cin; d.N = Cout; d.direction = 1;
+            d.x_split = U16(BP(c, b_a1s)); d.ldx = Cin; d.w_split = c.w_split + 2 * pc1w;
+            d.bias = c.params + pc1b; d.rowbias = BP(c, b_tproj) + toff; d.ld_rowbias = sumC_; d.out_scale = 1.f;
+            d.y = BP(c, b_h1); d.ldy = Cout;
+            BD_TRY(conv_p(c, d));
+        } else {
+            BD_TRY(gn_fwd(c, x, pn1w, pn1b, BP(c, b_a1), Cin, b_st1, 1));
+            bd_conv3x3_fwd_desc d = {};
+            d.B = c.B; d.Hs = H; d.Ws = W; d.Cin = Cin; d.Cout = Cout; d.stride = 1; d.pad_t = 1; d.pad_l = 1; d.Ho = H; d.Wo = W;
+            d.x = BP(c, b_a1); d.ldx = Cin; d.w = c.params + pc1w; d.bias = c.params + pc1b;
+            d.rowbias = BP(c, b_tproj) + toff; d.ld_rowbias = sumC_; d.out_scale = 1.f;
+            d.y = BP(c, b_h1); d.ldy = Cout;
+            BD_TRY(conv_f(c, d));
+        }
+        if (ps2) {
+            bd_gn_fwd_desc g = {};
+            g.B = c.B; g.HW = HW; g.C = Cout; g.G = G; g.eps = cfg.norm_eps; g.silu = 1;
+            g.x = BP(c, b_h1); g.ldx = Cout; g.gamma = c.params + pn2w; g.beta = c.params + pn2b;
+            g.y = c.training ? BP(c, b_a2) : nullptr; g.ldy = Cout;
+            g.y_split = U16(BP(c, b_a2s)); g.ldys = Cout;
+            g.mean = MEANP(c, b_st2, G); g.rstd = RSTDP(c, b_st2, G);
+            g.workspace = c.opws; g.workspace_bytes = c.opws_bytes;
+            if (!c.dry) BD_TRY(bd_gn_fwd(&g, (bd_stream_t)c.st));
+        } else {
+            BD_TRY(gn_fwd(c, h1v, pn2w, pn2b, BP(c, b_a2), Cout, b_st2, 1));
+        }
         const float* res = VP(c, x); int64_t ldr = x.ld;
         if (shortcut) {
             BD_TRY(linear_fwd(c, VP(c, x), x.ld, c.params + psw, c.params + psb, VP(c, y), y.ld, (int)rows(c, x), Cout, Cin));
             res = VP(c, y); ldr = y.ld;
+        }
+        if (ps2) {
+            bd_conv3x3_ps_desc e = {};
+            e.B = c.B; e.H = H; e.W = W; e.K = Cout; e.N = Cout; e.direction = 1;
+            e.x_split = U16(BP(c, b_a2s)); e.ldx = Cout; e.w_split = c.w_split + 2 * pc2w;
+            e.bias = c.params + pc2b; e.residual = res; e.ldr = ldr; e.out_scale = inv;
+            e.y = VP(c, y); e.ldy = y.ld;
+            return conv_p(c, e);
         }
         bd_conv3x3_fwd_desc e = {};
         e.B = c.B; e.Hs = H; e.Ws = W; e.Cin = Cout; e.Cout = Cout; e.stride = 1; e.pad_t = 1; e.pad_l = 1; e.Ho = H; e.Wo = W;
@@ -425,10 +486,21 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
         w2.B = c.B; w2.Hs = H; w2.Ws = W; w2.Cin = Cout; w2.Cout = Cout; w2.stride = 1; w2.pad_t = 1; w2.pad_l = 1; w2.Ho = H; w2.Wo = W;
         w2.x = BP(c, b_a2); w2.ldx = Cout; w2.dy = dy; w2.lddy = lddy; w2.dw = c.grads + pc2w; w2.db = c.grads + pc2b;
         BD_TRY(conv_w(c, w2));
-        bd_conv3x3_dgrad_desc g2 = {};
-        g2.B = c.B; g2.Hs = H; g2.Ws = W; g2.Cin = Cout; g2.Cout = Cout; g2.stride = 1; g2.pad_t = 1; g2.pad_l = 1; g2.Ho = H; g2.Wo = W;
-        g2.dy = dy; g2.lddy = lddy; g2.w = c.params + pc2w; g2.dx = BP(c, b_da2); g2.lddx = Cout;
-        BD_TRY(conv_d(c, g2));
+        const bool ps1 = ps_ok(c, H, W, Cout, Cin), ps2 = ps_ok(c, H, W, Cout, Cout);   // data gradients: K = Cout, N = Cin
+        if (ps2) {
+            BD_TRY(split_rows(c, dy, lddy, M, Cout, BP(c, b_dyS)));
+            if (!c.dry) BD_TRY(bd_split_wt(c.params + pc2w, Cout, Cout, U16(BP(c, b_wT2)), (bd_stream_t)c.st));
+            bd_conv3x3_ps_desc g2 = {};
+            g2.B = c.B; g2.H = H; g2.W = W; g2.K = Cout; g2.N = Cout; g2.direction = -1;
+            g2.x_split = U16(BP(c, b_dyS)); g2.ldx = Cout; g2.w_split = U16(BP(c, b_wT2)); g2.out_scale = 1.f;
+            g2.y = BP(c, b_da2); g2.ldy = Cout;
+            BD_TRY(conv_p(c, g2));
+        } else {
+            bd_conv3x3_dgrad_desc g2 = {};
+            g2.B = c.B; g2.Hs = H; g2.Ws = W; g2.Cin = Cout; g2.Cout = Cout; g2.stride = 1; g2.pad_t = 1; g2.pad_l = 1; g2.Ho = H; g2.Wo = W;
+            g2.dy = dy; g2.lddy = lddy; g2.w = c.params + pc2w; g2.dx = BP(c, b_da2); g2.lddx = Cout;
+            BD_TRY(conv_d(c, g2));
+        }
         {   // norm2 backward: dh1 = gn_silu_bwd(h1, da2)   (h1 has no persistent grad buffer: write to scratch)
             bd_gn_bwd_desc d = {};
             d.B = c.B; d.HW = HW; d.C = Cout; d.G = G; d.silu = 1;
@@ -439,16 +511,26 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
             // time-embedding gradient = per-sample column sums of dh1, out of the same launch
             d.dx_colsum = BP(c, b_dtproj) + toff; d.ld_colsum = sumC_;
+            if (ps1) { d.dx_split = U16(BP(c, b_dh1S)); d.lddxs = Cout; }
             if (!c.dry) BD_TRY(bd_gn_bwd(&d, (bd_stream_t)c.st));
         }
         bd_conv3x3_wgrad_desc w1 = {};
         w1.B = c.B; w1.Hs = H; w1.Ws = W; w1.Cin = Cin; w1.Cout = Cout; w1.stride = 1; w1.pad_t = 1; w1.pad_l = 1; w1.Ho = H; w1.Wo = W;
         w1.x = BP(c, b_a1); w1.ldx = Cin; w1.dy = BP(c, b_dh1); w1.lddy = Cout; w1.dw = c.grads + pc1w; w1.db = c.grads + pc1b;
         BD_TRY(conv_w(c, w1));
-        bd_conv3x3_dgrad_desc g1 = {};
-        g1.B = c.B; g1.Hs = H; g1.Ws = W; g1.Cin = Cin; g1.Cout = Cout; g1.stride = 1; g1.pad_t = 1; g1.pad_l = 1; g1.Ho = H; g1.Wo = W;
-        g1.dy = BP(c, b_dh1); g1.lddy = Cout; g1.w = c.params + pc1w; g1.dx = BP(c, b_da1); g1.lddx = Cin;
-        BD_TRY(conv_d(c, g1));
+        if (ps1) {
+            if (!c.dry) BD_TRY(bd_split_wt(c.params + pc1w, Cin, Cout, U16(BP(c, b_wT1)), (bd_stream_t)c.st));
+            bd_conv3x3_ps_desc g1 = {};
+            g1.B = c.B; g1.H = H; g1.W = W; g1.K = Cout; g1.N = Cin; g1.direction = -1;
+            g1.x_split = U16(BP(c, b_dh1S)); g1.ldx = Cout; g1.w_split = U16(BP(c, b_wT1)); g1.out_scale = 1.f;
+            g1.y = BP(c, b_da1); g1.ldy = Cin;
+            BD_TRY(conv_p(c, g1));
+        } else {
+            bd_conv3x3_dgrad_desc g1 = {};
+            g1.B = c.B; g1.Hs = H; g1.Ws = W; g1.Cin = Cin; g1.Cout = Cout; g1.stride = 1; g1.pad_t = 1; g1.pad_l = 1; g1.Ho = H; g1.Wo = W;
+            g1.dy = BP(c, b_dh1); g1.lddy = Cout; g1.w = c.params + pc1w; g1.dx = BP(c, b_da1); g1.lddx = Cin;
+            BD_TRY(conv_d(c, g1));
+        }
         BD_TRY(gn_bwd(c, x, pn1w, pn1b, b_st1, BP(c, b_da1), Cin, 1));
         // residual path
         if (shortcut) {
@@ -942,6 +1024,7 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
     BD_CHECK(ldx >= u->cfg.in_channels && ldo >= u->cfg.out_channels, BD_ERR_INVALID, "bd_unet_forward: ld < channels");
     BD_CHECK(aligned16(params), BD_ERR_INVALID, "bd_unet_forward: params must be 16-byte aligned");
     c.params = params; c.x = x; c.ldx = ldx; c.t = t; c.t_stride = t_stride; c.out = out; c.ldo = ldo; c.st = S(stream);
+    c.training = training != 0;
     if (c.w_split)   // split the weights once; forward convs and (same workspace) the backward dgrads read the copy
         BD_TRY(bd_split_bf16(params, (int64_t)wsplit_elems(u), const_cast<uint16_t*>(c.w_split), stream));
     if (!u->aux_enabled || B < 32) {

@@ -234,6 +234,40 @@ def split_bf16(x):
     return out
 
 
+def split_rows(x, out=None):
+    """fp32 [..., C] (last dim contiguous, uniform row stride) -> split planes int16 [rows, C/32, 2, 32]
+    (row, 32-channel block, hi|lo, element): include/bd_hip.h bd_split_rows."""
+    lib = L.load(); _need_cuda(x)
+    Cc = x.shape[-1]
+    rows = x.numel() // Cc
+    if out is None:
+        out = torch.empty(rows, Cc // 32, 2, 32, dtype=torch.int16, device=x.device)
+    L.check(lib.bd_split_rows(L.ptr(x), _ld(x), rows, Cc, L.ptr(out), Cc, L.stream()), "bd_split_rows")
+    return out
+
+
+def split_wT(w):
+    """conv weight [Cout,3,3,Cin] fp32 -> split planes of the transpose [Cin,3,3,Cout] (for the data gradient)."""
+    lib = L.load(); _need_cuda(w)
+    Cout, _, _, Cin = w.shape
+    out = torch.empty(Cin, 9 * Cout // 32, 2, 32, dtype=torch.int16, device=w.device)
+    L.check(lib.bd_split_wt(L.ptr(w.contiguous()), Cin, Cout, L.ptr(out), L.stream()), "bd_split_wt")
+    return out
+
+
+def conv3x3_ps(x_split, w_split, B, H, W, K, N, direction=1, bias=None, rowbias=None, residual=None, out_scale=1.0,
+               out=None, accumulate=False):
+    """stride-1 pad-1 3x3 convolution (direction +1) / data gradient (-1) on pre-split operands -> fp32 [B,H,W,N]."""
+    lib = L.load(); _need_cuda(x_split, w_split, bias, rowbias, residual)
+    y = torch.empty(B, H, W, N, device=x_split.device) if out is None else out
+    d = L.ConvPsDesc(B=B, H=H, W=W, K=K, N=N, direction=direction, x_split=L.ptr(x_split), ldx=K, w_split=L.ptr(w_split),
+                     bias=L.ptr(bias), rowbias=L.ptr(rowbias), ld_rowbias=rowbias.stride(0) if rowbias is not None else 0,
+                     residual=L.ptr(residual), ldr=_ld(residual) if residual is not None else 0, out_scale=out_scale,
+                     y=L.ptr(y), ldy=_ld(y), accumulate=int(accumulate))
+    L.check(lib.bd_conv3x3_ps(C.byref(d), L.stream()), "bd_conv3x3_ps")
+    return y
+
+
 def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False, mode=0, w_split=None):
     """Returns dx over the conv's own input grid [B, Hs<<ups, Ws<<ups, Cin]."""
     lib = L.load(); _need_cuda(dy, w)

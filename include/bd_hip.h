@@ -131,6 +131,8 @@ typedef struct {
     float* y; int64_t ldy;
     float* mean; float* rstd;       /* [B,G] */
     void* workspace; size_t workspace_bytes;
+    uint16_t* y_split; int64_t ldys;   /* optional: y also / only (y == NULL) as split planes [B*HW, ldys], see
+                                          "Pre-split operands" below: the operand format of bd_conv3x3_ps */
 } bd_gn_fwd_desc;
 size_t bd_gn_workspace_bytes(int B, int C);
 int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream);
@@ -147,6 +149,8 @@ typedef struct {
     float* dx_colsum; int64_t ld_colsum;    /* optional [B, C] (row stride ld_colsum): per-sample sum
                                                over pixels of the written dx (needs accumulate_dx=0);
                                                the time-embedding gradient of resnet.py:571            */
+    uint16_t* dx_split; int64_t lddxs;      /* optional: this launch's dx term also / only (dx == NULL) as split
+                                               planes (not accumulated)                                            */
 } bd_gn_bwd_desc;
 int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream);
 
@@ -250,6 +254,36 @@ typedef struct {
 } bd_conv3x3_wgrad_desc;
 int bd_conv3x3_wgrad(const bd_conv3x3_wgrad_desc* d, bd_stream_t stream);
 size_t bd_conv3x3_workspace_bytes(int B, int Ho, int Wo, int Hs, int Ws, int Cin, int Cout, int ups);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pre-split operands ("split planes"): an activation / gradient / weight matrix [rows, C] whose every
+ * 32-channel block of a row is one 128-byte line, 64 B of bf16 hi then 64 B of bf16 lo (hi = bf16
+ * truncation, lo = bf16 RNE of the remainder: exactly what BD_MODE_BF16X3 computes on the fly), i.e. the
+ * bd_split_bf16 layout with a leading dimension: element (r, c) lives at uint16 index
+ *     2*r*ld + (c/32)*64 + plane*32 + c%32          (ld % 32 == 0, 128-byte aligned base).
+ * Same 4 bytes per element as fp32.  Producers: bd_split_rows (from fp32), bd_gn_fwd / bd_gn_bwd
+ * (y_split / dx_split), bd_split_wt (transposed conv weights for the data gradient).
+ * bd_conv3x3_ps: stride-1 pad-1 3x3 convolution (direction +1) or its data gradient (direction -1, over
+ * the transposed weight planes) with both operands streamed global -> LDS by DMA; bit-identical to
+ * bd_conv3x3_fwd / bd_conv3x3_dgrad in BD_MODE_BF16X3.  Replaces aten::convolution(_backward input) of
+ * resnet.py:493,514 on the large layers.  H, W powers of two; K % 32 == 0; N % 128 == 0.
+ * ------------------------------------------------------------------------------------------------ */
+int bd_split_rows(const float* src, int64_t ld_src, int64_t rows, int C, uint16_t* dst, int64_t ld_dst, bd_stream_t stream);
+/* W[Cout][3][3][Cin] fp32 -> split planes of Wt[Cin][3][3][Cout] (rows = ci, k = tap*Cout + co) */
+int bd_split_wt(const float* w, int Cin, int Cout, uint16_t* out, bd_stream_t stream);
+typedef struct {
+    int B, H, W;                    /* image grid (input == output)                                  */
+    int K, N;                       /* contraction channels, output channels (fwd: Cin, Cout; dgrad: Cout, Cin) */
+    int direction;                  /* +1: y[p] = sum_tap x[p + tap] W[n][tap][:]   -1: dx[p] = sum_tap dy[p - tap] Wt[n][tap][:] */
+    const uint16_t* x_split; int64_t ldx;   /* [B*H*W, ldx] split planes                              */
+    const uint16_t* w_split;        /* [N][9][K] split planes (bd_split_bf16 of W, or bd_split_wt)   */
+    const float* bias;              /* [N] or NULL                                                   */
+    const float* rowbias; int64_t ld_rowbias;   /* [B, N] per-sample bias or NULL                    */
+    const float* residual; int64_t ldr;
+    float out_scale;                /* y = out_scale * (conv + bias + rowbias + residual)            */
+    float* y; int64_t ldy; int accumulate;
+} bd_conv3x3_ps_desc;
+int bd_conv3x3_ps(const bd_conv3x3_ps_desc* d, bd_stream_t stream);
 
 /* out[g, n] = sum over rows m in group g of x[m, n]  (rows_per_group rows each); bias / temb grads. */
 int bd_colsum(const float* x, int64_t ldx, int64_t rows, int N, int64_t rows_per_group, float* out,
