@@ -100,6 +100,11 @@ class ConvPsDesc(C.Structure):
                 ("residual", vp), ("ldr", i64), ("out_scale", f32), ("y", vp), ("ldy", i64), ("accumulate", i32)]
 
 
+class ConvPsWgradDesc(C.Structure):
+    _fields_ = [("B", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("x_split", vp), ("ldx", i64),
+                ("dy_split", vp), ("lddy", i64), ("dw", vp), ("db", vp), ("workspace", vp), ("workspace_bytes", sz)]
+
+
 class UnetConfig(C.Structure):
     _fields_ = [("sample_size", i32), ("in_channels", i32), ("out_channels", i32), ("num_blocks", i32),
                 ("block_out_channels", i32 * 8), ("down_attn", i32 * 8), ("up_attn", i32 * 8),
@@ -130,6 +135,8 @@ SIGNATURES = {
     "bd_split_rows": (i32, [vp, i64, i64, i32, vp, i64, vp]),
     "bd_split_wt": (i32, [vp, i32, i32, vp, vp]),
     "bd_conv3x3_ps": (i32, [C.POINTER(ConvPsDesc), vp]),
+    "bd_conv3x3_ps_wgrad": (i32, [C.POINTER(ConvPsWgradDesc), vp]),
+    "bd_conv3x3_ps_wgrad_workspace_bytes": (sz, [C.POINTER(ConvPsWgradDesc)]),
     "bd_conv3x3_fwd": (i32, [C.POINTER(ConvFwdDesc), vp]),
     "bd_conv3x3_dgrad": (i32, [C.POINTER(ConvDgradDesc), vp]),
     "bd_conv3x3_wgrad": (i32, [C.POINTER(ConvWgradDesc), vp]),

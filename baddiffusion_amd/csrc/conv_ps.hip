@@ -326,6 +326,209 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps_kernel(PsParams p) {
         }
 }
 
+// =====================================================================================================================
+// Weight gradient of the same convolutions on split planes:  dW[co][tap][ci] = sum_p dY[p][co] * X[p + tap][ci]
+//   GEMM view: M = Cout, N = 9*Cin (n = tap*Cin + ci), K = pixels.  Both operands are pixel-major ("row contiguous" in
+//   igemm.hip's terms), so a K chunk of 32 pixels x 128 channels is 32 rows of 512 contiguous bytes: two pixels per 1-KiB
+//   DMA instruction, and the MFMA fragments (k along pixels) are gathered with the hardware transpose read
+//   ds_read_b64_tr_b16.  LDS image of a chunk: [32 pixels][512 B]; pixel k's 16-byte slots are XOR-permuted by
+//   (k & 3) << 2 on the SOURCE side of the DMA (cdna guide rule 21), which puts the four pixels a transpose read touches
+//   on four different 64-byte bank windows: conflict-free.
+//   One workgroup = 8 waves (4 x 2) on a 128 (co) x 128 (one tap, 128 ci) tile, 32 x 64 per wave; K is split over
+//   ksplit workgroups per tile (fixed-order second pass, deterministic).  The bias gradient sum_p dY[p][co] rides along
+//   as two extra MFMAs against a vector of ones in the tn == 0 workgroups.
+// Replaces aten::convolution_backward(weight, bias) of resnet.py:493,514 for the stride-1 convolutions.
+constexpr int WG_BM = 128, WG_BN = 128, WG_OP_BYTES = 32 * 512, WG_STAGE_BYTES = 2 * WG_OP_BYTES;
+
+struct PsWgParams {
+    const char* dy; const char* x;     // split planes: dY [P][lddy], X [P][ldx]
+    long long lddy, ldx;
+    float* out;                        // ksplit == 1: dW [M][N]; else partial slabs [ksplit][M][N] then [ksplit][M] bias rows
+    float* db;                         // ksplit == 1 only (else the reduce pass writes it); may be null
+    int Cin, Cout, H, W, lw;           // image grid (powers of two)
+    int P;                             // pixels = K
+    int tiles_m, tiles_n, ksplit, cps; // chunks (of 32 pixels) per split
+    int want_db;
+};
+
+typedef short ps_short4 __attribute__((ext_vector_type(4)));
+typedef short ps_short8 __attribute__((ext_vector_type(8)));
+typedef __attribute__((address_space(3))) ps_short4 ps_lds_short4;
+
+__device__ __forceinline__ bf16x8 ps_tr_frag(const char* lds, int off) {
+    const ps_short4 v0 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ps_lds_short4*)(lds + off));
+    const ps_short4 v1 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((ps_lds_short4*)(lds + off + 4 * 512));
+    const ps_short8 v = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
+template <int STAGES>
+__global__ __launch_bounds__(512, 2) void conv_ps_wgrad_kernel(PsWgParams p) {
+    __shared__ __attribute__((aligned(128))) char smem[STAGES * WG_STAGE_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // logical order: n fastest, then m, then the K split; one contiguous run per XCD (same k-slice -> same L2)
+    int tm, tn, zz;
+    {
+        const unsigned L = blockIdx.x, T = gridDim.x, q = T >> 3;
+        const unsigned j = L < (q << 3) ? (L & 7) * q + (L >> 3) : L;
+        const unsigned ntiles = p.tiles_m * p.tiles_n;
+        zz = j / ntiles;
+        const unsigned tile = j - zz * ntiles;
+        tm = tile / p.tiles_n;
+        tn = tile - tm * p.tiles_n;
+    }
+    const int co0 = tm * WG_BM, n0 = tn * WG_BN;
+    const int tap = n0 / p.Cin, ci0 = n0 - tap * p.Cin;
+    const int dyt = tap / 3 - 1, dxt = tap - (tap / 3) * 3 - 1;
+    const int nchunks = p.P >> 5;
+    const int c_begin = zz * p.cps;
+    int c_end = c_begin + p.cps;
+    if (c_end > nchunks) c_end = nchunks;
+
+    // ---- DMA: wave w moves pixel pairs w and w + 8 of both operands; lane: pixel k = 2*pair + lane/32, slot lane%32
+    const int ps = lane & 31;
+    const char* asrc[2]; const char* bsrc[2];
+    int kpix[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = 2 * (wave + 8 * j) + (lane >> 5);
+        kpix[j] = k;
+        const int ls = ps ^ ((k & 3) << 2);
+        const long long pa = (long long)c_begin * 32 + k;
+        asrc[j] = p.dy + pa * p.lddy * 4 + co0 * 4 + ls * 16;
+        bsrc[j] = p.x + (pa + dyt * p.W + dxt) * p.ldx * 4 + ci0 * 4 + ls * 16;
+    }
+    const long long a_adv = 32 * p.lddy * 4, b_adv = 32 * p.ldx * 4;
+    int q_pix = c_begin * 32;   // first pixel of the next chunk to issue
+    auto issue = [&](char* stage) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int pp = q_pix + kpix[j];
+            const int x = pp & (p.W - 1), y = (pp >> p.lw) & (p.H - 1);
+            const bool ok = (unsigned)(y + dyt) < (unsigned)p.H && (unsigned)(x + dxt) < (unsigned)p.W;
+            ps_dma16(asrc[j], stage + (wave + 8 * j) * 1024);
+            ps_dma16(ok ? bsrc[j] : reinterpret_cast<const char*>(kPsZero), stage + WG_OP_BYTES + (wave + 8 * j) * 1024);
+            asrc[j] += a_adv; bsrc[j] += b_adv;
+        }
+        q_pix += 32;
+    };
+
+    // ---- fragment addresses (ds_read_b64_tr_b16, see igemm.hip rc_frag): lane reads 4 rows x 1 pixel (8 bytes)
+    const int sl = lane & 15, hb = (lane >> 4) & 1, h = lane >> 5;
+    const int kq = sl >> 2, rq = sl & 3;
+    const int lane_base = (8 * h + kq) * 512 + hb * 32 + rq * 8;
+    int xw[4];   // 64-byte window of (tile parity, plane) after the per-pixel XOR
+#pragma unroll
+    for (int v = 0; v < 4; ++v) xw[v] = (v ^ kq) << 6;
+    auto foff = [&](int t, int plane, int kk) { return lane_base + xw[(t & 1) * 2 + plane] + (t >> 1) * 256 + kk * 512; };
+
+    floatx16 acc[2], accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; accb[r] = 0.f; }
+    const bool do_db = p.want_db && tn == 0 && wn == 0;   // wave-uniform
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    auto compute = [&](const char* stage) {
+        const char* sa = stage;
+        const char* sb = stage + WG_OP_BYTES;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 ah = ps_tr_frag(sa, foff(wm, 0, 16 * s)), al = ps_tr_frag(sa, foff(wm, 1, 16 * s));
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                bh[q] = ps_tr_frag(sb, foff(wn * 2 + q, 0, 16 * s));
+                bl[q] = ps_tr_frag(sb, foff(wn * 2 + q, 1, 16 * s));
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[q], acc[q], 0, 0, 0);
+            if (do_db) {
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, accb, 0, 0, 0);
+            }
+        }
+    };
+
+    const int n = c_end - c_begin;
+    if constexpr (STAGES == 3) {
+        // ring of three: chunk c+2 is issued behind the barrier that frees chunk c-1's stage; 4 DMAs per wave and chunk
+        char* st[3] = {smem, smem + WG_STAGE_BYTES, smem + 2 * WG_STAGE_BYTES};
+        if (n > 0) issue(st[0]);
+        if (n > 1) issue(st[1]);
+        int c = 0;
+        for (; c + 2 < n; ++c) {   // steady state: two chunks in flight behind the one being waited for
+            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            const int cur = c % 3, nxt = (c + 2) % 3;
+            issue(smem + nxt * WG_STAGE_BYTES);
+            compute(smem + cur * WG_STAGE_BYTES);
+        }
+        for (; c < n; ++c) {
+            if (c + 1 < n) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            compute(smem + (c % 3) * WG_STAGE_BYTES);
+        }
+    } else {
+        if (n > 0) issue(smem);
+        for (int c = 0; c < n; ++c) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c + 1 < n) issue(smem + ((c + 1) & 1) * WG_STAGE_BYTES);
+            compute(smem + (c & 1) * WG_STAGE_BYTES);
+        }
+    }
+
+    // ---- epilogue: lane holds column n = li of rows (r&3) + 8*(r>>2) + 4*h
+    const int li = lane & 31;
+    const int M = p.Cout, N = 9 * p.Cin;
+    float* out = p.out + (p.ksplit > 1 ? (long long)zz * M * N : 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int nn = n0 + wn * 64 + q * 32 + li;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            out[(long long)m * N + nn] = acc[q][r];
+        }
+    }
+    if (do_db && li == 0) {
+        float* o = p.ksplit > 1 ? p.out + (long long)p.ksplit * M * N + (long long)zz * M : p.db;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = accb[r];
+    }
+}
+
+// fixed-order sum of the K-split slabs (float4 per thread); the tail threads fold the bias rows
+__global__ __launch_bounds__(256) void conv_ps_wgrad_reduce(const float* __restrict__ part, int ksplit, long long mn, int M,
+                                                            float* __restrict__ dw, float* __restrict__ db) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long n4 = mn >> 2;
+    if (i < n4) {
+        float4 a = *reinterpret_cast<const float4*>(part + 4 * i);
+        for (int s = 1; s < ksplit; ++s) {
+            const float4 b = *reinterpret_cast<const float4*>(part + (long long)s * mn + 4 * i);
+            a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+        }
+        *reinterpret_cast<float4*>(dw + 4 * i) = a;
+    } else if (db && i - n4 < M) {
+        const long long m = i - n4;
+        float v = 0.f;
+        for (int s = 0; s < ksplit; ++s) v += part[(long long)ksplit * mn + (long long)s * M + m];
+        db[m] = v;
+    }
+}
+
 // ---- producers of split planes -------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned ps_pack_hi(float a, float b) {
     return (__builtin_bit_cast(unsigned, a) >> 16) | (__builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
@@ -435,11 +638,80 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
     return BD_OK;
 }
 
+bool conv3x3_ps_wgrad_supported(int B, int H, int W, int Cin, int Cout) {
+    return ilog2x(H) >= 0 && ilog2x(W) >= 0 && Cin % WG_BN == 0 && Cout % WG_BM == 0 && ((long long)B * H * W) % 32 == 0;
+}
+static void ps_wgrad_split(const bd_conv3x3_ps_wgrad_desc& d, int& ksplit, int& cps) {
+    const long long tiles = (long long)(d.Cout / WG_BM) * (9 * d.Cin / WG_BN);
+    const int nchunks = (int)((long long)d.B * d.H * d.W / 32);
+    static const int slots = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const char* e = getenv("BD_PS_WG_SLOTS");
+        return e ? atoi(e) : 2 * cus;   // two 64-KB workgroups per CU (two LDS stages each): the pair de-phases, 141 vs 189 us
+    }();
+    int ks = (int)(slots / tiles);
+    if (ks < 1) ks = 1;
+    if (ks > nchunks / 4) ks = nchunks / 4 > 0 ? nchunks / 4 : 1;
+    cps = (int)cdiv(nchunks, ks);
+    ksplit = (int)cdiv(nchunks, cps);
+}
+size_t conv3x3_ps_wgrad_workspace_bytes(const bd_conv3x3_ps_wgrad_desc& d) {
+    int ks, cps;
+    ps_wgrad_split(d, ks, cps);
+    return ks > 1 ? (size_t)ks * ((size_t)d.Cout * 9 * d.Cin + d.Cout) * sizeof(float) : 0;
+}
+int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
+    BD_CHECK(d.x_split && d.dy_split && d.dw, BD_ERR_INVALID, "conv3x3_ps_wgrad: null pointer");
+    BD_CHECK(d.B > 0 && conv3x3_ps_wgrad_supported(d.B, d.H, d.W, d.Cin, d.Cout), BD_ERR_UNSUPPORTED,
+             "conv3x3_ps_wgrad: needs power-of-two H, W, Cin and Cout multiples of 128, B*H*W %% 32 == 0");
+    BD_CHECK(d.ldx % 32 == 0 && d.lddy % 32 == 0 && ((uintptr_t)d.x_split & 127) == 0 && ((uintptr_t)d.dy_split & 127) == 0,
+             BD_ERR_UNSUPPORTED, "conv3x3_ps_wgrad: split planes need ld %% 32 == 0 and 128-byte aligned bases");
+    PsWgParams p = {};
+    p.dy = reinterpret_cast<const char*>(d.dy_split); p.x = reinterpret_cast<const char*>(d.x_split);
+    p.lddy = d.lddy; p.ldx = d.ldx; p.Cin = d.Cin; p.Cout = d.Cout; p.H = d.H; p.W = d.W; p.lw = ilog2x(d.W);
+    p.P = d.B * d.H * d.W;
+    p.tiles_m = d.Cout / WG_BM; p.tiles_n = 9 * d.Cin / WG_BN;
+    ps_wgrad_split(d, p.ksplit, p.cps);
+    p.want_db = d.db != nullptr;
+    const long long mn = (long long)d.Cout * 9 * d.Cin;
+    if (p.ksplit > 1) {
+        const size_t need = (size_t)p.ksplit * ((size_t)mn + d.Cout) * sizeof(float);
+        BD_CHECK(d.workspace && d.workspace_bytes >= need, BD_ERR_WORKSPACE, "conv3x3_ps_wgrad: workspace %zu < %zu", d.workspace_bytes, need);
+        p.out = reinterpret_cast<float*>(d.workspace);
+    } else {
+        p.out = d.dw; p.db = d.db;
+    }
+    int rec = -1;
+    if (prof_on())
+        rec = prof_begin("conv_ps_wgrad", 2.0 * (double)p.P * d.Cout * 9.0 * d.Cin,
+                         ((double)p.P * (d.Cin + d.Cout) + 9.0 * d.Cin * d.Cout) * 4.0, st);
+    static const int stages = getenv("BD_PS_WG_STAGES") ? atoi(getenv("BD_PS_WG_STAGES")) : 2;
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.ksplit));
+    if (stages == 2) hipLaunchKernelGGL(conv_ps_wgrad_kernel<2>, grid, dim3(512), 0, st, p);
+    else hipLaunchKernelGGL(conv_ps_wgrad_kernel<3>, grid, dim3(512), 0, st, p);
+    BD_LAUNCH_CHECK("conv_ps_wgrad");
+    if (p.ksplit > 1) {
+        const long long total = mn / 4 + (d.db ? d.Cout : 0);
+        hipLaunchKernelGGL(conv_ps_wgrad_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, p.out, p.ksplit, mn, d.Cout, d.dw, d.db);
+        BD_LAUNCH_CHECK("conv_ps_wgrad_reduce");
+    }
+    prof_end(rec, st);
+    return BD_OK;
+}
+
 }  // namespace bd
 
 extern "C" int bd_conv3x3_ps(const bd_conv3x3_ps_desc* d, bd_stream_t s) {
     BD_CHECK(d, BD_ERR_INVALID, "bd_conv3x3_ps: null descriptor");
     return bd::conv3x3_ps(*d, bd::S(s));
+}
+extern "C" int bd_conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc* d, bd_stream_t s) {
+    BD_CHECK(d, BD_ERR_INVALID, "bd_conv3x3_ps_wgrad: null descriptor");
+    return bd::conv3x3_ps_wgrad(*d, bd::S(s));
+}
+extern "C" size_t bd_conv3x3_ps_wgrad_workspace_bytes(const bd_conv3x3_ps_wgrad_desc* d) {
+    return d ? bd::conv3x3_ps_wgrad_workspace_bytes(*d) : 0;
 }
 extern "C" int bd_split_rows(const float* src, int64_t ld_src, int64_t rows, int C, uint16_t* dst, int64_t ld_dst, bd_stream_t stream) {
     BD_CHECK(src && dst && rows > 0 && C > 0, BD_ERR_INVALID, "bd_split_rows: bad args");

@@ -28,6 +28,8 @@ int conv3x3_wgrad(const bd_conv3x3_wgrad_desc& d, hipStream_t st);
 bool conv3x3_wgrad_is_thin(const bd_conv3x3_wgrad_desc& d);
 int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st);                         // conv_ps.hip
 bool conv3x3_ps_supported(int B, int H, int W, int K_channels, int N_channels);
+int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st);
+bool conv3x3_ps_wgrad_supported(int B, int H, int W, int Cin, int Cout);
 
 struct View {
     int buf = -1;   // value buffer id
@@ -292,9 +294,19 @@ struct bd_unet {
     }
     // pre-split / LDS-DMA convolution (conv_ps.hip) for the stride-1 3x3 convs whose operands the producers can emit as
     // split planes: BF16X3 mode only (same arithmetic, bit-identical), shapes per conv3x3_ps_supported
-    bool ps_ok(const Ctx& c, int H, int W, int K, int N) const {
+    // One decision per convolution, for its forward, data gradient and weight gradient alike (they share the split
+    // operands), taken on the batch the workspace is laid out for (c.LB: the forward's half-batch pipelines and the
+    // backward must agree).
+    bool ps_ok(const Ctx& c, int H, int W, int Cin, int Cout) const {
         static const bool off = getenv("BD_CONV_PS") && atoi(getenv("BD_CONV_PS")) == 0;
-        return !off && cfg.compute_mode == BD_MODE_BF16X3 && (c.dry || c.w_split) && conv3x3_ps_supported(c.B, H, W, K, N);
+        const int B = c.LB > 0 ? c.LB : c.B;
+        return !off && cfg.compute_mode == BD_MODE_BF16X3 && (c.dry || c.w_split) && conv3x3_ps_supported(B, H, W, Cin, Cout) &&
+               conv3x3_ps_supported(B, H, W, Cout, Cin) && conv3x3_ps_wgrad_supported(B, H, W, Cin, Cout);
+    }
+    int conv_pw(Ctx& c, bd_conv3x3_ps_wgrad_desc& d) const {
+        d.workspace_bytes = c.opws_bytes;
+        if (c.dry) { note_conv(c); return BD_OK; }
+        return on_aux(c, [&](hipStream_t st, char* ws) { d.workspace = ws; return conv3x3_ps_wgrad(d, st); });
     }
     static uint16_t* U16(float* p) { return reinterpret_cast<uint16_t*>(p); }
     int conv_p(Ctx& c, bd_conv3x3_ps_desc& d) const {
@@ -423,7 +435,7 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             bd_gn_fwd_desc g = {};
             g.B = c.B; g.HW = HW; g.C = Cin; g.G = G; g.eps = cfg.norm_eps; g.silu = 1;
             g.x = VP(c, x); g.ldx = x.ld; g.gamma = c.params + pn1w; g.beta = c.params + pn1b;
-            g.y = c.training ? BP(c, b_a1) : nullptr; g.ldy = Cin;     // fp32 copy: operand of the weight gradient
+            g.y = nullptr; g.ldy = Cin;     // split planes only: conv1 fwd and (a1s is a value buffer) its weight gradient read them
             g.y_split = U16(BP(c, b_a1s)); g.ldys = Cin;
             g.mean = MEANP(c, b_st1, G); g.rstd = RSTDP(c, b_st1, G);
             g.workspace = c.opws; g.workspace_bytes = c.opws_bytes;
@@ -447,7 +459,7 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             bd_gn_fwd_desc g = {};
             g.B = c.B; g.HW = HW; g.C = Cout; g.G = G; g.eps = cfg.norm_eps; g.silu = 1;
             g.x = BP(c, b_h1); g.ldx = Cout; g.gamma = c.params + pn2w; g.beta = c.params + pn2b;
-            g.y = c.training ? BP(c, b_a2) : nullptr; g.ldy = Cout;
+            g.y = nullptr; g.ldy = Cout;
             g.y_split = U16(BP(c, b_a2s)); g.ldys = Cout;
             g.mean = MEANP(c, b_st2, G); g.rstd = RSTDP(c, b_st2, G);
             g.workspace = c.opws; g.workspace_bytes = c.opws_bytes;
@@ -482,13 +494,14 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             BD_TRY(add(c, dy, lddy, BP(c, b_dys), Cout, M, Cout, inv, 0));
             dy = BP(c, b_dys); lddy = Cout;
         }
-        bd_conv3x3_wgrad_desc w2 = {};
-        w2.B = c.B; w2.Hs = H; w2.Ws = W; w2.Cin = Cout; w2.Cout = Cout; w2.stride = 1; w2.pad_t = 1; w2.pad_l = 1; w2.Ho = H; w2.Wo = W;
-        w2.x = BP(c, b_a2); w2.ldx = Cout; w2.dy = dy; w2.lddy = lddy; w2.dw = c.grads + pc2w; w2.db = c.grads + pc2b;
-        BD_TRY(conv_w(c, w2));
-        const bool ps1 = ps_ok(c, H, W, Cout, Cin), ps2 = ps_ok(c, H, W, Cout, Cout);   // data gradients: K = Cout, N = Cin
+        const bool ps1 = ps_ok(c, H, W, Cin, Cout), ps2 = ps_ok(c, H, W, Cout, Cout);
         if (ps2) {
             BD_TRY(split_rows(c, dy, lddy, M, Cout, BP(c, b_dyS)));
+            bd_conv3x3_ps_wgrad_desc w2 = {};
+            w2.B = c.B; w2.H = H; w2.W = W; w2.Cin = Cout; w2.Cout = Cout;
+            w2.x_split = U16(BP(c, b_a2s)); w2.ldx = Cout; w2.dy_split = U16(BP(c, b_dyS)); w2.lddy = Cout;
+            w2.dw = c.grads + pc2w; w2.db = c.grads + pc2b;
+            BD_TRY(conv_pw(c, w2));
             if (!c.dry) BD_TRY(bd_split_wt(c.params + pc2w, Cout, Cout, U16(BP(c, b_wT2)), (bd_stream_t)c.st));
             bd_conv3x3_ps_desc g2 = {};
             g2.B = c.B; g2.H = H; g2.W = W; g2.K = Cout; g2.N = Cout; g2.direction = -1;
@@ -496,6 +509,10 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             g2.y = BP(c, b_da2); g2.ldy = Cout;
             BD_TRY(conv_p(c, g2));
         } else {
+            bd_conv3x3_wgrad_desc w2 = {};
+            w2.B = c.B; w2.Hs = H; w2.Ws = W; w2.Cin = Cout; w2.Cout = Cout; w2.stride = 1; w2.pad_t = 1; w2.pad_l = 1; w2.Ho = H; w2.Wo = W;
+            w2.x = BP(c, b_a2); w2.ldx = Cout; w2.dy = dy; w2.lddy = lddy; w2.dw = c.grads + pc2w; w2.db = c.grads + pc2b;
+            BD_TRY(conv_w(c, w2));
             bd_conv3x3_dgrad_desc g2 = {};
             g2.B = c.B; g2.Hs = H; g2.Ws = W; g2.Cin = Cout; g2.Cout = Cout; g2.stride = 1; g2.pad_t = 1; g2.pad_l = 1; g2.Ho = H; g2.Wo = W;
             g2.dy = dy; g2.lddy = lddy; g2.w = c.params + pc2w; g2.dx = BP(c, b_da2); g2.lddx = Cout;
@@ -506,7 +523,7 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             d.B = c.B; d.HW = HW; d.C = Cout; d.G = G; d.silu = 1;
             d.x = BP(c, b_h1); d.ldx = Cout; d.gamma = c.params + pn2w; d.beta = c.params + pn2b;
             d.mean = MEANP(c, b_st2, G); d.rstd = RSTDP(c, b_st2, G);
-            d.dy = BP(c, b_da2); d.lddy = Cout; d.dx = BP(c, b_dh1); d.lddx = Cout; d.accumulate_dx = 0;
+            d.dy = BP(c, b_da2); d.lddy = Cout; d.dx = ps1 ? nullptr : BP(c, b_dh1); d.lddx = Cout; d.accumulate_dx = 0;
             d.dgamma = c.grads + pn2w; d.dbeta = c.grads + pn2b;
             d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
             // time-embedding gradient = per-sample column sums of dh1, out of the same launch
@@ -514,11 +531,12 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             if (ps1) { d.dx_split = U16(BP(c, b_dh1S)); d.lddxs = Cout; }
             if (!c.dry) BD_TRY(bd_gn_bwd(&d, (bd_stream_t)c.st));
         }
-        bd_conv3x3_wgrad_desc w1 = {};
-        w1.B = c.B; w1.Hs = H; w1.Ws = W; w1.Cin = Cin; w1.Cout = Cout; w1.stride = 1; w1.pad_t = 1; w1.pad_l = 1; w1.Ho = H; w1.Wo = W;
-        w1.x = BP(c, b_a1); w1.ldx = Cin; w1.dy = BP(c, b_dh1); w1.lddy = Cout; w1.dw = c.grads + pc1w; w1.db = c.grads + pc1b;
-        BD_TRY(conv_w(c, w1));
         if (ps1) {
+            bd_conv3x3_ps_wgrad_desc w1 = {};
+            w1.B = c.B; w1.H = H; w1.W = W; w1.Cin = Cin; w1.Cout = Cout;
+            w1.x_split = U16(BP(c, b_a1s)); w1.ldx = Cin; w1.dy_split = U16(BP(c, b_dh1S)); w1.lddy = Cout;
+            w1.dw = c.grads + pc1w; w1.db = c.grads + pc1b;
+            BD_TRY(conv_pw(c, w1));
             if (!c.dry) BD_TRY(bd_split_wt(c.params + pc1w, Cin, Cout, U16(BP(c, b_wT1)), (bd_stream_t)c.st));
             bd_conv3x3_ps_desc g1 = {};
             g1.B = c.B; g1.H = H; g1.W = W; g1.K = Cout; g1.N = Cin; g1.direction = -1;
@@ -526,6 +544,10 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             g1.y = BP(c, b_da1); g1.ldy = Cin;
             BD_TRY(conv_p(c, g1));
         } else {
+            bd_conv3x3_wgrad_desc w1 = {};
+            w1.B = c.B; w1.Hs = H; w1.Ws = W; w1.Cin = Cin; w1.Cout = Cout; w1.stride = 1; w1.pad_t = 1; w1.pad_l = 1; w1.Ho = H; w1.Wo = W;
+            w1.x = BP(c, b_a1); w1.ldx = Cin; w1.dy = BP(c, b_dh1); w1.lddy = Cout; w1.dw = c.grads + pc1w; w1.db = c.grads + pc1b;
+            BD_TRY(conv_w(c, w1));
             bd_conv3x3_dgrad_desc g1 = {};
             g1.B = c.B; g1.Hs = H; g1.Ws = W; g1.Cin = Cin; g1.Cout = Cout; g1.stride = 1; g1.pad_t = 1; g1.pad_l = 1; g1.Ho = H; g1.Wo = W;
             g1.dy = BP(c, b_dh1); g1.lddy = Cout; g1.w = c.params + pc1w; g1.dx = BP(c, b_da1); g1.lddx = Cin;

@@ -268,6 +268,19 @@ def conv3x3_ps(x_split, w_split, B, H, W, K, N, direction=1, bias=None, rowbias=
     return y
 
 
+def conv3x3_ps_wgrad(x_split, dy_split, B, H, W, Cin, Cout, with_db=False):
+    """dw [Cout,3,3,Cin] (and db [Cout]) of the stride-1 pad-1 conv from split-plane operands."""
+    lib = L.load(); _need_cuda(x_split, dy_split)
+    dw = torch.empty(Cout, 3, 3, Cin, device=x_split.device)
+    db = torch.empty(Cout, device=x_split.device) if with_db else None
+    d = L.ConvPsWgradDesc(B=B, H=H, W=W, Cin=Cin, Cout=Cout, x_split=L.ptr(x_split), ldx=Cin, dy_split=L.ptr(dy_split),
+                          lddy=Cout, dw=L.ptr(dw), db=L.ptr(db))
+    ws = workspace(lib.bd_conv3x3_ps_wgrad_workspace_bytes(C.byref(d)), x_split.device, "ps_wgrad")
+    d.workspace = L.ptr(ws); d.workspace_bytes = ws.numel()
+    L.check(lib.bd_conv3x3_ps_wgrad(C.byref(d), L.stream()), "bd_conv3x3_ps_wgrad")
+    return (dw, db) if with_db else dw
+
+
 def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False, mode=0, w_split=None):
     """Returns dx over the conv's own input grid [B, Hs<<ups, Ws<<ups, Cin]."""
     lib = L.load(); _need_cuda(dy, w)

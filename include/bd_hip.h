@@ -284,6 +284,19 @@ typedef struct {
     float* y; int64_t ldy; int accumulate;
 } bd_conv3x3_ps_desc;
 int bd_conv3x3_ps(const bd_conv3x3_ps_desc* d, bd_stream_t stream);
+/* weight (and bias) gradient of the same convolution, both operands as split planes:
+ *   dw[Cout][3][3][Cin] = sum_p dy[p][co] x[p + tap][ci],  db[Cout] = sum_p dy[p][co] (optional, same launch).
+ * Cin, Cout % 128 == 0; K (pixels) is split over workgroups with a fixed-order second pass (deterministic);
+ * workspace >= bd_conv3x3_ps_wgrad_workspace_bytes().  Replaces aten::convolution_backward (weight, bias).   */
+typedef struct {
+    int B, H, W, Cin, Cout;
+    const uint16_t* x_split; int64_t ldx;     /* conv input  [B*H*W, ldx]  */
+    const uint16_t* dy_split; int64_t lddy;   /* output grad [B*H*W, lddy] */
+    float* dw; float* db;
+    void* workspace; size_t workspace_bytes;
+} bd_conv3x3_ps_wgrad_desc;
+size_t bd_conv3x3_ps_wgrad_workspace_bytes(const bd_conv3x3_ps_wgrad_desc* d);
+int bd_conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc* d, bd_stream_t stream);
 
 /* out[g, n] = sum over rows m in group g of x[m, n]  (rows_per_group rows each); bias / temb grads. */
 int bd_colsum(const float* x, int64_t ldx, int64_t rows, int N, int64_t rows_per_group, float* out,
