@@ -97,7 +97,8 @@ class ConvWgradDesc(C.Structure):
 class ConvPsDesc(C.Structure):
     _fields_ = [("B", i32), ("H", i32), ("W", i32), ("K", i32), ("N", i32), ("direction", i32),
                 ("x_split", vp), ("ldx", i64), ("w_split", vp), ("bias", vp), ("rowbias", vp), ("ld_rowbias", i64),
-                ("residual", vp), ("ldr", i64), ("out_scale", f32), ("y", vp), ("ldy", i64), ("accumulate", i32)]
+                ("residual", vp), ("ldr", i64), ("out_scale", f32), ("y", vp), ("ldy", i64), ("accumulate", i32),
+                ("workspace", vp), ("workspace_bytes", sz)]
 
 
 class ConvPsWgradDesc(C.Structure):
@@ -135,6 +136,7 @@ SIGNATURES = {
     "bd_split_rows": (i32, [vp, i64, i64, i32, vp, i64, vp]),
     "bd_split_wt": (i32, [vp, i32, i32, vp, vp]),
     "bd_conv3x3_ps": (i32, [C.POINTER(ConvPsDesc), vp]),
+    "bd_conv3x3_ps_workspace_bytes": (sz, [C.POINTER(ConvPsDesc)]),
     "bd_conv3x3_ps_wgrad": (i32, [C.POINTER(ConvPsWgradDesc), vp]),
     "bd_conv3x3_ps_wgrad_workspace_bytes": (sz, [C.POINTER(ConvPsWgradDesc)]),
     "bd_conv3x3_fwd": (i32, [C.POINTER(ConvFwdDesc), vp]),

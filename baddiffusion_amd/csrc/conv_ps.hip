@@ -44,7 +44,7 @@ struct PsParams {
     float out_scale;
     int accumulate;
     unsigned short* y_split; long long ldys;   // optional second output: y in split planes (same row count, ld)
-    int ablate;            // measurement only (BD_PS_ABLATE): 1 = no steady-state DMA, 2 = no MFMA, 4 = no fragment reads
+    int ablate;            // -DBD_PS_ABLATION builds only (BD_PS_ABLATE): 1 = no steady-state DMA, 2 = no MFMA, 4 = no fragment reads
 };
 
 // bank swizzle of the 16-byte slots of a 128-byte LDS row (row stride 128 B = half a 256-byte bank row): rows r and
@@ -139,7 +139,9 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps_kernel(PsParams p) {
     int q_aoff = -p.sign * (p.W + 1) * pix_bytes, q_woff = 0;   // tap (0,0) of block 0
     int issued = 0;
     auto issue = [&](char* stage) {
+#ifdef BD_PS_ABLATION
         if ((p.ablate & 1) && issued >= 2) return;
+#endif
         ++issued;
 #pragma unroll
         for (int j = 0; j < 4; ++j) ps_dma16((vm[j] & q_bit) ? ap[j] + q_aoff : reinterpret_cast<const char*>(kPsZero), stage + (wave + 8 * j) * 1024);
@@ -180,10 +182,13 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps_kernel(PsParams p) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 ah[2], al[2], bh[2], bl[2];
+#ifdef BD_PS_ABLATION
             if (p.ablate & 4) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) { ah[i] = al[i] = bh[i] = bl[i] = __builtin_bit_cast(bf16x8, make_float4(1.f, 1.f, (float)s, 1.f)); }
-            } else {
+            } else
+#endif
+            {
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 ah[i] = *reinterpret_cast<const bf16x8*>(stage + abase + i * 4096 + foff[s][0]);
@@ -192,11 +197,13 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps_kernel(PsParams p) {
                 bl[i] = *reinterpret_cast<const bf16x8*>(stage + bbase + i * 4096 + foff[s][1]);
             }
             }
+#ifdef BD_PS_ABLATION
             if (p.ablate & 2) {
 #pragma unroll
                 for (int i = 0; i < 2; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]), "v"(bh[i]), "v"(bl[i]));
                 continue;
             }
+#endif
 #pragma unroll
             for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -324,6 +331,193 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps_kernel(PsParams p) {
                 *dst = v;
             }
         }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
+// 128 x 128 tile variant for the SMALL layers (8x8 / 4x4 images: too few 256 x 128 tiles to fill the chip): same operands,
+// same fragment layout, 8 waves of 32 x 64, two LDS stages (64 KB -> two workgroups per CU, which de-phase), and the K
+// chunks (tap, 32 channels) split over `ksplit` workgroups per tile: partial slabs + a fixed-order second pass that also
+// applies the epilogue (deterministic, no atomics).
+struct PsSmallParams {
+    PsParams q;
+    float* partial;        // [ksplit][M][N] when ksplit > 1
+    int ksplit, cps;       // chunks per split
+};
+
+template <int EPI>
+__global__ __launch_bounds__(512, 4) void conv_ps128_kernel(PsSmallParams pp) {
+    const PsParams& p = pp.q;
+    constexpr int A_BYTES = 128 * 128, STAGE = 2 * A_BYTES;
+    __shared__ __attribute__((aligned(128))) char smem[2 * STAGE];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    int tm, tn, zz;
+    {
+        const unsigned L = blockIdx.x, T = gridDim.x, q = T >> 3;
+        const unsigned j = L < (q << 3) ? (L & 7) * q + (L >> 3) : L;
+        const unsigned ntiles = p.tiles_m * p.tiles_n;
+        zz = j / ntiles;
+        const unsigned tile = j - zz * ntiles;
+        tm = tile / p.tiles_n;
+        tn = tile - tm * p.tiles_n;
+    }
+    const int m0 = tm * 128, n0 = tn * 128;
+    const int nchunks = 9 * (p.C >> 5);
+    const int c_begin = zz * pp.cps;
+    int c_end = c_begin + pp.cps;
+    if (c_end > nchunks) c_end = nchunks;
+
+    const int dr = lane >> 3, ps = lane & 7;
+    const char* ap[2]; const char* wp[2];
+    int vm[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave + 8 * j) * 8 + dr;
+        const int m = m0 + r;
+        const int x = m & (p.W - 1), y = (m >> p.lw) & (p.H - 1);
+        int mask = 0;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + p.sign * (t / 3 - 1), xx = x + p.sign * (t % 3 - 1);
+            if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) mask |= 1 << t;
+        }
+        vm[j] = m < p.M ? mask : 0;
+        ap[j] = p.a + (long long)m * p.lda * 4 + ((ps ^ ps_swz(r)) << 4);
+        int n = n0 + r;
+        if (n >= p.N) n = p.N - 1;
+        wp[j] = p.w + (long long)n * 36 * p.C + ((ps ^ ps_swz(r)) << 4);
+    }
+    const int pix_bytes = (int)p.lda * 4;
+    int q_cb = c_begin / 9;
+    int q_tap = c_begin - 9 * q_cb;
+    int q_kh = q_tap / 3, q_kw = q_tap - 3 * q_kh, q_bit = 1 << q_tap;
+    int q_aoff = p.sign * ((q_kh - 1) * p.W + (q_kw - 1)) * pix_bytes + q_cb * 128;
+    int q_woff = (q_tap * p.C + q_cb * 32) * 4;
+    auto issue = [&](char* stage) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            ps_dma16((vm[j] & q_bit) ? ap[j] + q_aoff : reinterpret_cast<const char*>(kPsZero), stage + (wave + 8 * j) * 1024);
+            ps_dma16(wp[j] + q_woff, stage + A_BYTES + (wave + 8 * j) * 1024);
+        }
+        q_bit <<= 1;
+        q_woff += p.C * 4;
+        q_aoff += p.sign * pix_bytes;
+        if (++q_kw == 3) {
+            q_kw = 0;
+            q_aoff += p.sign * (p.W - 3) * pix_bytes;
+            if (++q_kh == 3) {
+                q_kh = 0; q_bit = 1;
+                q_aoff += 128 - p.sign * 3 * p.W * pix_bytes;
+                q_woff += 128 - 9 * p.C * 4;
+            }
+        }
+    };
+    int foff[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) foff[s][pl] = li * 128 + (((pl * 4 + s * 2 + h) ^ ps_swz(li)) << 4);
+    const int abase = wm * 32 * 128, bbase = A_BYTES + wn * 64 * 128;
+    floatx16 acc[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; }
+    auto compute = [&](const char* stage) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const bf16x8 ah = *reinterpret_cast<const bf16x8*>(stage + abase + foff[s][0]);
+            const bf16x8 al = *reinterpret_cast<const bf16x8*>(stage + abase + foff[s][1]);
+            bf16x8 bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                bh[i] = *reinterpret_cast<const bf16x8*>(stage + bbase + i * 4096 + foff[s][0]);
+                bl[i] = *reinterpret_cast<const bf16x8*>(stage + bbase + i * 4096 + foff[s][1]);
+            }
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[q], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[q], acc[q], 0, 0, 0);
+        }
+    };
+    const int n = c_end - c_begin;
+    if (n > 0) issue(smem);
+    for (int c = 0; c < n; ++c) {
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        if (c + 1 < n) issue(smem + ((c + 1) & 1) * STAGE);
+        compute(smem + (c & 1) * STAGE);
+    }
+    const int mw = m0 + wm * 32, nw = n0 + wn * 64;
+    if (pp.ksplit > 1) {
+        float* out = pp.partial + (long long)zz * p.M * p.N;
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int nn = nw + q * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (m < p.M) out[(long long)m * p.N + nn] = acc[q][r];
+            }
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int nn = nw + q * 32 + li;
+        const float bn = p.bias ? p.bias[nn] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (m >= p.M) continue;
+            float v = acc[q][r] + bn;
+            if constexpr (EPI & 2) v += p.rowbias[(long long)(m >> p.lhw) * p.ld_rowbias + nn];
+            if constexpr (EPI & 1) v += p.residual[(long long)m * p.ldr + nn];
+            v *= p.out_scale;
+            float* dst = p.y + (long long)m * p.ldy + nn;
+            if constexpr (EPI & 4) v += *dst;
+            *dst = v;
+        }
+    }
+}
+
+// second pass of the K split: fixed-order sum of the slabs + the epilogue, float4 per thread (N % 4 == 0)
+__global__ __launch_bounds__(256) void conv_ps128_reduce(PsSmallParams pp) {
+    const PsParams& p = pp.q;
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    const int n4 = p.N >> 2;
+    if (i >= (long long)p.M * n4) return;
+    const int m = (int)(i / n4), nn = (int)(i - (long long)m * n4) * 4;
+    const long long mn = (long long)p.M * p.N, e = (long long)m * p.N + nn;
+    float4 a = *reinterpret_cast<const float4*>(pp.partial + e);
+    for (int s = 1; s < pp.ksplit; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(pp.partial + (long long)s * mn + e);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    float v[4] = {a.x, a.y, a.z, a.w};
+    if (p.bias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.bias + nn);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.rowbias) {
+        const float4 b = *reinterpret_cast<const float4*>(p.rowbias + (long long)(m >> p.lhw) * p.ld_rowbias + nn);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    if (p.residual) {
+        const float4 b = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + nn);
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
+    float4* dst = reinterpret_cast<float4*>(p.y + (long long)m * p.ldy + nn);
+    if (p.accumulate) {
+        const float4 b = *dst;
+        v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w;
+    }
+    *dst = make_float4(v[0], v[1], v[2], v[3]);
 }
 
 // =====================================================================================================================
@@ -584,12 +778,40 @@ static int ilog2x(int v) {
     return l;
 }
 
-// shapes the kernel handles AND fills the chip with: a launch has tiles_m * tiles_n workgroups of one per CU and no
-// split-K, so small layers (8x8 / 4x4 images at CIFAR batch sizes) stay on the split-K igemm
+// shapes the LDS-DMA convolution handles: power-of-two images, whole 32-channel blocks, 128-wide output tiles.
+// Large layers (>= 96 tiles of 256 x 128) run the three-stage 256 x 128 kernel, one workgroup per CU and no K split;
+// small ones (8x8 / 4x4 images at CIFAR batch sizes) the 128 x 128 split-K variant.
 bool conv3x3_ps_supported(int B, int H, int W, int K_channels, int N_channels) {
-    if (!(ilog2x(H) >= 0 && ilog2x(W) >= 0 && K_channels % 32 == 0 && N_channels % PS_BN == 0 && K_channels >= 32)) return false;
-    const long long tiles = cdiv((long long)B * H * W, PS_BM) * (N_channels / PS_BN);
-    return tiles >= 96;
+    return B > 0 && ilog2x(H) >= 0 && ilog2x(W) >= 0 && K_channels % 32 == 0 && N_channels % PS_BN == 0 && K_channels >= 32;
+}
+static bool ps_large(long long M, int N) {
+    static const int force = getenv("BD_PS_TILE") ? atoi(getenv("BD_PS_TILE")) : 0;   // 128 / 256 force a variant (A/B)
+    if (force == 128) return false;
+    if (force == 256) return true;
+    return cdiv(M, PS_BM) * (N / PS_BN) >= 96;
+}
+static void ps_small_split(long long M, int N, int K, int& ksplit, int& cps) {
+    const long long tiles = cdiv(M, 128) * (N / 128);
+    const int nchunks = 9 * (K / 32);
+    static const int slots = [] {
+        int dev = 0, cus = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+        const char* e = getenv("BD_PS_SMALL_SLOTS");
+        return e ? atoi(e) : 2 * cus;
+    }();
+    int ks = (int)(slots / tiles);
+    if (ks < 1) ks = 1;
+    if (ks > nchunks / 4) ks = nchunks / 4;
+    if (ks < 1) ks = 1;
+    cps = (int)cdiv(nchunks, ks);
+    ksplit = (int)cdiv(nchunks, cps);
+}
+size_t conv3x3_ps_workspace_bytes(const bd_conv3x3_ps_desc& d) {
+    const long long M = (long long)d.B * d.H * d.W;
+    if (d.N % PS_BN || ps_large(M, d.N)) return 0;
+    int ks, cps;
+    ps_small_split(M, d.N, d.K, ks, cps);
+    return ks > 1 ? (size_t)ks * (size_t)M * d.N * sizeof(float) : 0;
 }
 
 int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
@@ -602,38 +824,67 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
     BD_CHECK(d.direction == 1 || d.direction == -1, BD_ERR_INVALID, "conv3x3_ps: direction must be +1 or -1");
     const long long M = (long long)d.B * d.H * d.W;
     BD_CHECK(M < (1ll << 31), BD_ERR_UNSUPPORTED, "conv3x3_ps: pixel count overflows int32");
+    BD_CHECK((long long)(d.W + 1) * d.ldx * 4 < (1ll << 31), BD_ERR_UNSUPPORTED, "conv3x3_ps: row pitch too large");
     PsParams p = {};
     p.a = reinterpret_cast<const char*>(d.x_split); p.w = reinterpret_cast<const char*>(d.w_split);
     p.y = d.y; p.bias = d.bias; p.rowbias = d.rowbias; p.residual = d.residual;
     p.lda = d.ldx; p.ldy = d.ldy; p.ldr = d.ldr; p.ld_rowbias = d.ld_rowbias;
     p.C = d.K; p.H = d.H; p.W = d.W; p.lw = ilog2x(d.W); p.lhw = ilog2x(d.W) + ilog2x(d.H);
     p.sign = d.direction; p.M = (int)M; p.N = d.N;
-    p.tiles_m = (int)cdiv(M, PS_BM); p.tiles_n = d.N / PS_BN;
     p.out_scale = d.out_scale == 0.f ? 1.f : d.out_scale; p.accumulate = d.accumulate;
+    const bool large = ps_large(M, d.N);
     int rec = -1;
     if (prof_on()) {
-        rec = prof_begin(d.direction > 0 ? "conv_ps_fwd" : "conv_ps_dgrad", 2.0 * (double)M * d.N * 9.0 * d.K,
-                         ((double)M * d.K + 9.0 * d.K * d.N + (double)M * d.N) * 4.0, st);
+        rec = prof_begin(d.direction > 0 ? (large ? "conv_ps_fwd" : "conv_ps128_fwd") : (large ? "conv_ps_dgrad" : "conv_ps128_dgrad"),
+                         2.0 * (double)M * d.N * 9.0 * d.K, ((double)M * d.K + 9.0 * d.K * d.N + (double)M * d.N) * 4.0, st);
     }
-    BD_CHECK((long long)(d.W + 1) * d.ldx * 4 < (1ll << 31), BD_ERR_UNSUPPORTED, "conv3x3_ps: row pitch too large");
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(PS_NT);
     const int epi = (d.residual ? 1 : 0) | (d.rowbias ? 2 : 0) | (d.accumulate ? 4 : 0);
-    p.ablate = getenv("BD_PS_ABLATE") ? atoi(getenv("BD_PS_ABLATE")) : 0;
-    static const int sched = getenv("BD_PS_SCHED") ? atoi(getenv("BD_PS_SCHED")) : 1;
+    if (large) {
+        p.tiles_m = (int)cdiv(M, PS_BM); p.tiles_n = d.N / PS_BN;
+        const dim3 grid((unsigned)(p.tiles_m * p.tiles_n)), block(PS_NT);
+#ifdef BD_PS_ABLATION
+        p.ablate = getenv("BD_PS_ABLATE") ? atoi(getenv("BD_PS_ABLATE")) : 0;
+#endif
+        static const int sched = getenv("BD_PS_SCHED") ? atoi(getenv("BD_PS_SCHED")) : 0;   // lock step measured equal or better than ping-pong
 #define PS_LAUNCH(E)                                                                              \
     do {                                                                                          \
         if (sched == 0) hipLaunchKernelGGL((conv_ps_kernel<E, 0>), grid, block, 0, st, p);        \
         else hipLaunchKernelGGL((conv_ps_kernel<E, 1>), grid, block, 0, st, p);                   \
     } while (0)
-    switch (epi) {
-        case 0: PS_LAUNCH(0); break;
-        case 1: PS_LAUNCH(1); break;
-        case 2: PS_LAUNCH(2); break;
-        case 4: PS_LAUNCH(4); break;
-        default: PS_LAUNCH(7); break;
-    }
+        switch (epi) {
+            case 0: PS_LAUNCH(0); break;
+            case 1: PS_LAUNCH(1); break;
+            case 2: PS_LAUNCH(2); break;
+            case 4: PS_LAUNCH(4); break;
+            default: PS_LAUNCH(7); break;
+        }
 #undef PS_LAUNCH
-    BD_LAUNCH_CHECK("conv_ps");
+        BD_LAUNCH_CHECK("conv_ps");
+    } else {
+        PsSmallParams pp = {};
+        p.tiles_m = (int)cdiv(M, 128); p.tiles_n = d.N / 128;
+        pp.q = p;
+        ps_small_split(M, d.N, d.K, pp.ksplit, pp.cps);
+        if (pp.ksplit > 1) {
+            const size_t need = (size_t)pp.ksplit * (size_t)M * d.N * sizeof(float);
+            BD_CHECK(d.workspace && d.workspace_bytes >= need, BD_ERR_WORKSPACE, "conv3x3_ps: split-K needs %zu workspace bytes, got %zu", need,
+                     d.workspace_bytes);
+            pp.partial = reinterpret_cast<float*>(d.workspace);
+        }
+        const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * pp.ksplit)), block(512);
+        switch (pp.ksplit > 1 ? 0 : epi) {
+            case 0: hipLaunchKernelGGL(conv_ps128_kernel<0>, grid, block, 0, st, pp); break;
+            case 1: hipLaunchKernelGGL(conv_ps128_kernel<1>, grid, block, 0, st, pp); break;
+            case 2: hipLaunchKernelGGL(conv_ps128_kernel<2>, grid, block, 0, st, pp); break;
+            case 4: hipLaunchKernelGGL(conv_ps128_kernel<4>, grid, block, 0, st, pp); break;
+            default: hipLaunchKernelGGL(conv_ps128_kernel<7>, grid, block, 0, st, pp); break;
+        }
+        BD_LAUNCH_CHECK("conv_ps128");
+        if (pp.ksplit > 1) {
+            hipLaunchKernelGGL(conv_ps128_reduce, dim3((unsigned)cdiv(M * (d.N / 4), 256)), dim3(256), 0, st, pp);
+            BD_LAUNCH_CHECK("conv_ps128_reduce");
+        }
+    }
     prof_end(rec, st);
     return BD_OK;
 }
@@ -702,6 +953,7 @@ int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
 
 }  // namespace bd
 
+extern "C" size_t bd_conv3x3_ps_workspace_bytes(const bd_conv3x3_ps_desc* d) { return d ? bd::conv3x3_ps_workspace_bytes(*d) : 0; }
 extern "C" int bd_conv3x3_ps(const bd_conv3x3_ps_desc* d, bd_stream_t s) {
     BD_CHECK(d, BD_ERR_INVALID, "bd_conv3x3_ps: null descriptor");
     return bd::conv3x3_ps(*d, bd::S(s));

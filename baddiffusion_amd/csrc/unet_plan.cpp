@@ -310,7 +310,8 @@ struct bd_unet {
     }
     static uint16_t* U16(float* p) { return reinterpret_cast<uint16_t*>(p); }
     int conv_p(Ctx& c, bd_conv3x3_ps_desc& d) const {
-        if (c.dry) return BD_OK;
+        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+        if (c.dry) { note_conv(c); return BD_OK; }
         return conv3x3_ps(d, c.st);
     }
     int split_rows(Ctx& c, const float* src, int64_t ld, int64_t nrows, int C, float* dst) const {

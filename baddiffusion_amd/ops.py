@@ -264,6 +264,8 @@ def conv3x3_ps(x_split, w_split, B, H, W, K, N, direction=1, bias=None, rowbias=
                      bias=L.ptr(bias), rowbias=L.ptr(rowbias), ld_rowbias=rowbias.stride(0) if rowbias is not None else 0,
                      residual=L.ptr(residual), ldr=_ld(residual) if residual is not None else 0, out_scale=out_scale,
                      y=L.ptr(y), ldy=_ld(y), accumulate=int(accumulate))
+    ws = workspace(lib.bd_conv3x3_ps_workspace_bytes(C.byref(d)), x_split.device, "ps")
+    d.workspace = L.ptr(ws); d.workspace_bytes = ws.numel()
     L.check(lib.bd_conv3x3_ps(C.byref(d), L.stream()), "bd_conv3x3_ps")
     return y
 

@@ -282,7 +282,9 @@ typedef struct {
     const float* residual; int64_t ldr;
     float out_scale;                /* y = out_scale * (conv + bias + rowbias + residual)            */
     float* y; int64_t ldy; int accumulate;
+    void* workspace; size_t workspace_bytes;   /* >= bd_conv3x3_ps_workspace_bytes(): K-split slabs of the small-layer variant */
 } bd_conv3x3_ps_desc;
+size_t bd_conv3x3_ps_workspace_bytes(const bd_conv3x3_ps_desc* d);
 int bd_conv3x3_ps(const bd_conv3x3_ps_desc* d, bd_stream_t stream);
 /* weight (and bias) gradient of the same convolution, both operands as split planes:
  *   dw[Cout][3][3][Cin] = sum_p dy[p][co] x[p + tap][ci],  db[Cout] = sum_p dy[p][co] (optional, same launch).
