@@ -199,14 +199,20 @@ def _dist():
     local = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        local = local % max(1, torch.cuda.device_count())   # BD_DIST_BACKEND=gloo: several ranks may share one GPU (functional tests)
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        backend = os.environ.get("BD_DIST_BACKEND", "nccl")
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local))
+        else:
+            dist.init_process_group(backend)
     return world, rank, local
 
 
 def get_data_loader(config, device):
+    n_img = int(os.environ["BD_NUM_IMAGES"]) if os.environ.get("BD_NUM_IMAGES") else None   # synthetic-dataset size (tests)
     dsl = DatasetLoader(root=config.dataset_path if os.path.isdir(config.dataset_path) else None, name=config.dataset,
-                        batch_size=config.batch, seed=config.seed, device=device)
+                        batch_size=config.batch, seed=config.seed, device=device, num_images=n_img)
     dsl.set_poison(trigger_type=config.trigger, target_type=config.target, clean_rate=config.clean_rate,
                    poison_rate=config.poison_rate).prepare_dataset(mode=config.dataset_load_mode)
     print(f"datasetloader len: {len(dsl)} ({dsl.source})")
@@ -286,7 +292,10 @@ def measure(config, dsl, folder_name, pipeline, rank=0, world=1):
     MSE / SSIM to the target are computed on the device from the written PNGs like the reference; FID needs
     pytorch_fid's Inception weights, absent here -> reported as null (statistics + Frechet distance: baddiffusion_amd/metrics.py)."""
     from baddiffusion_amd.model import batch_sampling_save
-    rng = torch.Generator().manual_seed(config.seed)
+    # per-step DDPM noise: one stream per rank (seed + rank).  With a shared seed every shard would consume the SAME
+    # noise sequence and chain j of each shard would be correlated with chain j of the others.  world == 1 keeps the
+    # reference's stream exactly; a sharded run is a different (equally valid) draw of the same distribution.
+    rng = torch.Generator().manual_seed(config.seed + rank)
     parts = [config.output_dir, folder_name] + ([f"ep{config.sample_ep}"] if config.sample_ep is not None else [])
     suffix = "_noclip" if not config.clip else ""
     clean_path, backdoor_path = os.path.join(*parts, "clean" + suffix), os.path.join(*parts, "backdoor" + suffix)
@@ -342,6 +351,7 @@ def train_loop(config, model, noise_sched, get_pipeline, dsl, device, world, ran
     if config.mode == MODE_RESUME and os.path.exists(opt_file):
         st = torch.load(opt_file, map_location="cpu")
         engine.m.copy_(st["m"]); engine.v.copy_(st["v"]); engine.opt_step = st["opt_step"]; engine.micro = st["micro"]
+        engine.sync_state()
     dsl.to_device(device)
     trigger, target = dsl.trigger.to(device), dsl.target.to(device)
     log = open(os.path.join(config.output_dir, "log.jsonl"), "a") if rank == 0 else None
@@ -350,11 +360,11 @@ def train_loop(config, model, noise_sched, get_pipeline, dsl, device, world, ran
     try:
         for epoch in range(int(start_epoch), int(config.epoch)):
             t0 = time.time()
-            for step, (imgs, pois) in enumerate(dsl.device_batches(shuffle=True, epoch=epoch, rank=rank, world=world)):
-                bs = imgs.shape[0]
+            for step, (rows, flips, pois) in enumerate(dsl.device_batch_rows(shuffle=True, epoch=epoch, rank=rank, world=world)):
+                bs = rows.shape[0]
                 noise = torch.randn((bs, dsl.channel, dsl.image_size, dsl.image_size), device=device)       # :596
                 timesteps = torch.randint(0, noise_sched.config.num_train_timesteps, (bs,), device=device).long()   # :600
-                loss = engine.train_step(imgs, pois, trigger, target, noise, timesteps)
+                loss = engine.train_step(dsl.device_images, pois, trigger, target, noise, timesteps, row_index=rows, flip=flips)
                 cur_step += 1
                 if log is not None and step % 50 == 0:
                     rec = {"loss": float(loss), "lr": engine.current_lr(), "epoch": epoch, "step": cur_step}
@@ -388,6 +398,9 @@ def main(argv=None):
     dsl = get_data_loader(config, device)
     config.image_size, config.channel = dsl.image_size, dsl.channel
     model, noise_sched, get_pipeline = get_model_sched(config, device)
+    config.pretrained = bool(getattr(model, "pretrained", True))   # False: topology built with default init (BD_ALLOW_RANDOM_INIT)
+    if rank == 0 and config.mode in (MODE_TRAIN, MODE_TRAIN_MEASURE) and os.path.isdir(config.output_dir):
+        _write_json(config.__dict__, config, "config.json")
     if config.mode in (MODE_TRAIN, MODE_RESUME, MODE_TRAIN_MEASURE):
         start_epoch = start_step = 0
         if config.mode == MODE_RESUME and os.path.exists(config.data_ckpt_path):

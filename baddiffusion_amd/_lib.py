@@ -19,7 +19,7 @@ class PoisonQsampleDesc(C.Structure):
                 ("images_f32", vp), ("images_u8", vp), ("is_poison", vp), ("trigger", vp), ("target_img", vp),
                 ("noise", vp), ("timesteps", vp), ("alphas", vp), ("alphas_cumprod", vp), ("vmin", f32),
                 ("x_noisy", vp), ("ld_noisy", i64), ("target", vp), ("ld_target", i64),
-                ("R_out", vp), ("x0_out", vp), ("mask_out", vp), ("image_out", vp)]
+                ("R_out", vp), ("x0_out", vp), ("mask_out", vp), ("image_out", vp), ("row_index", vp), ("flip", vp)]
 
 
 class QsampleDesc(C.Structure):

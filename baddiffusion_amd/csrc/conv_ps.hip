@@ -578,7 +578,7 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad_kernel(PsWgParams p) {
     const int co0 = tm * WG_BM, n0 = tn * WG_BN;
     const int tap = n0 / p.Cin, ci0 = n0 - tap * p.Cin;
     const int dyt = tap / 3 - 1, dxt = tap - (tap / 3) * 3 - 1;
-    const int nchunks = p.P >> 5;
+    const int nchunks = (p.P + 31) >> 5;   // a ragged last chunk reads zeros past the last pixel
     const int c_begin = zz * p.cps;
     int c_end = c_begin + p.cps;
     if (c_end > nchunks) c_end = nchunks;
@@ -603,8 +603,9 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad_kernel(PsWgParams p) {
         for (int j = 0; j < 2; ++j) {
             const int pp = q_pix + kpix[j];
             const int x = pp & (p.W - 1), y = (pp >> p.lw) & (p.H - 1);
-            const bool ok = (unsigned)(y + dyt) < (unsigned)p.H && (unsigned)(x + dxt) < (unsigned)p.W;
-            ps_dma16(asrc[j], stage + (wave + 8 * j) * 1024);
+            const bool in = pp < p.P;
+            const bool ok = in && (unsigned)(y + dyt) < (unsigned)p.H && (unsigned)(x + dxt) < (unsigned)p.W;
+            ps_dma16(in ? asrc[j] : reinterpret_cast<const char*>(kPsZero), stage + (wave + 8 * j) * 1024);
             ps_dma16(ok ? bsrc[j] : reinterpret_cast<const char*>(kPsZero), stage + WG_OP_BYTES + (wave + 8 * j) * 1024);
             asrc[j] += a_adv; bsrc[j] += b_adv;
         }
@@ -890,11 +891,11 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
 }
 
 bool conv3x3_ps_wgrad_supported(int B, int H, int W, int Cin, int Cout) {
-    return ilog2x(H) >= 0 && ilog2x(W) >= 0 && Cin % WG_BN == 0 && Cout % WG_BM == 0 && ((long long)B * H * W) % 32 == 0;
+    return B > 0 && ilog2x(H) >= 0 && ilog2x(W) >= 0 && Cin % WG_BN == 0 && Cout % WG_BM == 0;
 }
 static void ps_wgrad_split(const bd_conv3x3_ps_wgrad_desc& d, int& ksplit, int& cps) {
     const long long tiles = (long long)(d.Cout / WG_BM) * (9 * d.Cin / WG_BN);
-    const int nchunks = (int)((long long)d.B * d.H * d.W / 32);
+    const int nchunks = (int)cdiv((long long)d.B * d.H * d.W, 32);
     static const int slots = [] {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
@@ -915,7 +916,7 @@ size_t conv3x3_ps_wgrad_workspace_bytes(const bd_conv3x3_ps_wgrad_desc& d) {
 int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
     BD_CHECK(d.x_split && d.dy_split && d.dw, BD_ERR_INVALID, "conv3x3_ps_wgrad: null pointer");
     BD_CHECK(d.B > 0 && conv3x3_ps_wgrad_supported(d.B, d.H, d.W, d.Cin, d.Cout), BD_ERR_UNSUPPORTED,
-             "conv3x3_ps_wgrad: needs power-of-two H, W, Cin and Cout multiples of 128, B*H*W %% 32 == 0");
+             "conv3x3_ps_wgrad: needs power-of-two H, W, Cin and Cout multiples of 128");
     BD_CHECK(d.ldx % 32 == 0 && d.lddy % 32 == 0 && ((uintptr_t)d.x_split & 127) == 0 && ((uintptr_t)d.dy_split & 127) == 0,
              BD_ERR_UNSUPPORTED, "conv3x3_ps_wgrad: split planes need ld %% 32 == 0 and 128-byte aligned bases");
     PsWgParams p = {};

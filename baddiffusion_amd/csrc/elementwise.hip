@@ -43,15 +43,23 @@ __global__ __launch_bounds__(TPB) void poison_qsample_kernel(bd_poison_qsample_d
     const float s = sqrtf(1.0f - ac);                // (1 - alphas_cumprod[t]) ** 0.5
     const float rho = (1.0f - sqrtf(al)) * s / (1.0f - al);   // loss.py:270
     const bool poison = d.is_poison[b] != 0;
+    // fused DataLoader gather + RandomHorizontalFlip (dataset.py:127-128): batch row b reads image row_index[b] of the
+    // resident array, mirrored along W when flip[b]
+    const int64_t sb = d.row_index ? d.row_index[b] : b;
+    int64_t spix = pix;
+    if (d.flip && d.flip[b]) {
+        const int64_t y = pix / d.W;
+        spix = y * d.W + (d.W - 1 - (pix - y * d.W));
+    }
     for (int c = 0; c < d.C; ++c) {
         const int64_t chw = (int64_t)c * hw + pix;
         float x;
         if (d.images_u8) {
             // ToTensor (/255) then normalize(0,1 -> -1,1, eps=1e-5): ((x-0)/(1-0+eps))*(2)+(-1)
-            float u = (float)d.images_u8[((int64_t)b * hw + pix) * d.C + c] / 255.0f;
+            float u = (float)d.images_u8[(sb * hw + spix) * d.C + c] / 255.0f;
             x = (u / (1.0f + 1e-5f)) * 2.0f + -1.0f;
         } else {
-            x = d.images_f32[(int64_t)b * d.C * hw + chw];
+            x = d.images_f32[sb * d.C * hw + (int64_t)c * hw + spix];
         }
         const float g = d.trigger[chw];
         const float m = g > d.vmin ? 0.0f : 1.0f;                     // get_mask

@@ -198,6 +198,7 @@ class DatasetLoader:
         if name not in self._SIZES:
             raise NotImplementedError(f"Undefined dataset: {name}")
         self._root, self._name, self._batch_size, self._seed = root, name, batch_size, seed
+        self._label, self._subset = label, None
         c, s, n = self._SIZES[name]
         self._channel = channel or c
         self._image_size = image_size or s
@@ -237,15 +238,39 @@ class DatasetLoader:
         return self
 
     def prepare_dataset(self, mode: str = "FIXED"):
-        """FIXED mode (dataset.py:162-201): backdoor_n = int(N * poison_rate) samples become backdoor samples.
+        """FIXED (dataset.py:162-201): backdoor_n = int(N * poison_rate) of the N samples become backdoor samples,
+        clean_rate is ignored.  FLEX (dataset.py:225-243): train_n = int(N * clean_rate) clean samples PLUS
+        test_n = int(N * poison_rate) backdoor samples, disjoint, so the training set has train_n + test_n rows.
         The reference picks them with an UNSEEDED train_test_split (SURVEY D-5); here the choice is a seeded
-        permutation so runs are reproducible."""
+        permutation so runs are reproducible.  The class filter (`label`, dataset.py:247-248) needs real labels."""
+        if self._label is not None:
+            if bool((self._labels < 0).all()):
+                raise NotImplementedError("DatasetLoader(label=...) needs a dataset with labels (synthetic / label-free arrays have none)")
+            keep = torch.isin(self._labels.long(), torch.as_tensor(list(self._label) if hasattr(self._label, "__iter__") else [self._label]))
+            self._images, self._labels = self._images[keep], self._labels[keep]
         n = len(self._images)
-        backdoor_n = int(n * float(self._poison_rate))
         perm = torch.randperm(n, generator=torch.Generator().manual_seed(self._seed))
         self._is_poison = torch.zeros(n, dtype=torch.bool)
-        self._is_poison[perm[:backdoor_n]] = True
+        if mode == self.MODE_FIXED:
+            if float(self._poison_rate) < 0 or float(self._poison_rate) > 1:
+                raise ValueError(f"In {self.MODE_FIXED}, poison rate should <= 1.0 and >= 0.0")
+            backdoor_n = int(n * float(self._poison_rate))
+            self._is_poison[perm[:backdoor_n]] = True
+            self._subset = None
+        elif mode == self.MODE_FLEX:
+            train_n, test_n = int(n * float(self._clean_rate)), int(n * float(self._poison_rate))
+            if train_n + test_n > n:
+                raise ValueError(f"In {self.MODE_FLEX}, clean_rate + poison_rate must be <= 1 (train_test_split of one dataset)")
+            self._is_poison[perm[train_n: train_n + test_n]] = True
+            self._subset = perm[: train_n + test_n].sort().values      # the rows that take part in training
+        else:
+            raise NotImplementedError(f"Argument mode: {mode} isn't defined")
+        self._dev_images = None
         return self
+
+    def _rows(self):
+        """indices (into the resident image array) of the prepared dataset"""
+        return torch.arange(len(self._images)) if getattr(self, "_subset", None) is None else self._subset
 
     # ---- device-resident batches (the product path) --------------------------------------------------------
     def to_device(self, device=None):
@@ -257,19 +282,52 @@ class DatasetLoader:
         self._dev_target = self._target.to(device)
         return self
 
-    def device_batches(self, shuffle=True, epoch=0, rank=0, world=1, flip=True):
-        """Yield (images_u8 [B,H,W,C], is_poison [B]) already on the device; rank r takes every world-th batch row."""
+    def device_batch_rows(self, shuffle=True, epoch=0, rank=0, world=1, flip=True):
+        """The product path: yield (rows int64 [B], flip uint8 [B] or None, is_poison [B]) on the device -- row numbers
+        into the HBM-resident uint8 array (`self.device_images`) for the fused gather + flip + normalize + blend +
+        q_sample kernel (bd_poison_qsample row_index / flip); no image bytes move before that kernel.  Same
+        permutation, rank slicing and flip draws as device_batches()."""
         if self._dev_images is None:
             self.to_device()
-        n = len(self._dev_images)
+        rows = self._rows()
+        n = len(rows)
         g = torch.Generator().manual_seed(self._seed * 100003 + epoch)
-        idx = torch.randperm(n, generator=g) if shuffle else torch.arange(n)
+        idx = rows[torch.randperm(n, generator=g)] if shuffle else rows
         gb = self._batch_size * world
         for s in range(0, n, gb):
-            sel = idx[s + rank: s + gb: world].to(self._device)
+            chunk = idx[s: s + gb]
+            if world > 1 and len(chunk) % world:
+                chunk = torch.cat([chunk, idx[: world - len(chunk) % world]])
+            sel = chunk[rank::world].to(self._device)
+            f = (torch.rand(len(chunk), generator=g)[rank::world] < 0.5).to(torch.uint8).to(self._device) if flip else None
+            yield sel, f, self._dev_poison[sel]
+
+    @property
+    def device_images(self):
+        if self._dev_images is None:
+            self.to_device()
+        return self._dev_images
+
+    def device_batches(self, shuffle=True, epoch=0, rank=0, world=1, flip=True):
+        """Yield (images_u8 [B,H,W,C], is_poison [B]) already on the device; rank r takes every world-th row of each
+        global batch.  Every rank gets the SAME number of rows in every step (the last, partial global batch is
+        wrap-padded with rows from the start of the permutation, like DistributedSampler): unequal or empty per-rank
+        batches would mis-weight the 1/world gradient mean or hang the all-reduce."""
+        if self._dev_images is None:
+            self.to_device()
+        rows = self._rows()
+        n = len(rows)
+        g = torch.Generator().manual_seed(self._seed * 100003 + epoch)
+        idx = rows[torch.randperm(n, generator=g)] if shuffle else rows
+        gb = self._batch_size * world
+        for s in range(0, n, gb):
+            chunk = idx[s: s + gb]
+            if world > 1 and len(chunk) % world:
+                chunk = torch.cat([chunk, idx[: world - len(chunk) % world]])
+            sel = chunk[rank::world].to(self._device)
             img = self._dev_images[sel]
             if flip:   # RandomHorizontalFlip(p=0.5) (dataset.py:127-128), on the device
-                f = torch.rand(len(sel), generator=g) < 0.5
+                f = torch.rand(len(chunk), generator=g)[rank::world] < 0.5
                 img = torch.where(f.to(self._device)[:, None, None, None], img.flip(2), img)
             yield img, self._dev_poison[sel]
 
@@ -290,8 +348,9 @@ class DatasetLoader:
         dev = self._device
         if dev.type != "cuda":
             raise RuntimeError("DatasetLoader.get_dataloader needs a GPU: the per-sample transforms run in libbd_hip.so")
-        n = len(self._images)
-        idx = torch.randperm(n, generator=torch.Generator().manual_seed(self._seed)) if shuffle else torch.arange(n)
+        rows = self._rows()
+        n = len(rows)
+        idx = rows[torch.randperm(n, generator=torch.Generator().manual_seed(self._seed))] if shuffle else rows
         a = torch.ones(1, device=dev) * 0.5
         for s in range(0, n, self._batch_size):
             sel = idx[s: s + self._batch_size].to(dev)
@@ -309,9 +368,10 @@ class DatasetLoader:
         return self
 
     def __len__(self):
-        return len(self._images)
+        return len(self._rows())
 
     def __getitem__(self, i):
+        i = int(self._rows()[i])
         img = self._transform(self._images[i: i + 1])[0]
         return {self.IMAGE: img, self.LABEL: self._labels[i], self.IS_CLEAN: not bool(self._is_poison[i])}
 

@@ -193,7 +193,7 @@ class DiffuserModelSched:
         return get_pipeline
 
     @staticmethod
-    def _get_model_sched(ckpt_id: str, clip_sample: bool, noise_sched_type: str = None):
+    def _get_model_sched(ckpt_id: str, clip_sample: bool, noise_sched_type: str = None, allow_random_init: bool = False):
         # model.py:577-643
         clip_used = DiffuserModelSched.get_sample_clip(clip_sample, DiffuserModelSched.CLIP_SAMPLE_DEFAULT)
         local = _resolve_local(ckpt_id)
@@ -202,8 +202,15 @@ class DiffuserModelSched:
             ckpt_sched = load_scheduler(os.path.join(local, "scheduler")) if os.path.isdir(os.path.join(local, "scheduler")) \
                 else DDPMScheduler()
         elif ckpt_id in KNOWN_TOPOLOGIES:
+            # The reference fails in from_pretrained when the weights are missing; fine-tuning a backdoor from a
+            # random network with the fine-tune LR is a different experiment, so it needs an explicit opt-in.
+            if not (allow_random_init or os.environ.get("BD_ALLOW_RANDOM_INIT", "0") == "1"):
+                raise FileNotFoundError(
+                    f"pretrained weights for '{ckpt_id}' are not available locally (put the diffusers-layout checkpoint "
+                    f"under $BD_CKPT_ROOT).  Set BD_ALLOW_RANDOM_INIT=1 to build the documented topology with default "
+                    f"initialisation instead (recorded as pretrained=False).")
             print(f"[baddiffusion_amd] weights for '{ckpt_id}' are not available locally (set BD_CKPT_ROOT): "
-                  f"building the documented topology with default initialisation")
+                  f"building the documented topology with default initialisation (BD_ALLOW_RANDOM_INIT)")
             model = UNet2DModel(**KNOWN_TOPOLOGIES[ckpt_id])
             model.pretrained = False
             ckpt_sched = DDPMScheduler(**KNOWN_SCHEDULERS.get(ckpt_id, {}))
@@ -250,15 +257,18 @@ class DiffuserModelSched:
                  DiffuserModelSched.LDM_CELEBA_HQ_DEFAULT: DiffuserModelSched.LDM_CELEBA_HQ_256}
         if model_type not in table:
             raise NotImplementedError()
-        model, noise_sched, get_pipeline = DiffuserModelSched.get_pretrained(ckpt=table[model_type], noise_sched_type=noise_sched_type,
-                                                                             clip_sample=clip_sample)
-        model.reset_parameters()      # model.apply(weight_reset), model.py:647-652
+        # topology only: the weights are re-initialised right below (model.apply(weight_reset), model.py:647-652)
+        model, noise_sched, get_pipeline = DiffuserModelSched._get_model_sched(
+            ckpt_id=DiffuserModelSched._HUB.get(table[model_type], table[model_type]), clip_sample=clip_sample,
+            noise_sched_type=noise_sched_type, allow_random_init=True)
+        model.reset_parameters()
         return model, noise_sched, get_pipeline
 
     @staticmethod
-    def get_pretrained(ckpt: str, clip_sample: bool = None, noise_sched_type: str = None):
+    def get_pretrained(ckpt: str, clip_sample: bool = None, noise_sched_type: str = None, allow_random_init: bool = False):
         ckpt = DiffuserModelSched._HUB.get(ckpt, ckpt)
-        return DiffuserModelSched._get_model_sched(ckpt_id=ckpt, clip_sample=clip_sample, noise_sched_type=noise_sched_type)
+        return DiffuserModelSched._get_model_sched(ckpt_id=ckpt, clip_sample=clip_sample, noise_sched_type=noise_sched_type,
+                                                   allow_random_init=allow_random_init)
 
     @staticmethod
     def get_trained(ckpt: str, clip_sample: bool = None, noise_sched_type: str = None):

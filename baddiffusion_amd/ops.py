@@ -37,16 +37,25 @@ def _ld(t):
 
 # ------------------------------------------------------------------------------------------------ a-1/a-2
 def poison_qsample(images, is_poison, trigger, target_img, noise, timesteps, alphas, alphas_cumprod,
-                   vmin=-1.0, want_batch=False, want_mask=False, want_image=False):
+                   vmin=-1.0, want_batch=False, want_mask=False, want_image=False, row_index=None, flip=None):
     """Fused blend + q_sample.  images: float [B,C,H,W] (normalised) or uint8 [B,H,W,C].
+    row_index (int64 [B]): batch row b reads images[row_index[b]] (images is then the whole resident array);
+    flip (bool/uint8 [B]): mirror that image along W.  Both optional: the shuffled gather and
+    RandomHorizontalFlip of the reference's DataLoader, fused into the kernel.
     Returns (x_noisy NHWC [B,H,W,C], target NHWC [B,H,W,C][, R NCHW, x0 NCHW][, mask int64 [C,H,W]])."""
     lib = L.load()
-    _need_cuda(images, is_poison, trigger, target_img, noise, timesteps, alphas, alphas_cumprod)
+    _need_cuda(images, is_poison, trigger, target_img, noise, timesteps, alphas, alphas_cumprod, row_index, flip)
     u8 = images.dtype == torch.uint8
     if u8:
         B, H, W, Cc = images.shape
     else:
         B, Cc, H, W = images.shape
+    if row_index is not None:
+        row_index = row_index.to(torch.int64).contiguous()
+        B = row_index.numel()
+    if flip is not None:
+        flip = flip.to(torch.uint8).contiguous()
+        assert flip.numel() == B
     dev = images.device
     images = images.contiguous(); noise = noise.contiguous()
     is_poison = is_poison.to(torch.uint8).contiguous()
@@ -62,7 +71,8 @@ def poison_qsample(images, is_poison, trigger, target_img, noise, timesteps, alp
                             trigger=L.ptr(trigger), target_img=L.ptr(target_img), noise=L.ptr(noise),
                             timesteps=L.ptr(timesteps), alphas=L.ptr(alphas), alphas_cumprod=L.ptr(alphas_cumprod),
                             vmin=vmin, x_noisy=L.ptr(xn), ld_noisy=Cc, target=L.ptr(tg), ld_target=Cc,
-                            R_out=L.ptr(R), x0_out=L.ptr(x0), mask_out=L.ptr(mask), image_out=L.ptr(image))
+                            R_out=L.ptr(R), x0_out=L.ptr(x0), mask_out=L.ptr(mask), image_out=L.ptr(image),
+                            row_index=L.ptr(row_index), flip=L.ptr(flip))
     L.check(lib.bd_poison_qsample(C.byref(d), L.stream()), "bd_poison_qsample")
     out = [xn, tg]
     if want_batch:

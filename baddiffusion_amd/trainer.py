@@ -84,6 +84,15 @@ class TrainEngine:
         self._lib = L.load()
         self._nseg = self._lib.bd_unet_num_segments(model._plan)
         self.alphas, self.alphas_cumprod = noise_sched.device_tables(dev)
+        self.sync_state()
+
+    def sync_state(self):
+        """Make every rank start from rank 0's parameters and Adam moments (replicas only ever exchange gradients:
+        without this, ranks that initialised or resumed differently would apply the averaged gradient at different
+        points and drift apart).  Call again after loading optimizer state on a resume."""
+        if self.world > 1:
+            for t in (self.model.flat.data, self.m, self.v):
+                dist.broadcast(t, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
 
     # ---- LR schedule (host scalar; baddiffusion.py:327-331) ------------------------------------------
     def current_lr(self):
@@ -122,11 +131,13 @@ class TrainEngine:
                       self.betas, self.eps, grad_norm_out=self.grad_norm)
 
     # ---- the train step -----------------------------------------------------------------------------------
-    def train_step(self, images, is_poison, trigger, target_img, noise, timesteps):
+    def train_step(self, images, is_poison, trigger, target_img, noise, timesteps, row_index=None, flip=None):
         """images: uint8 [B,H,W,C] or float [B,C,H,W] on the GPU; is_poison bool [B]; trigger/target [C,H,W];
-        noise [B,C,H,W]; timesteps int64 [B].  Returns the (local) loss as a device scalar."""
+        noise [B,C,H,W]; timesteps int64 [B].  With row_index (int64 [B]) `images` is the whole HBM-resident dataset
+        and the shuffled gather (and, with flip [B], the random horizontal flip) happens inside the fused kernel.
+        Returns the (local) loss as a device scalar."""
         xn, tg = ops.poison_qsample(images, is_poison, trigger, target_img, noise, timesteps, self.alphas,
-                                    self.alphas_cumprod)
+                                    self.alphas_cumprod, row_index=row_index, flip=flip)
         return self.step_from_noisy(xn, tg, timesteps)
 
     def train_step_batch(self, x_start, R, noise, timesteps):

@@ -64,6 +64,9 @@ typedef struct {
     float* x0_out;                /* optional NCHW [B,C,H,W] (target), may be NULL            */
     int64_t* mask_out;            /* optional [C,H,W] int64 mask (bit-exact check), may be NULL */
     float* image_out;             /* optional NCHW [B,C,H,W] normalised image x, may be NULL  */
+    const int64_t* row_index;     /* optional [B]: batch row b reads image row_index[b] of the (larger, HBM-resident)
+                                     image array -- the DataLoader's shuffled gather, fused; NULL = row b          */
+    const uint8_t* flip;          /* optional [B]: 1 = mirror the image along W (RandomHorizontalFlip, dataset.py:127) */
 } bd_poison_qsample_desc;
 int bd_poison_qsample(const bd_poison_qsample_desc* d, bd_stream_t stream);
 

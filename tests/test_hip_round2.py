@@ -1,0 +1,407 @@
+"""GPU parity, round 2: the entry points and configurations the round-1 review found untested.
+
+  * TrainEngine.train_step (the function bench.py and the CLI time): uint8 images -> fused gather / flip / normalize /
+    blend / q_sample -> step, against oracle.train_ref at B = 8 and against train_step_batch at the full B = 128;
+  * the per-GPU shares of BASELINE configs[3] (256x256 net, batch 4) and configs[4] (CIFAR topology, 256 DDIM-50 chains);
+  * 4 samples of the B = 128 forward against the oracle;
+  * bd_adam_clip_dev (device-resident step scalars) against bd_adam_clip;
+  * the fused row gather + horizontal flip of bd_poison_qsample against torch indexing / flip;
+  * the LDS-DMA convolution family on split planes (bd_conv3x3_ps, bd_conv3x3_ps_wgrad, bd_split_rows, bd_split_wt,
+    GroupNorm's split outputs) against the fp32 igemm path;
+  * two ranks (gloo, sharing the one GPU): divergent initial weights are made equal, the CIFAR-topology step equals the
+    one-process global batch, bench.py --gpus 2 and the CLI train loop run end to end.
+Tolerance: 1e-3 relative fp32 (BASELINE.json north_star) unless a tighter one is stated; index / mask data bit-exact."""
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import backdoor_ref as BD
+from oracle import sched_ref, train_ref
+from oracle import unet_ref as U
+from tests.golden import cases as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def relerr(a, b):
+    a = a.detach().cpu().double(); b = b.detach().cpu().double()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def make_model(cfg, seed, dev):
+    from baddiffusion_amd.unet import unet_from_config
+    m = unet_from_config(cfg).to(dev)
+    m.load_state_dict(U.gen_params(cfg, seed))
+    return m
+
+
+def _u8_batch(B, S, seed):
+    return torch.randint(0, 256, (B, S, S, 3), generator=torch.Generator().manual_seed(seed), dtype=torch.uint8)
+
+
+# ------------------------------------------------------------------------------------------------ 1(a)
+def test_train_engine_uint8_step_vs_oracle(gpu):
+    """TrainEngine.train_step on raw uint8 rows (BOX_14 trigger, CORNER target, 1 of 8 rows poisoned) on the
+    DDPM-CIFAR10-32 topology: loss, clipped-gradient norm and the post-Adam weights against oracle.train_ref
+    (reference: baddiffusion.py:590-615, dataset.py:288-315, loss.py:257-307)."""
+    from baddiffusion_amd.dataset import Backdoor
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    cfg = U.CIFAR10_32
+    B, S = 8, 32
+    u8 = _u8_batch(B, S, 11)
+    pois = torch.zeros(B, dtype=torch.bool); pois[3] = True
+    bd = Backdoor(root=None)
+    trig = bd.get_trigger("BOX_14", 3, S); tgt = bd.get_target("CORNER", trig)
+    assert torch.equal(trig, BD.get_trigger("BOX_14", 3, S)) and torch.equal(tgt, BD.get_target("CORNER", BD.get_trigger("BOX_14", 3, S)))
+    eps = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(12))
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(13))
+    m = make_model(cfg, 0, gpu)
+    eng = TrainEngine(m, DDPMScheduler(), lr=2e-4)
+    loss = eng.train_step(u8.cuda(), pois.cuda(), trig.cuda(), tgt.cuda(), eps.cuda(), t.cuda())
+    # oracle
+    _, a, ac = sched_ref.make_tables()
+    x = torch.stack([BD.image_u8_to_float(u8[i]) for i in range(B)])
+    R, x0 = BD.make_batch(x, pois, trig, tgt)
+    P = U.gen_params(cfg, 0)
+    ref_loss, G = train_ref.loss_and_grads(cfg, P, a, ac, x0, R, t, eps)
+    newP, _, norm = train_ref.clip_and_adam(P, G, {}, 2e-4, 1)
+    assert abs(float(loss) - float(ref_loss)) < 1e-4 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+    assert abs(float(eng.grad_norm) - float(norm)) < 1e-3 * float(norm)
+    sd = m.state_dict()
+    diffs = torch.cat([(sd[k].cpu() - newP[k]).abs().flatten() for k in newP if not k.endswith("key.bias")])
+    # Adam's first update is ~lr * sign(g): single elements whose gradient is rounding noise may flip (2 lr); the bulk agrees
+    assert float(diffs.max()) <= 2.2 * 2e-4 and float((diffs > 5e-5).float().mean()) < 1e-3 and float(diffs.mean()) < 2e-6
+
+
+def test_train_engine_uint8_step_full_batch_equals_collated_step(gpu):
+    """BASELINE configs[1] at full size (B = 128, poison 0.1): the fused uint8 entry point == the reference calling
+    convention (collated x_start / R batches, train_step_batch) on the same rows -- same kernels after q_sample."""
+    from baddiffusion_amd import ops
+    from baddiffusion_amd.dataset import Backdoor
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    cfg = U.CIFAR10_32
+    B, S = 128, 32
+    u8 = _u8_batch(B, S, 21).cuda()
+    pois = (torch.arange(B) % 10 == 0).cuda()
+    bd = Backdoor(root=None)
+    trig = bd.get_trigger("BOX_14", 3, S).cuda(); tgt = bd.get_target("CORNER", trig.cpu()).cuda()
+    eps = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(22)).cuda()
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(23)).cuda()
+    m1, m2 = make_model(cfg, 0, gpu), make_model(cfg, 0, gpu)
+    e1, e2 = TrainEngine(m1, DDPMScheduler(), lr=2e-4), TrainEngine(m2, DDPMScheduler(), lr=2e-4)
+    l1 = e1.train_step(u8, pois, trig, tgt, eps, t)
+    _, _, R, x0 = ops.poison_qsample(u8, pois, trig, tgt, eps, t, e2.alphas, e2.alphas_cumprod, want_batch=True)
+    l2 = e2.train_step_batch(x0, R, eps, t)
+    assert torch.isfinite(l1) and abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l2))
+    assert abs(float(e1.grad_norm) - float(e2.grad_norm)) <= 1e-5 * float(e2.grad_norm)
+    assert relerr(m1.flat, m2.flat) < 1e-6
+
+
+# ------------------------------------------------------------------------------------------------ 1(b)
+def test_celeba256_batch4_train_step(gpu):
+    """per-GPU share of BASELINE configs[3]: DDPM-CELEBA-HQ-256 network, batch 4 (32 global / 8 GPUs), one train step:
+    finite, split-bf16 == exact-fp32 contraction, and sample i of the batch == the same sample run alone."""
+    cfg = U.CELEBA_HQ_256
+    m = make_model(cfg, 5, gpu)
+    B = 4
+    x = torch.randn(B, 3, 256, 256, generator=torch.Generator().manual_seed(3)).cuda()
+    t = torch.tensor([417, 3, 999, 500]).cuda()
+    dout = torch.randn(B, 3, 256, 256, generator=torch.Generator().manual_seed(4)).cuda() / (B * 3 * 65536)
+    res = {}
+    for mode in ("f32", "bf16x3"):
+        m.set_compute_mode(mode)
+        m.flat.grad = None
+        out = m(x, t, return_dict=False)[0]
+        out.backward(dout)
+        assert torch.isfinite(out).all() and torch.isfinite(m.flat.grad).all()
+        res[mode] = (out.detach().clone(), m.flat.grad.detach().clone())
+    assert relerr(res["bf16x3"][0], res["f32"][0]) < 1e-4
+    assert relerr(res["bf16x3"][1], res["f32"][1]) < 1e-3
+    with torch.no_grad():
+        alone = m(x[2:3], t[2:3], return_dict=False)[0]
+    assert relerr(alone, res["bf16x3"][0][2:3]) < 5e-5
+
+
+# ------------------------------------------------------------------------------------------------ 1(c)
+def test_cifar_ddim50_share_of_sampling_config(gpu, tmp_path):
+    """per-GPU share of BASELINE configs[4]: CIFAR topology, 256 chains (2048 / 8 GPUs), DDIM 50 steps.  The first two
+    steps of 4 chains against the oracle (pipeline_ddim.py:114-121, scheduling_ddim.py:261-381), the full loop finite
+    and in [0,1], chunked == unchunked, and batch_sampling_save(rank, world=8) writes exactly this rank's index range."""
+    from baddiffusion_amd.model import batch_sampling, batch_sampling_save
+    from baddiffusion_amd.pipelines import DDIMPipeline
+    from baddiffusion_amd.schedulers import DDIMScheduler
+    cfg = U.CIFAR10_32
+    m = make_model(cfg, 0, gpu)
+    P = U.gen_params(cfg, 0)
+    _, a, ac = sched_ref.make_tables()
+    sch = DDIMScheduler(clip_sample=False)
+    sch.set_timesteps(50)
+    ts = [int(v) for v in sch.timesteps]
+    init = torch.randn(256, 3, 32, 32, generator=torch.Generator().manual_seed(9))
+    # two steps of 4 chains, product vs oracle
+    x = init[:4].clone(); xg = x.cuda()
+    with torch.no_grad():
+        for i in range(2):
+            tt = ts[i]
+            e_ref = U.unet_forward(cfg, P, x, tt)
+            x = sched_ref.ddim_step(ac, e_ref, tt, x, num_inference_steps=50, eta=0.0, clip_sample=False)[0]
+            e = m(xg, tt).sample
+            xg = sch.step(e, tt, xg).prev_sample
+    assert relerr(xg, x) < 1e-3
+    # the full loop
+    pipe = DDIMPipeline(m, DDIMScheduler(clip_sample=False))
+    call = lambda **kw: pipe(num_inference_steps=50, **kw)
+    full = batch_sampling(256, call, init=init, max_batch_n=256)
+    assert full.shape == (256, 32, 32, 3) and np.isfinite(full).all() and full.min() >= 0.0 and full.max() <= 1.0
+    part = batch_sampling(64, call, init=init[:64], max_batch_n=24)          # 24 + 24 + 16: chunks of other sizes
+    np.testing.assert_allclose(part, full[:64], rtol=0, atol=2e-3)           # kernels may differ per batch size: rounding only
+    assert float(np.abs(part - full[:64]).mean()) < 2e-5
+    # rank sharding of the 2048-chain job: rank 5 of 8 owns samples [1280, 1536)
+    short = lambda **kw: pipe(num_inference_steps=2, **kw)
+    big_init = torch.randn(2048, 3, 32, 32, generator=torch.Generator().manual_seed(10))
+    batch_sampling_save(2048, short, str(tmp_path / "s"), init=big_init, max_batch_n=2048, rank=5, world=8)
+    names = sorted(int(n[:-4]) for n in os.listdir(tmp_path / "s"))
+    assert names == list(range(1280, 1536))
+    from PIL import Image
+    own = pipe(batch_size=2, init=big_init[1280:1282], output_type=None, num_inference_steps=2).images
+    png = np.asarray(Image.open(tmp_path / "s" / "1281.png"))
+    assert np.abs(png.astype(int) - (own[1] * 255).round().astype(int)).max() <= 1
+
+
+# ------------------------------------------------------------------------------------------------ 1(d)
+def test_cifar_full_batch_forward_samples_vs_oracle(gpu):
+    """4 samples (both half-batch pipelines) of the B = 128 DDPM-CIFAR10-32 forward against the oracle's outputs"""
+    cfg = U.CIFAR10_32
+    m = make_model(cfg, 0, gpu)
+    P = U.gen_params(cfg, 0)
+    B = 128
+    x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(3))
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(4))
+    with torch.no_grad():
+        out = m(x.cuda(), t.cuda(), return_dict=False)[0].cpu()
+        idx = [0, 63, 64, 127]
+        ref = U.unet_forward(cfg, P, x[idx], t[idx])
+    for j, i in enumerate(idx):
+        assert relerr(out[i], ref[j]) < 1e-4, (i, relerr(out[i], ref[j]))
+
+
+# ------------------------------------------------------------------------------------------------ 1(f)
+def test_adam_clip_dev_matches_host_scalar_form(gpu):
+    """bd_adam_clip_dev (step size / bias correction read from DEVICE memory: what a replayed hipGraph needs) is the same
+    update as bd_adam_clip with host scalars, bit for bit, over several steps"""
+    import ctypes
+    import math
+    from baddiffusion_amd import _lib as L
+    from baddiffusion_amd import ops
+    lib = L.load()
+    n = 100003
+    g = torch.Generator().manual_seed(5)
+    p1 = torch.randn(n, generator=g).cuda(); p2 = p1.clone()
+    m1 = torch.zeros(n).cuda(); v1 = torch.zeros(n).cuda(); m2 = torch.zeros(n).cuda(); v2 = torch.zeros(n).cuda()
+    lr, b1, b2, eps = 2e-4, 0.9, 0.999, 1e-8
+    n1 = torch.zeros((), device="cuda"); n2 = torch.zeros((), device="cuda")
+    for step in range(1, 4):
+        gr = (torch.randn(n, generator=g) * 3).cuda()
+        ss = ops.sumsq(gr)
+        ops.adam_clip(p1, gr, m1, v1, ss, step, lr, 1.0, (b1, b2), eps, grad_norm_out=n1)
+        hyper = torch.tensor([lr / (1 - b1 ** step), math.sqrt(1 - b2 ** step)], dtype=torch.float32).cuda()
+        L.check(lib.bd_adam_clip_dev(p2.data_ptr(), gr.data_ptr(), m2.data_ptr(), v2.data_ptr(), n, ss.data_ptr(), 1.0,
+                                     hyper.data_ptr(), b1, b2, eps, n2.data_ptr(), L.stream()), "bd_adam_clip_dev")
+        assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2) and float(n1) == float(n2)
+
+
+# ------------------------------------------------------------------------------------------------ 1(g)
+def test_fused_gather_and_flip(gpu):
+    """row_index / flip of bd_poison_qsample == indexing the resident array and torch.flip along W
+    (the DataLoader's shuffle + RandomHorizontalFlip, dataset.py:127-128), bit for bit; DatasetLoader.device_batch_rows
+    feeds exactly the rows / flips that device_batches materialises."""
+    from baddiffusion_amd import ops
+    from baddiffusion_amd.dataset import Backdoor, DatasetLoader
+    S, N, B = 32, 40, 8
+    imgs = _u8_batch(N, S, 31).cuda()
+    rows = torch.tensor([5, 39, 0, 17, 17, 3, 22, 8]).cuda()
+    flip = torch.tensor([1, 0, 1, 1, 0, 0, 1, 0], dtype=torch.uint8).cuda()
+    pois = torch.tensor([1, 0, 0, 1, 0, 0, 0, 1], dtype=torch.bool).cuda()
+    bd = Backdoor(root=None)
+    trig = bd.get_trigger("BOX_14", 3, S).cuda(); tgt = bd.get_target("CORNER", trig.cpu()).cuda()
+    eps = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(32)).cuda()
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(33)).cuda()
+    _, a, ac = sched_ref.make_tables()
+    a, ac = a.cuda(), ac.cuda()
+    fused = ops.poison_qsample(imgs, pois, trig, tgt, eps, t, a, ac, want_batch=True, want_image=True, row_index=rows, flip=flip)
+    gathered = imgs[rows]
+    gathered = torch.where(flip.bool()[:, None, None, None], gathered.flip(2), gathered)
+    plain = ops.poison_qsample(gathered, pois, trig, tgt, eps, t, a, ac, want_batch=True, want_image=True)
+    for u, v in zip(fused, plain):
+        assert torch.equal(u, v)
+    dsl = DatasetLoader(root=None, name="CIFAR10", batch_size=8, seed=4, num_images=N, device="cuda")
+    dsl.set_poison("BOX_14", "CORNER", poison_rate=0.2).prepare_dataset("FIXED").to_device("cuda")
+    for (r, f, p), (img, p2) in zip(dsl.device_batch_rows(epoch=2), dsl.device_batches(epoch=2)):
+        g = dsl.device_images[r]
+        g = torch.where(f.bool()[:, None, None, None], g.flip(2), g)
+        assert torch.equal(g, img) and torch.equal(p, p2)
+
+
+# ------------------------------------------------------------------------------------------------ split-plane convolution family
+@pytest.mark.parametrize("B,S,Cin,Cout", [(2, 16, 128, 128), (3, 8, 256, 128), (128, 16, 128, 256), (5, 4, 128, 384), (64, 32, 128, 128)])
+def test_conv_ps_family_vs_igemm(gpu, B, S, Cin, Cout):
+    """bd_conv3x3_ps (+1 / -1) and bd_conv3x3_ps_wgrad on split planes against the exact-fp32 igemm path (1e-4) and the
+    split-bf16 igemm path (rounding level: same products, possibly another K-split order); GroupNorm's split outputs
+    and bd_split_rows are bit-identical to splitting the fp32 result."""
+    from baddiffusion_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + S)
+    x = torch.randn(B, S, S, Cin, generator=g).cuda(); dy = torch.randn(B, S, S, Cout, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).cuda(); bias = torch.randn(Cout, generator=g).cuda()
+    rb = torch.randn(B, Cout, generator=g).cuda(); res = torch.randn(B, S, S, Cout, generator=g).cuda()
+    ws, xs, dys, wts = ops.split_bf16(w), ops.split_rows(x), ops.split_rows(dy), ops.split_wT(w)
+    # split planes: [rows, C/32, (hi|lo), 32] == the flat 32-element-block split of the same contiguous buffer
+    assert torch.equal(xs.reshape(-1), ops.split_bf16(x).reshape(-1))
+    for kw in (dict(), dict(rowbias=rb), dict(residual=res, out_scale=0.7)):
+        new = ops.conv3x3_ps(xs, ws, B, S, S, Cin, Cout, 1, bias=bias, **kw)
+        assert relerr(new, ops.conv3x3_fwd(x, w, bias, mode=0, **kw)) < 1e-4
+        assert relerr(new, ops.conv3x3_fwd(x, w, bias, mode=1, **kw)) < 2e-6
+    if Cin % 128 == 0:
+        newd = ops.conv3x3_ps(dys, wts, B, S, S, Cout, Cin, -1)
+        assert relerr(newd, ops.conv3x3_dgrad(dy, w, (B, S, S, Cin), mode=0)) < 1e-4
+        acc = ops.conv3x3_ps(dys, wts, B, S, S, Cout, Cin, -1, out=newd.clone(), accumulate=True)
+        assert relerr(acc, 2 * newd) < 1e-6
+        dw, db = ops.conv3x3_ps_wgrad(xs, dys, B, S, S, Cin, Cout, with_db=True)
+        dw_ref, db_ref = ops.conv3x3_wgrad(x, dy, mode=0, with_db=True)
+        assert relerr(dw, dw_ref) < 1e-4 and relerr(db, db_ref) < 1e-4
+        dw2 = ops.conv3x3_ps_wgrad(xs, dys, B, S, S, Cin, Cout)
+        assert torch.equal(dw, dw2)                    # run-to-run determinism (fixed-order K split)
+
+
+def test_groupnorm_split_outputs(gpu):
+    """bd_gn_fwd.y_split / bd_gn_bwd.dx_split == bd_split_rows of the fp32 outputs, bit for bit (resident and split kernels)"""
+    import ctypes as CT
+    from baddiffusion_amd import _lib as L
+    from baddiffusion_amd import ops
+    lib = L.load()
+    for (B, HW, Cc) in [(4, 256, 128), (2, 4096, 64), (3, 16, 256)]:
+        g = torch.Generator().manual_seed(HW)
+        x = torch.randn(B, HW, Cc, generator=g).cuda(); dy = torch.randn(B, HW, Cc, generator=g).cuda()
+        ga = (1 + 0.1 * torch.randn(Cc, generator=g)).cuda(); be = (0.1 * torch.randn(Cc, generator=g)).cuda()
+        y, mean, rstd = ops.gn_fwd(x, ga, be, 32, 1e-6, True)
+        ys = torch.empty(B * HW, Cc // 32, 2, 32, dtype=torch.int16, device="cuda")
+        st = torch.empty(2, B, 32, device="cuda")
+        ws = ops.workspace(lib.bd_gn_workspace_bytes(B, Cc), x.device)
+        d = L.GnFwdDesc(B=B, HW=HW, C=Cc, G=32, eps=1e-6, silu=1, x=L.ptr(x), ldx=Cc, gamma=L.ptr(ga), beta=L.ptr(be), y=None, ldy=Cc,
+                        mean=L.ptr(st[0]), rstd=L.ptr(st[1]), workspace=L.ptr(ws), workspace_bytes=ws.numel(), y_split=L.ptr(ys), ldys=Cc)
+        L.check(lib.bd_gn_fwd(CT.byref(d), L.stream()), "bd_gn_fwd")
+        assert torch.equal(ys, ops.split_rows(y)) and torch.equal(st[0], mean)
+        dx, _, _ = ops.gn_bwd(x, ga, be, mean, rstd, dy, 32, True)
+        dxs = torch.empty_like(ys)
+        dg = torch.empty(Cc, device="cuda"); db = torch.empty(Cc, device="cuda")
+        e = L.GnBwdDesc(B=B, HW=HW, C=Cc, G=32, silu=1, x=L.ptr(x), ldx=Cc, gamma=L.ptr(ga), beta=L.ptr(be), mean=L.ptr(mean),
+                        rstd=L.ptr(rstd), dy=L.ptr(dy), lddy=Cc, dx=None, lddx=Cc, accumulate_dx=0, dgamma=L.ptr(dg), dbeta=L.ptr(db),
+                        workspace=L.ptr(ws), workspace_bytes=ws.numel(), dx_split=L.ptr(dxs), lddxs=Cc)
+        L.check(lib.bd_gn_bwd(CT.byref(e), L.stream()), "bd_gn_bwd")
+        assert torch.equal(dxs, ops.split_rows(dx))
+
+
+# ------------------------------------------------------------------------------------------------ 7: two ranks over gloo on one GPU
+def _dp_cifar_worker(rank, world, port, ret):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    torch.cuda.set_device(0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    from baddiffusion_amd.unet import unet_from_config
+    cfg = U.CIFAR10_32
+    x0, R, t, eps = [v.cuda() for v in C.train_inputs(cfg, 4)]
+    m = unet_from_config(cfg).cuda()
+    m.load_state_dict(U.gen_params(cfg, rank))          # DIFFERENT initial weights per rank: the engine must broadcast rank 0's
+    e = TrainEngine(m, DDPMScheduler(), lr=1e-3)
+    ret[f"init{rank}"] = m.flat.detach().cpu()
+    sl = slice(rank, None, world)
+    for _ in range(2):
+        e.train_step_batch(x0[sl], R[sl], eps[sl], t[sl])
+    torch.cuda.synchronize()
+    ret[f"flat{rank}"] = m.flat.detach().cpu()
+    ret[f"gn{rank}"] = float(e.grad_norm)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_ranks_cifar_topology_sync_and_equal_global_batch(gpu):
+    """2 processes x batch 2 on the DDPM-CIFAR10-32 topology: ranks built with different seeds start from rank 0's weights
+    (TrainEngine.sync_state), stay bit-identical over 2 steps, and match 1 process x batch 4 (flat-gradient all-reduce per
+    backward segment replaces nn.DataParallel, baddiffusion.py:325)."""
+    import socket
+    import torch.multiprocessing as mp
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    ret = mp.Manager().dict()
+    mp.spawn(_dp_cifar_worker, args=(2, port, ret), nprocs=2, join=True)
+    assert torch.equal(ret["init0"], ret["init1"])
+    assert torch.equal(ret["flat0"], ret["flat1"]) and ret["gn0"] == ret["gn1"]
+    cfg = U.CIFAR10_32
+    x0, R, t, eps = [v.cuda() for v in C.train_inputs(cfg, 4)]
+    m = make_model(cfg, 0, gpu)
+    assert torch.equal(m.flat.detach().cpu(), ret["init0"])
+    e = TrainEngine(m, DDPMScheduler(), lr=1e-3)
+    for _ in range(2):
+        e.train_step_batch(x0, R, eps, t)
+    assert abs(float(e.grad_norm) - ret["gn0"]) < 1e-3 * float(e.grad_norm)
+    d = (m.flat.detach().cpu() - ret["flat0"]).abs()
+    assert float((d > 2e-4).float().mean()) < 1e-3 and float(d.mean()) < 2e-5
+
+
+def _torchrun(args, env_extra, timeout=600):
+    import socket
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    env = dict(os.environ, BD_DIST_BACKEND="gloo", PYTHONPATH=ROOT, **env_extra)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port)] + args
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_two_ranks_end_to_end(gpu):
+    """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per process), with gloo so that
+    both ranks can share the test box's single GPU: one JSON line from rank 0 with the whole-job aggregate."""
+    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline"], {})
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
+    assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"] + 1e-3     # images of ALL ranks / max-over-ranks time
+
+
+def test_cli_train_loop_two_ranks(gpu, tmp_path):
+    """python baddiffusion.py --mode train on 2 ranks (gloo): 8 synthetic images, global batch 4 -> 2 steps; rank 0 writes
+    the diffusers-layout checkpoint, the run records that it was not started from pretrained weights."""
+    out = str(tmp_path / "res")
+    r = _torchrun(["baddiffusion.py", "--mode", "train", "--dataset", "CIFAR10", "--batch", "2", "--epoch", "1", "--poison_rate", "0.25",
+                   "--trigger", "BOX_14", "--target", "CORNER", "--ckpt", "DDPM-CIFAR10-32", "--result", out, "-o",
+                   "--save_image_epochs", "100"],
+                  {"BD_NUM_IMAGES": "8", "BD_ALLOW_RANDOM_INIT": "1"})
+    assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
+    runs = [os.path.join(out, d) for d in os.listdir(out)]
+    assert len(runs) == 1
+    files = os.listdir(runs[0])
+    assert "unet" in files and "scheduler" in files and "model_index.json" in files and "config.json" in files
+    cfgj = json.load(open(os.path.join(runs[0], "config.json")))
+    assert cfgj["pretrained"] is False
+    log = [json.loads(ln) for ln in open(os.path.join(runs[0], "log.jsonl"))]
+    assert log and np.isfinite(log[0]["loss"])

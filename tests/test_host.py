@@ -120,7 +120,11 @@ def test_lr_schedule_and_cli_rules(tmp_path, monkeypatch):
 
 def test_checkpoint_layout_roundtrip(tmp_path):
     from baddiffusion_amd.model import DiffuserModelSched, load_scheduler, load_unet
-    model, sched, get_pipeline = DiffuserModelSched.get_pretrained("DDPM-CIFAR10-32", clip_sample=False, noise_sched_type="DDPM-SCHED")
+    with pytest.raises(FileNotFoundError):      # like from_pretrained: no silent random-init fine-tuning
+        DiffuserModelSched.get_pretrained("DDPM-CIFAR10-32", clip_sample=False, noise_sched_type="DDPM-SCHED")
+    model, sched, get_pipeline = DiffuserModelSched.get_pretrained("DDPM-CIFAR10-32", clip_sample=False, noise_sched_type="DDPM-SCHED",
+                                                                   allow_random_init=True)
+    assert model.pretrained is False
     d = str(tmp_path / "run")
     get_pipeline(model, sched).save_pretrained(d)
     assert sorted(os.listdir(d)) == ["model_index.json", "scheduler", "unet"]
@@ -132,4 +136,39 @@ def test_checkpoint_layout_roundtrip(tmp_path):
     m3, s3, _ = DiffuserModelSched.get_trained(d, clip_sample=None)
     assert torch.equal(m3.flat, model.flat) and s3.config.clip_sample is False and m3.pretrained
     with pytest.raises(NotImplementedError):
-        DiffuserModelSched.get_pretrained("DDPM-CIFAR10-32", noise_sched_type="UNIPC-SCHED")
+        DiffuserModelSched.get_pretrained("DDPM-CIFAR10-32", noise_sched_type="UNIPC-SCHED", allow_random_init=True)
+
+
+def test_dataset_modes_and_rank_sharding():
+    """FIXED vs FLEX sizes (/root/reference/dataset.py:162-243) and equal, non-empty per-rank batches incl. the tail."""
+    from baddiffusion_amd.dataset import Backdoor, DatasetLoader
+    n = 203
+    mk = lambda: DatasetLoader(root=None, name="CIFAR10", batch_size=8, seed=3, num_images=n, device="cpu")
+    d = mk().set_poison(Backdoor.TRIGGER_BOX_14 if hasattr(Backdoor, "TRIGGER_BOX_14") else "BOX_14", "CORNER", clean_rate=0.5,
+                        poison_rate=0.1).prepare_dataset("FIXED")
+    assert len(d) == n and int(d._is_poison.sum()) == int(n * 0.1)            # clean_rate ignored in FIXED
+    f = mk().set_poison("BOX_14", "CORNER", clean_rate=0.5, poison_rate=0.1).prepare_dataset("FLEX")
+    train_n, test_n = int(n * 0.5), int(n * 0.1)
+    assert len(f) == train_n + test_n
+    rows = f._rows()
+    assert int(f._is_poison[rows].sum()) == test_n and int(f._is_poison.sum()) == test_n and len(set(rows.tolist())) == len(rows)
+    with pytest.raises(ValueError):
+        mk().set_poison("BOX_14", "CORNER", clean_rate=0.95, poison_rate=0.1).prepare_dataset("FLEX")
+    with pytest.raises(NotImplementedError):
+        mk().set_poison("BOX_14", "CORNER").prepare_dataset("OTHER")
+    with pytest.raises(NotImplementedError):      # class filter without labels
+        DatasetLoader(root=None, name="CIFAR10", label=[1], batch_size=8, num_images=16, device="cpu").prepare_dataset("FIXED")
+    # rank sharding: same count on every rank at every step (203 % (8*3) = 11, 11 % 3 = 2 -> tail wrap-padded), disjoint
+    # rows inside a step, and the union over ranks covers the dataset
+    world = 3
+    per_rank = [list(d.device_batches(shuffle=True, epoch=1, rank=r, world=world, flip=False)) for r in range(world)]
+    assert len({len(b) for b in per_rank}) == 1
+    seen = 0
+    for step in range(len(per_rank[0])):
+        sizes = {per_rank[r][step][0].shape[0] for r in range(world)}
+        assert len(sizes) == 1 and 0 not in sizes
+        seen += sum(per_rank[r][step][0].shape[0] for r in range(world))
+    assert n <= seen < n + world
+    # flip flags are drawn per global row, so world = 1 and world = 3 flip the same images
+    one = torch.cat([b[0] for b in d.device_batches(shuffle=True, epoch=1, rank=0, world=1, flip=True)])
+    assert one.shape[0] == n
