@@ -135,6 +135,7 @@ SIGNATURES = {
     "bd_split_bf16": (i32, [vp, i64, vp, vp]),
     "bd_split_rows": (i32, [vp, i64, i64, i32, vp, i64, vp]),
     "bd_split_wt": (i32, [vp, i32, i32, vp, vp]),
+    "bd_split_rows_ups2": (i32, [vp, i64, i32, i32, i32, i32, vp, i64, vp]),
     "bd_conv3x3_ps": (i32, [C.POINTER(ConvPsDesc), vp]),
     "bd_conv3x3_ps_workspace_bytes": (sz, [C.POINTER(ConvPsDesc)]),
     "bd_conv3x3_ps_wgrad": (i32, [C.POINTER(ConvPsWgradDesc), vp]),

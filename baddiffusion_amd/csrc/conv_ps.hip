@@ -28,6 +28,7 @@ typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 typedef __attribute__((address_space(3))) void* lds_ptr;
 typedef const __attribute__((address_space(1))) void* gbl_ptr;
 
+constexpr int BD_WT_MAX = 64;   // weights per batched transpose launch (table passed by value)
 constexpr int PS_BM = 256, PS_BN = 128, PS_NT = 512, PS_STAGES = 3;
 constexpr int PS_A_BYTES = PS_BM * 128, PS_B_BYTES = PS_BN * 128, PS_STAGE_BYTES = PS_A_BYTES + PS_B_BYTES;
 constexpr int PS_LDS_BYTES = PS_STAGES * PS_STAGE_BYTES;   // 147456 of 163840
@@ -752,6 +753,28 @@ __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict
     }
 }
 
+// nearest-neighbour x2 upsampling folded into the split: src [B, H, W, C] fp32 -> split planes of [B, 2H, 2W, C]
+// (Upsample2D, resnet.py:126-161: F.interpolate(scale_factor=2, mode="nearest") feeding a 3x3 conv)
+__global__ __launch_bounds__(256) void split_rows_ups2_kernel(const float* __restrict__ src, long long lds, int B, int H, int W, int C,
+                                                               unsigned short* __restrict__ dst, long long ldd) {
+    const int c8 = C >> 3;
+    const long long total = (long long)B * 4 * H * W * c8;
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long long)gridDim.x * 256) {
+        const long long r = i / c8;                      // output pixel (b, y, x) over the 2H x 2W grid
+        const int j = (int)(i - r * c8);
+        const int x = (int)(r % (2 * W));
+        const long long t = r / (2 * W);
+        const int y = (int)(t % (2 * H));
+        const long long b = t / (2 * H);
+        const long long rs = (b * H + (y >> 1)) * W + (x >> 1);
+        const float4 a = *reinterpret_cast<const float4*>(src + rs * lds + j * 8);
+        const float4 bb = *reinterpret_cast<const float4*>(src + rs * lds + j * 8 + 4);
+        unsigned short* o = dst + 2 * r * ldd + (j >> 2) * 64 + (j & 3) * 8;
+        *reinterpret_cast<uint4*>(o) = make_uint4(ps_pack_hi(a.x, a.y), ps_pack_hi(a.z, a.w), ps_pack_hi(bb.x, bb.y), ps_pack_hi(bb.z, bb.w));
+        *reinterpret_cast<uint4*>(o + 32) = make_uint4(ps_pack_lo(a.x, a.y), ps_pack_lo(a.z, a.w), ps_pack_lo(bb.x, bb.y), ps_pack_lo(bb.z, bb.w));
+    }
+}
+
 // conv weights W[co][tap][ci] fp32 -> split planes of the transpose Wt[ci][tap][co] (rows ci, K = (tap, co)); Cin, Cout % 32 == 0.
 // One workgroup = one (tap, 32 co x 32 ci) block through LDS.
 __global__ __launch_bounds__(256) void split_wT_kernel(const float* __restrict__ w, int Cin, int Cout, unsigned short* __restrict__ out) {
@@ -770,6 +793,55 @@ __global__ __launch_bounds__(256) void split_wT_kernel(const float* __restrict__
     unsigned short* o = out + 2 * (((long long)(cib * 32 + r) * 9 + tap) * Cout + cob * 32) + c4;
     *reinterpret_cast<uint2*>(o) = make_uint2(ps_pack_hi(v0, v1), ps_pack_hi(v2, v3));
     *reinterpret_cast<uint2*>(o + 32) = make_uint2(ps_pack_lo(v0, v1), ps_pack_lo(v2, v3));
+}
+
+// all 3x3 conv weights of a network in ONE launch: the table (by value in the kernel arguments) lists, per weight,
+// its element offset in the flat fp32 buffer (== its offset in the transposed split copy), the channel counts and the
+// first block of the 1-D grid that belongs to it
+struct WtTable {
+    int n;
+    long long off[BD_WT_MAX];
+    int cin[BD_WT_MAX], cout[BD_WT_MAX], blk0[BD_WT_MAX + 1];
+};
+__global__ __launch_bounds__(256) void split_wT_batched_kernel(const float* __restrict__ params, unsigned short* __restrict__ out, WtTable t) {
+    __shared__ float tl[32][33];
+    int e = 0;
+    while (e + 1 < t.n && (int)blockIdx.x >= t.blk0[e + 1]) ++e;
+    const int Cin = t.cin[e], Cout = t.cout[e];
+    const float* w = params + t.off[e];
+    unsigned short* o_base = out + 2 * t.off[e];
+    int b = blockIdx.x - t.blk0[e];
+    const int ncib = Cin / 32, ncob = Cout / 32;
+    const int cib = b % ncib; b /= ncib;
+    const int cob = b % ncob; const int tap = b / ncob;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int co = cob * 32 + ty + 8 * i;
+        tl[ty + 8 * i][tx] = w[((long long)co * 9 + tap) * Cin + cib * 32 + tx];
+    }
+    __syncthreads();
+    const int r = threadIdx.x >> 3, c4 = (threadIdx.x & 7) * 4;
+    const float v0 = tl[c4][r], v1 = tl[c4 + 1][r], v2 = tl[c4 + 2][r], v3 = tl[c4 + 3][r];
+    unsigned short* o = o_base + 2 * (((long long)(cib * 32 + r) * 9 + tap) * Cout + cob * 32) + c4;
+    *reinterpret_cast<uint2*>(o) = make_uint2(ps_pack_hi(v0, v1), ps_pack_hi(v2, v3));
+    *reinterpret_cast<uint2*>(o + 32) = make_uint2(ps_pack_lo(v0, v1), ps_pack_lo(v2, v3));
+}
+
+int split_wt_batched(const float* params, uint16_t* out, const long long* off, const int* cin, const int* cout, int n, hipStream_t st) {
+    for (int i0 = 0; i0 < n; i0 += BD_WT_MAX) {
+        WtTable t;
+        t.n = n - i0 < BD_WT_MAX ? n - i0 : BD_WT_MAX;
+        int blk = 0;
+        for (int i = 0; i < t.n; ++i) {
+            t.off[i] = off[i0 + i]; t.cin[i] = cin[i0 + i]; t.cout[i] = cout[i0 + i]; t.blk0[i] = blk;
+            blk += 9 * (t.cin[i] / 32) * (t.cout[i] / 32);
+        }
+        t.blk0[t.n] = blk;
+        hipLaunchKernelGGL(split_wT_batched_kernel, dim3((unsigned)blk), dim3(256), 0, st, params, out, t);
+        BD_LAUNCH_CHECK("split_wT_batched");
+    }
+    return BD_OK;
 }
 
 static int ilog2x(int v) {
@@ -975,6 +1047,17 @@ extern "C" int bd_split_rows(const float* src, int64_t ld_src, int64_t rows, int
     hipLaunchKernelGGL(bd::split_rows_kernel, dim3((unsigned)nb), dim3(256), 0, bd::S(stream), src, (long long)ld_src, (long long)rows, C, dst,
                        (long long)ld_dst);
     BD_LAUNCH_CHECK("split_rows");
+    return BD_OK;
+}
+extern "C" int bd_split_rows_ups2(const float* src, int64_t ld_src, int B, int H, int W, int C, uint16_t* dst, int64_t ld_dst, bd_stream_t stream) {
+    BD_CHECK(src && dst && B > 0 && H > 0 && W > 0 && C > 0, BD_ERR_INVALID, "bd_split_rows_ups2: bad args");
+    BD_CHECK(C % 32 == 0 && ld_dst % 32 == 0 && (ld_src & 3) == 0 && bd::aligned16(src) && ((uintptr_t)dst & 127) == 0, BD_ERR_UNSUPPORTED,
+             "bd_split_rows_ups2: C, ld_dst %% 32, ld_src %% 4, 16-byte aligned src and 128-byte aligned dst required");
+    long long nb = bd::cdiv((long long)B * 4 * H * W * (C / 8), 256);
+    if (nb > 8192) nb = 8192;
+    hipLaunchKernelGGL(bd::split_rows_ups2_kernel, dim3((unsigned)nb), dim3(256), 0, bd::S(stream), src, (long long)ld_src, B, H, W, C, dst,
+                       (long long)ld_dst);
+    BD_LAUNCH_CHECK("split_rows_ups2");
     return BD_OK;
 }
 extern "C" int bd_split_wt(const float* w, int Cin, int Cout, uint16_t* out, bd_stream_t stream) {

@@ -30,6 +30,7 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st);                    
 bool conv3x3_ps_supported(int B, int H, int W, int K_channels, int N_channels);
 int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st);
 bool conv3x3_ps_wgrad_supported(int B, int H, int W, int Cin, int Cout);
+int split_wt_batched(const float* params, uint16_t* out, const long long* off, const int* cin, const int* cout, int n, hipStream_t st);
 
 struct View {
     int buf = -1;   // value buffer id
@@ -75,6 +76,7 @@ struct Ctx {
     hipStream_t st2 = nullptr; hipEvent_t ev_fork = nullptr, ev_join[2] = {nullptr, nullptr};
     char* opws2 = nullptr; int par = 0; bool launched = false, pend[2] = {false, false};
     const uint16_t* w_split = nullptr;   // pre-split weights (BF16X3, bd_split_bf16 layout): element e of params <-> 2*e here
+    const uint16_t* wT_split = nullptr;  // transposed split planes Wt[ci][tap][co] of the 3x3 conv weights, same element offsets
     std::vector<char> ginit;
 };
 
@@ -105,6 +107,7 @@ struct bd_unet {
     int T = 0, sumC = 0;     // time-embed dim, total time_emb_proj rows
     int64_t p_tw = 0, p_tb = 0;  // offsets of the batched time_emb_proj weight / bias
     int b_tproj = -1, b_dtproj = -1, b_embs = -1;
+    std::vector<long long> wt_off; std::vector<int> wt_cin, wt_cout;   // 3x3 conv weights with a transposed split copy
 
     // ---------------------------------------------------------------- construction helpers
     int new_buf(int64_t per_sample, int64_t fixed, int region) {
@@ -413,6 +416,10 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
         psw = add_param(pre + "conv_shortcut.weight", {Cout, Cin, 1, 1}, 1);
         psb = add_param(pre + "conv_shortcut.bias", {Cout});
     }
+    if (Cin % 32 == 0 && Cout % 32 == 0) {
+        wt_off.push_back(pc1w); wt_cin.push_back(Cin); wt_cout.push_back(Cout);
+        wt_off.push_back(pc2w); wt_cin.push_back(Cout); wt_cout.push_back(Cout);
+    }
     const int b_a1 = new_buf((int64_t)HW * Cin, 0, R_VALUE), b_h1 = new_buf((int64_t)HW * Cout, 0, R_VALUE);
     const int b_a2 = new_buf((int64_t)HW * Cout, 0, R_VALUE);
     // split-plane twins of a1 / a2 (operands of the LDS-DMA convolutions; 4 B per element like fp32)
@@ -426,7 +433,6 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
     const int b_da1 = scratch((int64_t)HW * Cin);
     // backward operands of the LDS-DMA data gradients: dy / dh1 as split planes, transposed weight planes
     const int b_dyS = scratch((int64_t)HW * Cout), b_dh1S = scratch((int64_t)HW * Cout);
-    const int b_wT2 = scratch(0, (int64_t)9 * Cout * Cout), b_wT1 = scratch(0, (int64_t)9 * Cin * Cout);
     const float inv = 1.f / scale;
     const int sumC_ = sumC;
 
@@ -503,10 +509,9 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             w2.x_split = U16(BP(c, b_a2s)); w2.ldx = Cout; w2.dy_split = U16(BP(c, b_dyS)); w2.lddy = Cout;
             w2.dw = c.grads + pc2w; w2.db = c.grads + pc2b;
             BD_TRY(conv_pw(c, w2));
-            if (!c.dry) BD_TRY(bd_split_wt(c.params + pc2w, Cout, Cout, U16(BP(c, b_wT2)), (bd_stream_t)c.st));
             bd_conv3x3_ps_desc g2 = {};
             g2.B = c.B; g2.H = H; g2.W = W; g2.K = Cout; g2.N = Cout; g2.direction = -1;
-            g2.x_split = U16(BP(c, b_dyS)); g2.ldx = Cout; g2.w_split = U16(BP(c, b_wT2)); g2.out_scale = 1.f;
+            g2.x_split = U16(BP(c, b_dyS)); g2.ldx = Cout; g2.w_split = c.wT_split + 2 * pc2w; g2.out_scale = 1.f;
             g2.y = BP(c, b_da2); g2.ldy = Cout;
             BD_TRY(conv_p(c, g2));
         } else {
@@ -538,10 +543,9 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             w1.x_split = U16(BP(c, b_a1s)); w1.ldx = Cin; w1.dy_split = U16(BP(c, b_dh1S)); w1.lddy = Cout;
             w1.dw = c.grads + pc1w; w1.db = c.grads + pc1b;
             BD_TRY(conv_pw(c, w1));
-            if (!c.dry) BD_TRY(bd_split_wt(c.params + pc1w, Cin, Cout, U16(BP(c, b_wT1)), (bd_stream_t)c.st));
             bd_conv3x3_ps_desc g1 = {};
             g1.B = c.B; g1.H = H; g1.W = W; g1.K = Cout; g1.N = Cin; g1.direction = -1;
-            g1.x_split = U16(BP(c, b_dh1S)); g1.ldx = Cout; g1.w_split = U16(BP(c, b_wT1)); g1.out_scale = 1.f;
+            g1.x_split = U16(BP(c, b_dh1S)); g1.ldx = Cout; g1.w_split = c.wT_split + 2 * pc1w; g1.out_scale = 1.f;
             g1.y = BP(c, b_da1); g1.ldy = Cin;
             BD_TRY(conv_p(c, g1));
         } else {
@@ -701,8 +705,21 @@ void bd_unet::node_downsample(const std::string& pre, const View& x, const View&
 void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y) {
     const int C = x.C, H = x.H, W = x.W;
     const int64_t pw = add_param(pre + "conv.weight", {C, C, 3, 3}, 1), pb = add_param(pre + "conv.bias", {C});
+    if (C % 32 == 0) { wt_off.push_back(pw); wt_cin.push_back(C); wt_cout.push_back(C); }
     const int b_bs = scratch(C), b_du = scratch((int64_t)4 * H * W * C);
+    // LDS-DMA path: the nearest-upsampled input is materialised ONCE as split planes (4 B per element of the 2H x 2W
+    // grid) and feeds the stride-1 "same" kernels of conv_ps.hip: forward, weight gradient and (through b_du + 2x2 sums)
+    // the data gradient.  Otherwise the upsampling stays folded into the igemm gather.
+    const int b_xuS = new_buf((int64_t)4 * H * W * C, 0, R_VALUE), b_dyS = scratch((int64_t)4 * H * W * C);
     F([=](Ctx& c) {
+        if (ps_ok(c, 2 * H, 2 * W, C, C)) {
+            if (!c.dry) BD_TRY(bd_split_rows_ups2(VP(c, x), x.ld, c.B, H, W, C, U16(BP(c, b_xuS)), C, (bd_stream_t)c.st));
+            bd_conv3x3_ps_desc d = {};
+            d.B = c.B; d.H = 2 * H; d.W = 2 * W; d.K = C; d.N = C; d.direction = 1;
+            d.x_split = U16(BP(c, b_xuS)); d.ldx = C; d.w_split = c.w_split + 2 * pw; d.bias = c.params + pb; d.out_scale = 1.f;
+            d.y = VP(c, y); d.ldy = y.ld;
+            return conv_p(c, d);
+        }
         bd_conv3x3_fwd_desc d = {};
         d.B = c.B; d.Hs = H; d.Ws = W; d.Cin = C; d.Cout = C; d.stride = 1; d.pad_t = 1; d.pad_l = 1; d.ups = 1; d.Ho = 2 * H; d.Wo = 2 * W;
         d.x = VP(c, x); d.ldx = x.ld; d.w = c.params + pw; d.bias = c.params + pb; d.out_scale = 1.f;
@@ -711,16 +728,30 @@ void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y
     });
     Bk([=](Ctx& c) {
         const float* dy = GP(c, y);
-        bd_conv3x3_wgrad_desc w = {};
-        w.B = c.B; w.Hs = H; w.Ws = W; w.Cin = C; w.Cout = C; w.stride = 1; w.pad_t = 1; w.pad_l = 1; w.ups = 1; w.Ho = 2 * H; w.Wo = 2 * W;
-        w.x = VP(c, x); w.ldx = x.ld; w.dy = dy; w.lddy = y.ld; w.dw = c.grads + pw; w.db = c.grads + pb;
-        BD_TRY(conv_w(c, w));
-        bd_conv3x3_dgrad_desc g = {};
-        g.B = c.B; g.Hs = H; g.Ws = W; g.Cin = C; g.Cout = C; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.ups = 1; g.Ho = 2 * H; g.Wo = 2 * W;
-        g.dy = dy; g.lddy = y.ld; g.w = c.params + pw; g.dx = BP(c, b_du); g.lddx = C;
-        BD_TRY(conv_d(c, g));
         const int acc = c.ginit[x.buf];
         c.ginit[x.buf] = 1;
+        if (ps_ok(c, 2 * H, 2 * W, C, C)) {
+            BD_TRY(split_rows(c, dy, y.ld, (int64_t)c.B * 4 * H * W, C, BP(c, b_dyS)));
+            bd_conv3x3_ps_wgrad_desc w = {};
+            w.B = c.B; w.H = 2 * H; w.W = 2 * W; w.Cin = C; w.Cout = C;
+            w.x_split = U16(BP(c, b_xuS)); w.ldx = C; w.dy_split = U16(BP(c, b_dyS)); w.lddy = C;
+            w.dw = c.grads + pw; w.db = c.grads + pb;
+            BD_TRY(conv_pw(c, w));
+            bd_conv3x3_ps_desc g = {};
+            g.B = c.B; g.H = 2 * H; g.W = 2 * W; g.K = C; g.N = C; g.direction = -1;
+            g.x_split = U16(BP(c, b_dyS)); g.ldx = C; g.w_split = c.wT_split + 2 * pw; g.out_scale = 1.f;
+            g.y = BP(c, b_du); g.ldy = C;
+            BD_TRY(conv_p(c, g));
+        } else {
+            bd_conv3x3_wgrad_desc w = {};
+            w.B = c.B; w.Hs = H; w.Ws = W; w.Cin = C; w.Cout = C; w.stride = 1; w.pad_t = 1; w.pad_l = 1; w.ups = 1; w.Ho = 2 * H; w.Wo = 2 * W;
+            w.x = VP(c, x); w.ldx = x.ld; w.dy = dy; w.lddy = y.ld; w.dw = c.grads + pw; w.db = c.grads + pb;
+            BD_TRY(conv_w(c, w));
+            bd_conv3x3_dgrad_desc g = {};
+            g.B = c.B; g.Hs = H; g.Ws = W; g.Cin = C; g.Cout = C; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.ups = 1; g.Ho = 2 * H; g.Wo = 2 * W;
+            g.dy = dy; g.lddy = y.ld; g.w = c.params + pw; g.dx = BP(c, b_du); g.lddx = C;
+            BD_TRY(conv_d(c, g));
+        }
         if (c.dry) return (int)BD_OK;
         return bd_sum2x2(BP(c, b_du), C, GP(c, x), x.ld, c.B, H, W, C, acc, (bd_stream_t)c.st);
     });
@@ -1004,7 +1035,7 @@ extern "C" size_t bd_unet_workspace_bytes(bd_unet* u, int B, int training) {
     if (!u || B <= 0) return 0;
     u->layout(B, training);
     return (size_t)(u->value_floats + u->grad_floats + u->scratch_floats) * sizeof(float) + u->opws_bytes + 256 +
-           wsplit_bytes(u) + align_up(u->opws_bytes, 256);   // + the side stream's op workspace
+           2 * wsplit_bytes(u) + align_up(u->opws_bytes, 256);   // + transposed conv-weight planes + the side stream's op workspace
 }
 
 static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, size_t workspace_bytes) {
@@ -1021,7 +1052,8 @@ static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, si
     if (u->cfg.compute_mode == BD_MODE_BF16X3) {
         c.w_split = reinterpret_cast<const uint16_t*>(c.opws + align_up(u->opws_bytes, 256));
     }
-    c.opws2 = c.opws + align_up(u->opws_bytes, 256) + wsplit_bytes(u);
+    c.opws2 = c.opws + align_up(u->opws_bytes, 256) + 2 * wsplit_bytes(u);
+    if (c.w_split) c.wT_split = reinterpret_cast<const uint16_t*>(c.opws + align_up(u->opws_bytes, 256) + wsplit_bytes(u));
     c.ginit.assign(u->bufs.size(), 0);
     return BD_OK;
 }
@@ -1050,7 +1082,14 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
     c.training = training != 0;
     if (c.w_split)   // split the weights once; forward convs and (same workspace) the backward dgrads read the copy
         BD_TRY(bd_split_bf16(params, (int64_t)wsplit_elems(u), const_cast<uint16_t*>(c.w_split), stream));
+    // transposed split planes of the 3x3 conv weights for the backward's data gradients: one launch, needed only in training
+    auto transpose_weights = [&](hipStream_t st) -> int {
+        if (!training || !c.wT_split || u->wt_off.empty()) return BD_OK;
+        return split_wt_batched(params, const_cast<uint16_t*>(c.wT_split), u->wt_off.data(), u->wt_cin.data(), u->wt_cout.data(),
+                                (int)u->wt_off.size(), st);
+    };
     if (!u->aux_enabled || B < 32) {
+        BD_TRY(transpose_weights(c.st));
         for (auto& f : u->fwd) BD_TRY(f(c));
         return BD_OK;
     }
@@ -1067,6 +1106,7 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
     c2.x = x + (int64_t)Bh * hw * ldx; c2.t = t + (int64_t)Bh * t_stride; c2.out = out + (int64_t)Bh * hw * ldo;
     BD_HIP_TRY(hipEventRecord(u->aux_ev_fork, c.st));
     BD_HIP_TRY(hipStreamWaitEvent(c2.st, u->aux_ev_fork, 0));
+    BD_TRY(transpose_weights(c2.st));   // memory-bound, off the first pipeline's critical path
     for (auto& f : u->fwd) {
         BD_TRY(f(c));
         BD_TRY(f(c2));

@@ -256,6 +256,15 @@ def split_rows(x, out=None):
     return out
 
 
+def split_rows_ups2(x):
+    """x [B,H,W,C] fp32 -> split planes of the nearest x2 upsampling, int16 [B*2H*2W, C/32, 2, 32]."""
+    lib = L.load(); _need_cuda(x)
+    B, H, W, Cc = x.shape
+    out = torch.empty(B * 4 * H * W, Cc // 32, 2, 32, dtype=torch.int16, device=x.device)
+    L.check(lib.bd_split_rows_ups2(L.ptr(x), _ld(x), B, H, W, Cc, L.ptr(out), Cc, L.stream()), "bd_split_rows_ups2")
+    return out
+
+
 def split_wT(w):
     """conv weight [Cout,3,3,Cin] fp32 -> split planes of the transpose [Cin,3,3,Cout] (for the data gradient)."""
     lib = L.load(); _need_cuda(w)

@@ -278,7 +278,7 @@ def main():
     log("warmup done")
     # roofline: hipEvent pairs around every igemm launch of every PROF_EVERY-th timed step (the pairs cost ~5 % of
     # a step when recorded on all of them, so the timed region samples)
-    PROF_EVERY = 4
+    PROF_EVERY = 10
     prof_steps = 0
     if not args.no_prof:
         lib.bd_prof_reset()

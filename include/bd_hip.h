@@ -272,6 +272,8 @@ size_t bd_conv3x3_workspace_bytes(int B, int Ho, int Wo, int Hs, int Ws, int Cin
  * resnet.py:493,514 on the large layers.  H, W powers of two; K % 32 == 0; N % 128 == 0.
  * ------------------------------------------------------------------------------------------------ */
 int bd_split_rows(const float* src, int64_t ld_src, int64_t rows, int C, uint16_t* dst, int64_t ld_dst, bd_stream_t stream);
+/* src [B,H,W,C] fp32 -> split planes of its nearest-neighbour x2 upsampling [B,2H,2W,C] (Upsample2D, resnet.py:126-161) */
+int bd_split_rows_ups2(const float* src, int64_t ld_src, int B, int H, int W, int C, uint16_t* dst, int64_t ld_dst, bd_stream_t stream);
 /* W[Cout][3][3][Cin] fp32 -> split planes of Wt[Cin][3][3][Cout] (rows = ci, k = tap*Cout + co) */
 int bd_split_wt(const float* w, int Cin, int Cout, uint16_t* out, bd_stream_t stream);
 typedef struct {
