@@ -97,7 +97,10 @@ struct bd_unet {
     std::vector<Step> fwd;
     struct BStep { Step fn; int seg; int group; };
     std::vector<BStep> bwd;  // in FORWARD emission order; executed reversed
-    struct Seg { int64_t lo, hi; };
+    // gradient ranges that are final when a backward segment has run: the segment's own parameters [lo, hi) plus, for the
+    // blocks that hold resnets, their rows of the batched time_emb_proj weight / bias (which live in the time-embedding
+    // segment's range of the flat buffer but get their gradient inside the resnet's backward)
+    struct Seg { int64_t lo, hi; int64_t tw_lo = -1, tw_hi = -1, tb_lo = -1, tb_hi = -1; };
     std::vector<Seg> segs;   // indexed by segment id (backward order)
     int cur_seg = 0, cur_group = 0;
     // layout cache
@@ -348,10 +351,10 @@ void bd_unet::node_time_embed() {
     const int64_t pw2 = add_param("time_embedding.linear_2.weight", {T, T});
     const int64_t pb2 = add_param("time_embedding.linear_2.bias", {T});
     // batched time_emb_proj of every resnet: one [sumC, T] weight, one [sumC] bias (aliases registered per resnet)
-    nparams = (nparams + 31) / 32 * 32;
+    segs[cur_seg].hi = nparams;          // the time segment proper: linear_1 / linear_2 (the batched projection below is
+    nparams = (nparams + 31) / 32 * 32;   // reduced row range by row range with the blocks that own the resnets)
     p_tw = nparams; nparams += (int64_t)sumC * T;
     p_tb = nparams; nparams += sumC;
-    segs[cur_seg].hi = nparams;
     const int b_tsin = new_buf(c0, 0, R_VALUE), b_e1 = new_buf(T, 0, R_VALUE), b_e1s = new_buf(T, 0, R_VALUE);
     const int b_emb = new_buf(T, 0, R_VALUE);
     b_embs = new_buf(T, 0, R_VALUE);
@@ -370,7 +373,7 @@ void bd_unet::node_time_embed() {
     });
     Bk([=](Ctx& c) {
         float* dtp = BP(c, b_dtproj);
-        BD_TRY(linear_wgrad(c, dtp, sumC, BP(c, b_embs), T, c.grads + p_tw, c.B, sumC, T, c.grads + p_tb));
+        // (the weight / bias gradient of the batched projection is produced resnet by resnet, see node_resnet)
         BD_TRY(linear_dgrad(c, dtp, sumC, c.params + p_tw, BP(c, b_dembs), T, c.B, sumC, T, 0));
         if (!c.dry) BD_TRY(bd_silu_bwd(BP(c, b_emb), BP(c, b_dembs), BP(c, b_demb), (int64_t)c.B * T, 0, (bd_stream_t)c.st));
         BD_TRY(linear_wgrad(c, BP(c, b_demb), T, BP(c, b_e1s), T, c.grads + pw2, c.B, T, T, c.grads + pb2));
@@ -409,6 +412,19 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
     const int64_t pc1w = add_param(pre + "conv1.weight", {Cout, Cin, 3, 3}, 1), pc1b = add_param(pre + "conv1.bias", {Cout});
     alias_param(pre + "time_emb_proj.weight", p_tw + (int64_t)toff * T, {Cout, T});
     alias_param(pre + "time_emb_proj.bias", p_tb + toff, {Cout});
+    {   // this block's rows of the batched projection become final with this segment (resnets of a block are consecutive)
+        Seg& sg = segs[cur_seg];
+        const int64_t wlo = p_tw + (int64_t)toff * T, whi = wlo + (int64_t)Cout * T, blo = p_tb + toff, bhi = blo + Cout;
+        if (sg.tw_lo < 0) { sg.tw_lo = wlo; sg.tw_hi = whi; sg.tb_lo = blo; sg.tb_hi = bhi; }
+        else {
+            if (wlo < sg.tw_lo) sg.tw_lo = wlo;
+            if (whi > sg.tw_hi) sg.tw_hi = whi;
+            if (blo < sg.tb_lo) sg.tb_lo = blo;
+            if (bhi > sg.tb_hi) sg.tb_hi = bhi;
+        }
+    }
+    const int b_embs_ = b_embs, T_ = T;
+    const int64_t p_tw_ = p_tw, p_tb_ = p_tb;
     const int64_t pn2w = add_param(pre + "norm2.weight", {Cout}), pn2b = add_param(pre + "norm2.bias", {Cout});
     const int64_t pc2w = add_param(pre + "conv2.weight", {Cout, Cout, 3, 3}, 1), pc2b = add_param(pre + "conv2.bias", {Cout});
     int64_t psw = -1, psb = -1;
@@ -537,6 +553,9 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             if (ps1) { d.dx_split = U16(BP(c, b_dh1S)); d.lddxs = Cout; }
             if (!c.dry) BD_TRY(bd_gn_bwd(&d, (bd_stream_t)c.st));
         }
+        // this resnet's rows of the batched time_emb_proj weight / bias gradient: dW = dtproj[:, rows]^T embs (resnet.py:571)
+        BD_TRY(linear_wgrad(c, BP(c, b_dtproj) + toff, sumC_, BP(c, b_embs_), T_, c.grads + p_tw_ + (int64_t)toff * T_, c.B, Cout, T_,
+                            c.grads + p_tb_ + toff));
         if (ps1) {
             bd_conv3x3_ps_wgrad_desc w1 = {};
             w1.B = c.B; w1.H = H; w1.W = W; w1.Cin = Cin; w1.Cout = Cout;
@@ -1117,6 +1136,19 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
 }
 
 extern "C" int bd_unet_num_segments(const bd_unet* u) { return u ? (int)u->segs.size() : 0; }
+extern "C" int bd_unet_segment_num_ranges(const bd_unet* u, int seg) {
+    if (!u || seg < 0 || seg >= (int)u->segs.size()) return 0;
+    return u->segs[seg].tw_lo >= 0 ? 3 : 1;
+}
+extern "C" int bd_unet_segment_range_k(const bd_unet* u, int seg, int k, int64_t* lo, int64_t* hi) {
+    BD_CHECK(u && seg >= 0 && seg < (int)u->segs.size() && k >= 0 && k < bd_unet_segment_num_ranges(u, seg), BD_ERR_INVALID,
+             "bd_unet_segment_range_k: segment / range out of range");
+    const bd_unet::Seg& s = u->segs[seg];
+    const int64_t l = k == 0 ? s.lo : (k == 1 ? s.tw_lo : s.tb_lo), h = k == 0 ? s.hi : (k == 1 ? s.tw_hi : s.tb_hi);
+    if (lo) *lo = l;
+    if (hi) *hi = h;
+    return BD_OK;
+}
 extern "C" int bd_unet_segment_range(const bd_unet* u, int seg, int64_t* lo, int64_t* hi) {
     BD_CHECK(u && seg >= 0 && seg < (int)u->segs.size(), BD_ERR_INVALID, "bd_unet_segment_range: segment out of range");
     if (lo) *lo = u->segs[seg].lo;

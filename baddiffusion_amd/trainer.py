@@ -48,13 +48,22 @@ class DPReducer:
 
 
 def plan_segments(model):
-    """[(lo, hi)] ranges of the flat gradient in the order backward finalises them."""
+    """[(lo, hi)] main ranges of the flat gradient in the order backward finalises them."""
+    return [r[0] for r in plan_segment_ranges(model)]
+
+
+def plan_segment_ranges(model):
+    """Per backward segment, ALL ranges of the flat gradient that are final once it has run: its own parameters and, for
+    blocks with resnets, their rows of the batched time_emb_proj weight / bias."""
     lib = L.load()
     out = []
     lo, hi = ctypes.c_int64(), ctypes.c_int64()
     for s in range(lib.bd_unet_num_segments(model._plan)):
-        L.check(lib.bd_unet_segment_range(model._plan, s, ctypes.byref(lo), ctypes.byref(hi)), "bd_unet_segment_range")
-        out.append((lo.value, hi.value))
+        rs = []
+        for k in range(lib.bd_unet_segment_num_ranges(model._plan, s)):
+            L.check(lib.bd_unet_segment_range_k(model._plan, s, k, ctypes.byref(lo), ctypes.byref(hi)), "bd_unet_segment_range_k")
+            rs.append((lo.value, hi.value))
+        out.append(rs)
     return out
 
 
@@ -83,6 +92,7 @@ class TrainEngine:
         self.micro = 0
         self._lib = L.load()
         self._nseg = self._lib.bd_unet_num_segments(model._plan)
+        self._seg_ranges = plan_segment_ranges(model)
         self.alphas, self.alphas_cumprod = noise_sched.device_tables(dev)
         self.sync_state()
 
@@ -117,7 +127,8 @@ class TrainEngine:
                 "bd_unet_backward_segment")
             # the collective waits (on RCCL's stream) for the kernels enqueued so far, then overlaps with the
             # next segments' kernels; 143 MB in total per step for the CIFAR UNet
-            red.reduce_range(lo.value, hi.value)
+            for (rlo, rhi) in self._seg_ranges[s]:
+                red.reduce_range(rlo, rhi)
         red.finish()
         model._release_ws(ws)
         return loss

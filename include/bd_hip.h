@@ -386,7 +386,11 @@ int bd_unet_backward(bd_unet* u, int B, const float* params, const float* x, int
  * `stream` with events, once per node -- still hipGraph-capturable and free of host synchronisation).  0 disables it. */
 int bd_unet_set_aux_stream(bd_unet* u, int enabled);
 int bd_unet_num_segments(const bd_unet* u);
-int bd_unet_segment_range(const bd_unet* u, int seg, int64_t* lo, int64_t* hi);   /* host-only query */
+int bd_unet_segment_range(const bd_unet* u, int seg, int64_t* lo, int64_t* hi);   /* host-only query: the main range */
+/* a segment finalises 1 or 3 ranges of the flat gradient: k = 0 its own parameters, k = 1 / 2 its resnets' rows of the
+ * batched time_emb_proj weight / bias (stored with the time embedding, computed in the resnets' backward) */
+int bd_unet_segment_num_ranges(const bd_unet* u, int seg);
+int bd_unet_segment_range_k(const bd_unet* u, int seg, int k, int64_t* lo, int64_t* hi);
 int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float* params, const float* x, int64_t ldx,
                              const float* dout, int64_t lddo, float* grads, void* workspace, size_t workspace_bytes,
                              bd_stream_t stream, int64_t* ready_lo, int64_t* ready_hi);

@@ -23,7 +23,7 @@ def _worker(rank, world, port, ret):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    from baddiffusion_amd.trainer import DPReducer, plan_segments
+    from baddiffusion_amd.trainer import DPReducer, plan_segment_ranges, plan_segments
     from baddiffusion_amd.unet import unet_from_config
     from oracle import sched_ref, train_ref
     from oracle import unet_ref as U
@@ -39,8 +39,14 @@ def _worker(rank, world, port, ret):
     red = DPReducer(flat)
     segs = plan_segments(model)
     assert segs[0][1] >= segs[-1][1] and segs[-1][0] == 0          # backward order: output side first
-    for lo, hi in segs:
-        red.reduce_range(lo, hi)
+    ranges = plan_segment_ranges(model)
+    cover = sorted(r for rs in ranges for r in rs)
+    assert cover[0][0] == 0 and all(a[1] <= b[0] and b[0] - a[1] < 64 for a, b in zip(cover, cover[1:]))   # exact partition (+ alignment pads)
+    assert cover[-1][1] >= model.num_flat - 4
+    assert sum(hi - lo for lo, hi in ranges[-1]) * 4 < 10e6        # what is still exposed after the last dgrad: < 10 MB
+    for rs in ranges:                                              # the order TrainEngine issues them in
+        for lo, hi in rs:
+            red.reduce_range(lo, hi)
     red.finish()
     if rank == 0:
         _, Gfull = train_ref.loss_and_grads(cfg, P, a, ac, x0, R, t, eps)

@@ -299,10 +299,13 @@ def test_backward_segments_equal_whole(bd):
         L.check(lib.bd_unet_backward_segment(m._plan, s, 2, m.flat.data_ptr(), x.data_ptr(), 3, dout.data_ptr(), 3, g2.data_ptr(),
                                              ws2.data_ptr(), ws2.numel(), L.stream(), ctypes.byref(lo), ctypes.byref(hi)))
         assert 0 <= lo.value < hi.value <= m.num_flat
-        assert not covered[lo.value:hi.value].any()
-        # the range reported ready must already be final
+        # every range reported ready (the segment's own parameters + its resnets' rows of the batched time_emb_proj)
+        # must already be final, and the ranges partition the flat gradient
         torch.cuda.synchronize()
-        assert torch.equal(g2[lo.value:hi.value], g1[lo.value:hi.value]), s
-        covered[lo.value:hi.value] = True
+        for k in range(lib.bd_unet_segment_num_ranges(m._plan, s)):
+            L.check(lib.bd_unet_segment_range_k(m._plan, s, k, ctypes.byref(lo), ctypes.byref(hi)))
+            assert not covered[lo.value:hi.value].any()
+            assert torch.equal(g2[lo.value:hi.value], g1[lo.value:hi.value]), (s, k)
+            covered[lo.value:hi.value] = True
     assert torch.equal(g1, g2)
     assert int((~covered).sum()) < 64      # only alignment padding is uncovered
