@@ -155,6 +155,7 @@ SIGNATURES = {
     "bd_sumsq": (i32, [vp, i64, vp, vp, vp]),
     "bd_adam_clip": (i32, [vp, vp, vp, vp, i64, vp, f64, f64, f64, f64, f64, i32, vp, vp]),
     "bd_prof_enable": (i32, [i32]),
+    "bd_prof_enabled": (i32, []),
     "bd_prof_reset": (i32, []),
     "bd_prof_num_classes": (i32, []),
     "bd_prof_get": (i32, [i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]),

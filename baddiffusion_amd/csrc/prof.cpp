@@ -63,6 +63,7 @@ static void drain() {
 using namespace bd;
 
 extern "C" int bd_prof_enable(int on) { g_on = on != 0; return BD_OK; }
+extern "C" int bd_prof_enabled(void) { return g_on ? 1 : 0; }
 extern "C" int bd_prof_reset(void) {
     drain();
     g_cls.clear(); g_idx.clear();

@@ -197,6 +197,8 @@ def main():
                          "ddim50 / ddpm1000 = CIFAR sampling loops (samples/s, --batch samples per GPU, --steps ignored) -- side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--graph", type=int, default=int(os.environ.get("BD_TRAIN_GRAPH", "0")),
+                    help="1: replay the train step as one hipGraph (TrainEngine(use_graph=True)); sampled roofline steps stay eager")
     ap.add_argument("--mode", default=os.environ.get("BD_COMPUTE_MODE", "bf16x3"), choices=["f32", "bf16x3"],
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (hi+lo, 3 MFMAs, ~2^-16 rel. error)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
@@ -238,7 +240,7 @@ def main():
     model = UNet2DModel(**topo, compute_mode=args.mode).to(dev)
     sched = DDPMScheduler(num_train_timesteps=1000)
     B = args.batch if args.batch > 0 else (4 if celeba else 128)
-    eng = TrainEngine(model, sched, lr=2e-4, lr_warmup_steps=500, num_training_steps=469 * 50)
+    eng = TrainEngine(model, sched, lr=2e-4, lr_warmup_steps=500, num_training_steps=469 * 50, use_graph=bool(args.graph))
 
     # synthetic CIFAR-like data, resident in HBM: uint8 images, BOX_14 trigger, CORNER target (HAT stand-in:
     # static/fedora-hat.png is a reference asset and does not travel), poison flags i % 10 == 0

@@ -401,6 +401,7 @@ int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float* params, co
  * flops = 2*M*N*K algorithmic ; bytes = unique operand + output bytes (algorithmic, fp32).
  * ------------------------------------------------------------------------------------------------ */
 int bd_prof_enable(int on);
+int bd_prof_enabled(void);   /* 1 while launches are being bracketed by events (such launches cannot be graph-captured) */
 int bd_prof_reset(void);
 int bd_prof_num_classes(void);
 int bd_prof_get(int cls, const char** name, int64_t* launches, double* total_ms, double* flops, double* bytes);

@@ -226,6 +226,35 @@ def test_adam_clip_dev_matches_host_scalar_form(gpu):
         assert torch.equal(p1, p2) and torch.equal(m1, m2) and torch.equal(v1, v2) and float(n1) == float(n2)
 
 
+def test_train_step_graph_replay_bit_identical(gpu):
+    """TrainEngine(use_graph=True): the whole step replayed as one hipGraph (device-resident Adam scalars, static input
+    buffers) leaves bit-identical weights, moments, loss and gradient norm compared with the eager launch sequence,
+    over a warm-up step, the capture step and two replays with different inputs and learning rates."""
+    from baddiffusion_amd.dataset import Backdoor
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    cfg = C.SMALL_CFGS["small"]
+    B, S = 6, 16
+    bd = Backdoor(root=None)
+    trig = bd.get_trigger("BOX_14", 3, S).cuda(); tgt = bd.get_target("CORNER", trig.cpu()).cuda()
+    m1, m2 = make_model(cfg, 7, gpu), make_model(cfg, 7, gpu)
+    kw = dict(lr=1e-3, lr_warmup_steps=2, num_training_steps=10)
+    e1, e2 = TrainEngine(m1, DDPMScheduler(), use_graph=False, **kw), TrainEngine(m2, DDPMScheduler(), use_graph=True, **kw)
+    assert e2.use_graph and not e1.use_graph
+    data = _u8_batch(40, S, 41).cuda()
+    g = torch.Generator().manual_seed(42)
+    for step in range(4):
+        rows = torch.randint(0, 40, (B,), generator=g).cuda()
+        flip = (torch.rand(B, generator=g) < 0.5).to(torch.uint8).cuda()
+        pois = (torch.rand(B, generator=g) < 0.3).cuda()
+        eps = torch.randn(B, 3, S, S, generator=g).cuda(); t = torch.randint(0, 1000, (B,), generator=g).cuda()
+        l1 = e1.train_step(data, pois, trig, tgt, eps, t, row_index=rows, flip=flip)
+        l2 = e2.train_step(data, pois, trig, tgt, eps, t, row_index=rows, flip=flip)
+        assert float(l1) == float(l2) and float(e1.grad_norm) == float(e2.grad_norm), step
+        assert torch.equal(m1.flat, m2.flat) and torch.equal(e1.m, e2.m) and torch.equal(e1.v, e2.v), step
+    assert e1.opt_step == e2.opt_step == 4 and any(v["graph"] is not None for v in e2._graphs.values())
+
+
 # ------------------------------------------------------------------------------------------------ 1(g)
 def test_fused_gather_and_flip(gpu):
     """row_index / flip of bd_poison_qsample == indexing the resident array and torch.flip along W
