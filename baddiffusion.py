@@ -334,10 +334,31 @@ def checkpoint(config, engine, pipeline, cur_epoch, cur_step):
     os.makedirs(config.ckpt_path, exist_ok=True)
     torch.save({"m": engine.m.cpu(), "v": engine.v.cpu(), "opt_step": engine.opt_step, "micro": engine.micro},
                os.path.join(config.ckpt_path, "optimizer.bin"))
-    torch.save({"epoch": cur_epoch, "step": cur_step}, config.data_ckpt_path)
+    # + the random-number state, so that a resumed run draws the noise / timesteps the uninterrupted run would have drawn
+    torch.save({"epoch": cur_epoch, "step": cur_step, "cpu_rng": torch.get_rng_state(),
+                "cuda_rng": torch.cuda.get_rng_state() if torch.cuda.is_available() else None}, config.data_ckpt_path)
     pipeline.save_pretrained(config.output_dir)
     if config.is_save_all_model_epochs:
         pipeline.save_pretrained(os.path.join(config.output_dir, config.ep_model_dir, f"ep{cur_epoch}"))
+
+
+def restore_training_state(config, engine):
+    """baddiffusion.py:336-342 (accelerator.load_state): Adam moments, optimizer step counters and the RNG state written by
+    checkpoint(); the weights themselves come from the diffusers-layout directory (get_trained).  Returns (epoch, step)."""
+    opt_file = os.path.join(config.ckpt_path, "optimizer.bin")
+    if os.path.exists(opt_file):
+        st = torch.load(opt_file, map_location="cpu")
+        engine.m.copy_(st["m"]); engine.v.copy_(st["v"]); engine.opt_step = st["opt_step"]; engine.micro = st["micro"]
+        engine.sync_state()
+    epoch = step = 0
+    if os.path.exists(config.data_ckpt_path):
+        st = torch.load(config.data_ckpt_path, map_location="cpu")
+        epoch, step = st["epoch"], st["step"]
+        if st.get("cpu_rng") is not None:
+            torch.set_rng_state(st["cpu_rng"])
+        if st.get("cuda_rng") is not None and torch.cuda.is_available():
+            torch.cuda.set_rng_state(st["cuda_rng"])
+    return epoch, step
 
 
 def train_loop(config, model, noise_sched, get_pipeline, dsl, device, world, rank, start_epoch=0, start_step=0):
@@ -347,11 +368,8 @@ def train_loop(config, model, noise_sched, get_pipeline, dsl, device, world, ran
     engine = TrainEngine(model, noise_sched, lr=config.learning_rate, lr_warmup_steps=config.lr_warmup_steps,
                          num_training_steps=num_batch * config.epoch // config.gradient_accumulation_steps,
                          grad_accum_steps=config.gradient_accumulation_steps)
-    opt_file = os.path.join(config.ckpt_path, "optimizer.bin")
-    if config.mode == MODE_RESUME and os.path.exists(opt_file):
-        st = torch.load(opt_file, map_location="cpu")
-        engine.m.copy_(st["m"]); engine.v.copy_(st["v"]); engine.opt_step = st["opt_step"]; engine.micro = st["micro"]
-        engine.sync_state()
+    if config.mode == MODE_RESUME:
+        restore_training_state(config, engine)
     dsl.to_device(device)
     trigger, target = dsl.trigger.to(device), dsl.target.to(device)
     log = open(os.path.join(config.output_dir, "log.jsonl"), "a") if rank == 0 else None

@@ -434,3 +434,48 @@ def test_cli_train_loop_two_ranks(gpu, tmp_path):
     assert cfgj["pretrained"] is False
     log = [json.loads(ln) for ln in open(os.path.join(runs[0], "log.jsonl"))]
     assert log and np.isfinite(log[0]["loss"])
+
+
+def test_checkpoint_resume_equals_straight_run(gpu, tmp_path):
+    """--mode resume (baddiffusion.py:336-342, 558-570): 2 steps -> checkpoint() -> a NEW model / engine restored from the
+    written directory (diffusers-layout weights, optimizer.bin, data.ckpt incl. RNG state) -> 1 step  ==  3 straight steps,
+    bit for bit (weights, Adam moments, step counters)."""
+    import baddiffusion as cli
+    from baddiffusion_amd.dataset import Backdoor
+    from baddiffusion_amd.model import DiffuserModelSched
+    from baddiffusion_amd.pipelines import DDPMPipeline
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    cfg = C.SMALL_CFGS["small"]
+    B, S = 4, 16
+    bd = Backdoor(root=None)
+    trig = bd.get_trigger("BOX_14", 3, S).cuda(); tgt = bd.get_target("CORNER", trig.cpu()).cuda()
+    data = _u8_batch(16, S, 51).cuda()
+    pois = torch.tensor([1, 0, 0, 0], dtype=torch.bool).cuda()
+    kw = dict(lr=1e-3, lr_warmup_steps=2, num_training_steps=10)
+
+    def one_step(engine):      # noise / timesteps from the GLOBAL generators, like the CLI's loop body (:596, :600)
+        rows = torch.randint(0, 16, (B,)).cuda()
+        eps = torch.randn(B, 3, S, S, device="cuda"); t = torch.randint(0, 1000, (B,), device="cuda")
+        return engine.train_step(data, pois, trig, tgt, eps, t, row_index=rows)
+
+    config = cli.TrainingConfig()
+    config.output_dir = str(tmp_path / "run"); os.makedirs(config.output_dir)
+    config.ckpt_path = os.path.join(config.output_dir, config.ckpt_dir)
+    config.data_ckpt_path = os.path.join(config.output_dir, config.data_ckpt_dir)
+    config.is_save_all_model_epochs = False
+    torch.manual_seed(77)
+    m = make_model(cfg, 7, gpu); sched = DDPMScheduler(clip_sample=False)
+    e = TrainEngine(m, sched, **kw)
+    one_step(e); one_step(e)
+    cli.checkpoint(config, e, DDPMPipeline(m, sched), 0, 2)
+    one_step(e)
+    torch.cuda.synchronize()
+    # the resumed process
+    torch.manual_seed(12345)      # whatever state a fresh process has: restore_training_state must overwrite it
+    m2, sched2, _ = DiffuserModelSched.get_trained(config.output_dir, clip_sample=None)
+    m2 = m2.to(gpu)
+    e2 = TrainEngine(m2, sched2, **kw)
+    assert cli.restore_training_state(config, e2) == (0, 2) and e2.opt_step == 2
+    one_step(e2)
+    assert torch.equal(m2.flat, m.flat) and torch.equal(e2.m, e.m) and torch.equal(e2.v, e.v) and e2.opt_step == e.opt_step == 3

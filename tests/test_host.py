@@ -172,3 +172,48 @@ def test_dataset_modes_and_rank_sharding():
     # flip flags are drawn per global row, so world = 1 and world = 3 flip the same images
     one = torch.cat([b[0] for b in d.device_batches(shuffle=True, epoch=1, rank=0, world=1, flip=True)])
     assert one.shape[0] == n
+
+
+def test_reference_checkpoint_layout(tmp_path):
+    """G9: the directory the REFERENCE's save_pretrained wrote (tests/golden/ckpt, captured by make_ckpt_fixture.py from
+    pipeline_utils.py:527-600 / modeling_utils.py:287-301): the product loads it (JSON files verbatim, weights
+    re-materialised from the same seed and checked against the stored probes) and saves a directory with the same tree,
+    the same JSON keys / values and the same tensor manifest (keys, order, shapes, dtypes, contiguity)."""
+    import json
+    import shutil
+    import numpy as np
+    from baddiffusion_amd.model import DiffuserModelSched
+    from oracle import unet_ref as U
+    from tests.golden import cases as C
+    src = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "ckpt")
+    man = json.load(open(os.path.join(src, "manifest.json")))
+    probe = np.load(os.path.join(src, "weights_probe.npz"))
+    d = str(tmp_path / "ref")
+    shutil.copytree(src, d)
+    P = U.gen_params(C.SMALL_CFGS[man["config"]], man["seed"])
+    # (key ORDER is a registration-order artefact of nn.Module -- the reference lists up_blocks before mid_block and
+    #  attentions before resnets -- and no consumer of a state dict depends on it: compared as a set)
+    assert sorted(e["key"] for e in man["state_dict"]) == sorted(P.keys())
+    for e in man["state_dict"]:      # the regenerated weights are the ones the reference stored
+        v = P[e["key"]]
+        assert list(v.shape) == e["shape"] and str(v.dtype) == e["dtype"]
+        np.testing.assert_allclose(np.concatenate([v.flatten()[:4].double().numpy(), [float(v.double().sum())]]), probe[e["key"]], rtol=1e-12)
+    torch.save({k: v.clone() for k, v in P.items()}, os.path.join(d, "unet", "diffusion_pytorch_model.bin"))
+    model, sched, get_pipeline = DiffuserModelSched.get_trained(d, clip_sample=None)
+    assert model.pretrained and type(sched).__name__ == "DDPMScheduler"
+    assert sched.config.variance_type == "fixed_large" and sched.config.clip_sample is False
+    sd = model.state_dict()
+    assert sorted(sd.keys()) == sorted(P.keys()) and all(torch.equal(sd[k].cpu(), P[k]) for k in P)
+    out = str(tmp_path / "out")
+    get_pipeline(model, sched).save_pretrained(out)
+    tree = sorted(os.path.relpath(os.path.join(r, f), out) for r, _, fs in os.walk(out) for f in fs)
+    assert tree == man["tree"]
+    for rel in tree:
+        if rel.endswith(".json"):
+            ours, ref = json.load(open(os.path.join(out, rel))), json.load(open(os.path.join(src, rel)))
+            assert ours == ref, (rel, {k: (ours.get(k), ref.get(k)) for k in set(ours) | set(ref) if ours.get(k) != ref.get(k)})
+    sd2 = torch.load(os.path.join(out, "unet", "diffusion_pytorch_model.bin"), map_location="cpu")
+    key = lambda e: e["key"]
+    assert sorted(({"key": k, "shape": list(v.shape), "dtype": str(v.dtype), "contiguous": bool(v.is_contiguous())} for k, v in sd2.items()),
+                  key=key) == sorted(man["state_dict"], key=key)
+    assert all(torch.equal(sd2[k], P[k]) for k in P)
