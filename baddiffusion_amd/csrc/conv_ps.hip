@@ -335,6 +335,169 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps_kernel(PsParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Wave-specialised form of the 256 x 128 kernel: 12 waves = 8 COMPUTE waves (the 4 x 2 grid of 64 x 64 tiles: LDS
+// fragment reads + MFMAs, no VMEM instruction at all) + 4 LOADER waves (one per SIMD; each owns 8 of the 32 A row groups
+// and 4 of the 16 B row groups: 12 DMA instructions per K chunk, their address arithmetic and the counted vmcnt).
+// An LDS-DMA instruction costs its wave 60-180 issue cycles (MI355X_MICROARCH.md, per-instruction constants); in the
+// lock-step kernel those cycles sit in the MFMA waves' own instruction streams, here they belong to a wave that has
+// nothing else to do.  Same ring, same barrier protocol, same arithmetic (bit-identical).
+constexpr int PS_WS_NT = 768;
+
+template <int EPI>
+__global__ __launch_bounds__(PS_WS_NT, 3) void conv_ps_ws_kernel(PsParams p) {
+    __shared__ __attribute__((aligned(128))) char smem[PS_LDS_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int tm, tn;
+    {
+        const unsigned L = blockIdx.x, T = gridDim.x, q = T >> 3;
+        const unsigned j = L < (q << 3) ? (L & 7) * q + (L >> 3) : L;
+        tm = j / p.tiles_n;
+        tn = j - tm * p.tiles_n;
+    }
+    const int m0 = tm * PS_BM, n0 = tn * PS_BN;
+    const int nchunks = 9 * (p.C >> 5);
+    const int trips = nchunks / 3;
+    char* const st0 = smem;
+    char* const st1 = smem + PS_STAGE_BYTES;
+    char* const st2 = smem + 2 * PS_STAGE_BYTES;
+
+    if (wave >= 8) {
+        // ------------------------------------------------------------------ loader wave lw = 0..3
+        const int lw = wave - 8;
+        const int dr = lane >> 3, ps = lane & 7;
+        const char* ap[8];
+        int vm[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int r = (lw + 4 * j) * 8 + dr;
+            const int m = m0 + r;
+            const int x = m & (p.W - 1), y = (m >> p.lw) & (p.H - 1);
+            int mask = 0;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + p.sign * (t / 3 - 1), xx = x + p.sign * (t % 3 - 1);
+                if ((unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W) mask |= 1 << t;
+            }
+            vm[j] = m < p.M ? mask : 0;
+            ap[j] = p.a + (long long)m * p.lda * 4 + ((ps ^ ps_swz(r)) << 4);
+        }
+        const char* wp[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int r = (lw + 4 * j) * 8 + dr;
+            int n = n0 + r;
+            if (n >= p.N) n = p.N - 1;
+            wp[j] = p.w + (long long)n * 36 * p.C + ((ps ^ ps_swz(r)) << 4);
+        }
+        const int pix_bytes = (int)p.lda * 4;
+        int q_kh = 0, q_kw = 0, q_bit = 1;
+        int q_aoff = -p.sign * (p.W + 1) * pix_bytes, q_woff = 0;
+        auto issue = [&](char* stage) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+                ps_dma16((vm[j] & q_bit) ? ap[j] + q_aoff : reinterpret_cast<const char*>(kPsZero), stage + (lw + 4 * j) * 1024);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) ps_dma16(wp[j] + q_woff, stage + PS_A_BYTES + (lw + 4 * j) * 1024);
+            q_bit <<= 1;
+            q_woff += p.C * 4;
+            q_aoff += p.sign * pix_bytes;
+            if (++q_kw == 3) {
+                q_kw = 0;
+                q_aoff += p.sign * (p.W - 3) * pix_bytes;
+                if (++q_kh == 3) {
+                    q_kh = 0; q_bit = 1;
+                    q_aoff += 128 - p.sign * 3 * p.W * pix_bytes;
+                    q_woff += 128 - 9 * p.C * 4;
+                }
+            }
+        };
+        auto sync12 = [&]() { asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+        issue(st0);
+        issue(st1);
+        for (int t = 0; t + 1 < trips; ++t) {
+            sync12(); issue(st2);
+            sync12(); issue(st0);
+            sync12(); issue(st1);
+        }
+        sync12(); issue(st2);
+        sync12();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier();
+        return;
+    }
+
+    // ---------------------------------------------------------------------- compute waves
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    int foff[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) foff[s][pl] = li * 128 + (((pl * 4 + s * 2 + h) ^ ps_swz(li)) << 4);
+    const int abase = wm * 64 * 128, bbase = PS_A_BYTES + wn * 64 * 128;
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+    auto compute = [&](const char* stage) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(stage + abase + i * 4096 + foff[s][0]);
+                al[i] = *reinterpret_cast<const bf16x8*>(stage + abase + i * 4096 + foff[s][1]);
+                bh[i] = *reinterpret_cast<const bf16x8*>(stage + bbase + i * 4096 + foff[s][0]);
+                bl[i] = *reinterpret_cast<const bf16x8*>(stage + bbase + i * 4096 + foff[s][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
+        }
+    };
+    auto csync = [&]() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+    for (int t = 0; t < trips; ++t) {
+        csync(); compute(st0);
+        csync(); compute(st1);
+        csync(); compute(st2);
+    }
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+    const bool full = mw + 64 <= p.M;
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = nw + q * 32 + li;
+            const float bn = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                if (!full && m >= p.M) continue;
+                float v = acc[i][q][r] + bn;
+                if constexpr (EPI & 2) v += p.rowbias[(long long)(m >> p.lhw) * p.ld_rowbias + n];
+                if constexpr (EPI & 1) v += p.residual[(long long)m * p.ldr + n];
+                v *= p.out_scale;
+                float* dst = p.y + (long long)m * p.ldy + n;
+                if constexpr (EPI & 4) v += *dst;
+                *dst = v;
+            }
+        }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 128 x 128 tile variant for the SMALL layers (8x8 / 4x4 images: too few 256 x 128 tiles to fill the chip): same operands,
 // same fragment layout, 8 waves of 32 x 64, two LDS stages (64 KB -> two workgroups per CU, which de-phase), and the K
 // chunks (tap, 32 channels) split over `ksplit` workgroups per tile: partial slabs + a fixed-order second pass that also
@@ -557,8 +720,12 @@ __device__ __forceinline__ bf16x8 ps_tr_frag(const char* lds, int off) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
-template <int STAGES>
-__global__ __launch_bounds__(512, 2) void conv_ps_wgrad_kernel(PsWgParams p) {
+// NW = 8: waves 4 x 2, 32 x 64 each.  NW = 4: waves 2 x 2, 64 x 64 each (a third fewer LDS fragment reads per MFMA, twice
+// the MFMAs between barriers, half the waves per SIMD).
+template <int STAGES, int NW>
+__global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel(PsWgParams p) {
+    constexpr int TMW = 8 / NW;        // 32-row co tiles per wave
+    constexpr int NDMA = 16 / NW;      // pixel pairs per wave, operand and chunk
     __shared__ __attribute__((aligned(128))) char smem[STAGES * WG_STAGE_BYTES];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -586,11 +753,11 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad_kernel(PsWgParams p) {
 
     // ---- DMA: wave w moves pixel pairs w and w + 8 of both operands; lane: pixel k = 2*pair + lane/32, slot lane%32
     const int ps = lane & 31;
-    const char* asrc[2]; const char* bsrc[2];
-    int kpix[2];
+    const char* asrc[NDMA]; const char* bsrc[NDMA];
+    int kpix[NDMA];
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-        const int k = 2 * (wave + 8 * j) + (lane >> 5);
+    for (int j = 0; j < NDMA; ++j) {
+        const int k = 2 * (wave + NW * j) + (lane >> 5);
         kpix[j] = k;
         const int ls = ps ^ ((k & 3) << 2);
         const long long pa = (long long)c_begin * 32 + k;
@@ -601,13 +768,13 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad_kernel(PsWgParams p) {
     int q_pix = c_begin * 32;   // first pixel of the next chunk to issue
     auto issue = [&](char* stage) {
 #pragma unroll
-        for (int j = 0; j < 2; ++j) {
+        for (int j = 0; j < NDMA; ++j) {
             const int pp = q_pix + kpix[j];
             const int x = pp & (p.W - 1), y = (pp >> p.lw) & (p.H - 1);
             const bool in = pp < p.P;
             const bool ok = in && (unsigned)(y + dyt) < (unsigned)p.H && (unsigned)(x + dxt) < (unsigned)p.W;
-            ps_dma16(in ? asrc[j] : reinterpret_cast<const char*>(kPsZero), stage + (wave + 8 * j) * 1024);
-            ps_dma16(ok ? bsrc[j] : reinterpret_cast<const char*>(kPsZero), stage + WG_OP_BYTES + (wave + 8 * j) * 1024);
+            ps_dma16(in ? asrc[j] : reinterpret_cast<const char*>(kPsZero), stage + (wave + NW * j) * 1024);
+            ps_dma16(ok ? bsrc[j] : reinterpret_cast<const char*>(kPsZero), stage + WG_OP_BYTES + (wave + NW * j) * 1024);
             asrc[j] += a_adv; bsrc[j] += b_adv;
         }
         q_pix += 32;
@@ -622,9 +789,11 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad_kernel(PsWgParams p) {
     for (int v = 0; v < 4; ++v) xw[v] = (v ^ kq) << 6;
     auto foff = [&](int t, int plane, int kk) { return lane_base + xw[(t & 1) * 2 + plane] + (t >> 1) * 256 + kk * 512; };
 
-    floatx16 acc[2], accb;
+    floatx16 acc[TMW][2], accb[TMW];
 #pragma unroll
-    for (int r = 0; r < 16; ++r) { acc[0][r] = 0.f; acc[1][r] = 0.f; accb[r] = 0.f; }
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; accb[i][r] = 0.f; }
     const bool do_db = p.want_db && tn == 0 && wn == 0;   // wave-uniform
     bf16x8 ones;
 #pragma unroll
@@ -635,22 +804,35 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad_kernel(PsWgParams p) {
         const char* sb = stage + WG_OP_BYTES;
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-            const bf16x8 ah = ps_tr_frag(sa, foff(wm, 0, 16 * s)), al = ps_tr_frag(sa, foff(wm, 1, 16 * s));
-            bf16x8 bh[2], bl[2];
+            bf16x8 ah[TMW], al[TMW], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) {
+                ah[i] = ps_tr_frag(sa, foff(wm * TMW + i, 0, 16 * s));
+                al[i] = ps_tr_frag(sa, foff(wm * TMW + i, 1, 16 * s));
+            }
 #pragma unroll
             for (int q = 0; q < 2; ++q) {
                 bh[q] = ps_tr_frag(sb, foff(wn * 2 + q, 0, 16 * s));
                 bl[q] = ps_tr_frag(sb, foff(wn * 2 + q, 1, 16 * s));
             }
 #pragma unroll
-            for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], acc[q], 0, 0, 0);
+            for (int i = 0; i < TMW; ++i)
 #pragma unroll
-            for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[q], acc[q], 0, 0, 0);
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[q], acc[i][q], 0, 0, 0);
 #pragma unroll
-            for (int q = 0; q < 2; ++q) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[q], acc[q], 0, 0, 0);
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < TMW; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
             if (do_db) {
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, accb, 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) {
+                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], ones, accb[i], 0, 0, 0);
+                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], ones, accb[i], 0, 0, 0);
+                }
             }
         }
     };
@@ -663,14 +845,16 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad_kernel(PsWgParams p) {
         if (n > 1) issue(st[1]);
         int c = 0;
         for (; c + 2 < n; ++c) {   // steady state: two chunks in flight behind the one being waited for
-            asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             const int cur = c % 3, nxt = (c + 2) % 3;
             issue(smem + nxt * WG_STAGE_BYTES);
             compute(smem + cur * WG_STAGE_BYTES);
         }
         for (; c < n; ++c) {
-            if (c + 1 < n) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            if (c + 1 < n && NW == 8) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else if (c + 1 < n) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
             else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             compute(smem + (c % 3) * WG_STAGE_BYTES);
@@ -690,18 +874,22 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad_kernel(PsWgParams p) {
     const int M = p.Cout, N = 9 * p.Cin;
     float* out = p.out + (p.ksplit > 1 ? (long long)zz * M * N : 0);
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int nn = n0 + wn * 64 + q * 32 + li;
+    for (int i = 0; i < TMW; ++i)
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            out[(long long)m * N + nn] = acc[q][r];
+        for (int q = 0; q < 2; ++q) {
+            const int nn = n0 + wn * 64 + q * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = co0 + (wm * TMW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(long long)m * N + nn] = acc[i][q][r];
+            }
         }
-    }
     if (do_db && li == 0) {
         float* o = p.ksplit > 1 ? p.out + (long long)p.ksplit * M * N + (long long)zz * M : p.db;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = accb[r];
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[co0 + (wm * TMW + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = accb[i][r];
     }
 }
 
@@ -922,6 +1110,7 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
 #define PS_LAUNCH(E)                                                                              \
     do {                                                                                          \
         if (sched == 0) hipLaunchKernelGGL((conv_ps_kernel<E, 0>), grid, block, 0, st, p);        \
+        else if (sched == 2) hipLaunchKernelGGL((conv_ps_ws_kernel<E>), grid, dim3(PS_WS_NT), 0, st, p); \
         else hipLaunchKernelGGL((conv_ps_kernel<E, 1>), grid, block, 0, st, p);                   \
     } while (0)
         switch (epi) {
@@ -1012,8 +1201,14 @@ int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
                          ((double)p.P * (d.Cin + d.Cout) + 9.0 * d.Cin * d.Cout) * 4.0, st);
     static const int stages = getenv("BD_PS_WG_STAGES") ? atoi(getenv("BD_PS_WG_STAGES")) : 2;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.ksplit));
-    if (stages == 2) hipLaunchKernelGGL(conv_ps_wgrad_kernel<2>, grid, dim3(512), 0, st, p);
-    else hipLaunchKernelGGL(conv_ps_wgrad_kernel<3>, grid, dim3(512), 0, st, p);
+    static const int nw = getenv("BD_PS_WG_WAVES") ? atoi(getenv("BD_PS_WG_WAVES")) : 8;
+    if (nw == 4) {
+        if (stages == 2) hipLaunchKernelGGL((conv_ps_wgrad_kernel<2, 4>), grid, dim3(256), 0, st, p);
+        else hipLaunchKernelGGL((conv_ps_wgrad_kernel<3, 4>), grid, dim3(256), 0, st, p);
+    } else {
+        if (stages == 2) hipLaunchKernelGGL((conv_ps_wgrad_kernel<2, 8>), grid, dim3(512), 0, st, p);
+        else hipLaunchKernelGGL((conv_ps_wgrad_kernel<3, 8>), grid, dim3(512), 0, st, p);
+    }
     BD_LAUNCH_CHECK("conv_ps_wgrad");
     if (p.ksplit > 1) {
         const long long total = mn / 4 + (d.db ? d.Cout : 0);
