@@ -16,7 +16,13 @@ import torch.nn.functional as F   # F.pad only
 
 
 def mse(a, b):
-    """nn.MSELoss(reduction='mean') (baddiffusion.py:545)."""
+    """nn.MSELoss(reduction='mean') (baddiffusion.py:545).  GPU tensors: the fused l2-loss kernel (bd_loss_fwd_bwd, fp64
+    partial sums); CPU tensors (tests): the same formula in fp64."""
+    if a.is_cuda and b.is_cuda and a.shape == b.shape and a.shape[-1] % 1 == 0:
+        from . import ops
+        a32, b32 = a.float().contiguous(), b.float().contiguous()
+        loss, _ = ops.loss_fwd_bwd(a32.reshape(-1, a32.shape[-1]), b32.reshape(-1, b32.shape[-1]), "l2", want_grad=False)
+        return float(loss)
     return float(((a.double() - b.double()) ** 2).mean())
 
 

@@ -68,6 +68,11 @@ class _PipelineBase:
         """image: NHWC storage [B,H,W,C] -> float32 numpy [B,H,W,C] in [0,1] (pipeline_ddpm.py:115-116)."""
         return ops.to_image(image_nhwc_storage, True, shape).cpu().numpy()
 
+    def _to_u8(self, image_nhwc_storage, shape):
+        """device uint8 [B,H,W,C] = round(255 * (x/2+0.5).clamp(0,1)): what the PNG writer needs, without leaving the GPU
+        and without a host synchronisation (output_type="u8"; model.py:496-502 quantises the same way on the host)."""
+        return ops.to_image(image_nhwc_storage, True, shape, want_u8=True)[1]
+
     def _start(self, batch_size, generator, init):
         shape = self._image_shape(batch_size)
         if init is None:
@@ -108,6 +113,9 @@ class DDPMPipeline(_PipelineBase):
                                         ).prev_sample.permute(0, 2, 3, 1)
             if save_every_step:
                 mov.append(self._to_numpy(image, shape))
+        if output_type == "u8":
+            images = self._to_u8(image, shape)
+            return ImagePipelineOutput(images=images, movie=mov) if return_dict else (images,)
         images = self._to_numpy(image, shape)
         if output_type == "pil":
             images = self.numpy_to_pil(images)
@@ -141,6 +149,9 @@ class DDIMPipeline(_PipelineBase):
                                         generator=generator).prev_sample.permute(0, 2, 3, 1)
             if save_every_step:
                 mov.append(self._to_numpy(image, shape))
+        if output_type == "u8":
+            images = self._to_u8(image, shape)
+            return ImagePipelineOutput(images=images, movie=mov) if return_dict else (images,)
         images = self._to_numpy(image, shape)
         if output_type == "pil":
             images = self.numpy_to_pil(images)
