@@ -33,33 +33,60 @@ HBM_PEAK_GBS = 8000.0
 
 
 _PMC_OPERANDS = {"conv_fwd": ("ConvKC", ("WgtKC", "WgtKCs")), "conv_dgrad": ("TConvKC", ("WgtRC", "WgtRCs")),
-                 "conv_wgrad": ("DenseRC", ("ConvRC",)), "gemm_nt": ("DenseKC", ("DenseKC",)),
+                 "conv_wgrad": ("DenseRC", ("ConvRC", "ConvRCs")), "gemm_nt": ("DenseKC", ("DenseKC",)),
                  "gemm_nn": ("DenseKC", ("DenseRC",)), "gemm_tn": ("DenseRC", ("DenseRC",))}
+# kernel classes of the LDS-DMA family (conv_ps.hip) -> kernel-name patterns whose HBM traffic makes up one call
+_PMC_PS = {"conv_ps_wgrad": (r"conv_ps_wgrad_kernel<", r"conv_ps_wgrad_reduce"), "conv_ps_fwd": (r"conv_ps_kernel<[12]>",),
+           "conv_ps_dgrad": (r"conv_ps_kernel<0>",), "conv_ps128_fwd": (r"conv_ps128_kernel<", r"conv_ps128_reduce"),
+           "conv_ps128_dgrad": (r"conv_ps128_kernel<", r"conv_ps128_reduce")}
+PMC_FILE = "profiles/r02_pmc_bench_{mode}.json"
 
 
-def _pmc_traffic(cls):
-    """HBM-side bytes per launch of kernel class `cls` from the committed rocprofv3 PMC passes of this same command
-    (scripts/pmc_bench.sh -> profiles/r01_pmc_bench_<mode>.json; FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950
+def _pmc_traffic(cls, launches_per_step=None):
+    """HBM-side bytes per call of kernel class `cls` from the committed rocprofv3 PMC passes of this same command
+    (scripts/pmc_bench.sh -> profiles/r02_pmc_bench_<mode>.json; FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950
     correction for 16 B/lane reads, + WRITE_SIZE; KB -> bytes; launch-weighted over the kernel instantiations of the
-    class).  None when that file or kernel is absent: counters cannot be collected from inside the timed process."""
+    class, split-K second passes included).  Returns (bytes, source) -- (None, reason) when that file or kernel is
+    absent: counters cannot be collected from inside the timed process, so this is read from a committed file."""
     import re
+    mode = "bf16x3" if ("bf16x3" in cls or cls.startswith("conv_ps")) else "f32"
+    rel = PMC_FILE.format(mode=mode)
+    path = os.path.join(ROOT, rel)
+    if not os.path.exists(path):
+        return None, f"{rel} not found"
+    kernels = json.load(open(path))["kernels"]
+    by = lambda v: (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
+    if cls in _PMC_PS:
+        main_pat = re.compile(_PMC_PS[cls][0])
+        tot = n = 0.0
+        for name, v in kernels.items():
+            if main_pat.search(name):
+                tot += by(v) * v["launches"]; n += v["launches"]
+        if not n:
+            return None, f"no {cls} kernel in {rel}"
+        extra = 0.0
+        for pat in _PMC_PS[cls][1:]:     # second-pass kernels: one launch per call of the class
+            pp = re.compile(pat)
+            t2 = n2 = 0.0
+            for name, v in kernels.items():
+                if pp.search(name):
+                    t2 += by(v) * v["launches"]; n2 += v["launches"]
+            if n2:
+                extra += t2 / n2
+        return tot / n + extra, rel
     m = re.match(r"igemm_(\w+?)_(\d+)(_bf16x3)?$", cls)
     if not m or m.group(1) not in _PMC_OPERANDS:
-        return None
-    mode = "bf16x3" if m.group(3) else "f32"
-    path = os.path.join(ROOT, "profiles", f"r01_pmc_bench_{mode}.json")
-    if not os.path.exists(path):
-        return None
+        return None, "class not mapped to a kernel"
     la, lbs = _PMC_OPERANDS[m.group(1)]
     kname = "igemm_bf16x3_kernel" if m.group(3) else "igemm_kernel"
     pat = re.compile(rf"{kname}<{m.group(2)}, {m.group(2)}, bd::(\w+)<[^>]*>, bd::(\w+)<[^>]*>")
     tot = n = 0.0
-    for name, v in json.load(open(path))["kernels"].items():
+    for name, v in kernels.items():
         mm = pat.search(name)
         if mm and mm.group(1) == la and mm.group(2) in lbs and "FETCH_SIZE_KB_per_launch" in v and "WRITE_SIZE_KB_per_launch" in v:
-            tot += (2.0 * v["FETCH_SIZE_KB_per_launch"] + v["WRITE_SIZE_KB_per_launch"]) * 1024.0 * v["launches"]
+            tot += by(v) * v["launches"]
             n += v["launches"]
-    return tot / n if n else None
+    return (tot / n, rel) if n else (None, f"no {cls} kernel in {rel}")
 
 
 def _host_cores():
@@ -356,8 +383,9 @@ def main():
                 # split-bf16 issues 3 bf16 MFMA products per algorithmic multiply: its ceiling for ALGORITHMIC flops is
                 # the dense bf16 peak / 3 (833 TF), above the exact-fp32 MFMA peak (157 TF) the f32 mode is bound by
                 peak = FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 3
+                traffic, traffic_source = (None, "not collected for this workload") if celeba else _pmc_traffic(d["kernel"])
                 out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": peak,
-                                   "unit": "TFLOP/s", "frac": ach / peak, "traffic": None if celeba else _pmc_traffic(d["kernel"]),
+                                   "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
                                    "mfma_flops_per_algorithmic_flop": 1 if args.mode == "f32" else 3,
                                    "mfma_dense_peak": FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS,
                                    "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,

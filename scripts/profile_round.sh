@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile artifacts (run on the GPU box through gpurun): rocprofv3 kernel-trace summary + bench JSON of the
 # same command, then the PMC traffic passes.  usage: scripts/profile_round.sh <tag>   -> gpurun_out/<tag>_*
-tag=${1:-r01_e}
+tag=${1:-r02}
 out=$GRAFT_REPO_ROOT/gpurun_out
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rp
