@@ -21,6 +21,7 @@ SOURCES = [  # (file, extra flags)
     ("groupnorm.hip", []),
     ("igemm.hip", []),
     ("conv_ps.hip", []),
+    ("attn.hip", []),
     ("conv.cpp", ["-x", "hip"]),
     ("conv_thin.hip", []),
     ("unet_plan.cpp", ["-x", "hip"]),

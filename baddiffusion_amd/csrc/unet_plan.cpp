@@ -30,6 +30,8 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st);                    
 bool conv3x3_ps_supported(int B, int H, int W, int K_channels, int N_channels);
 int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st);
 bool conv3x3_ps_wgrad_supported(int B, int H, int W, int Cin, int Cout);
+int attn_fwd(const bd_attn_fwd_desc& d, hipStream_t st);                             // attn.hip
+bool attn_fwd_supported(int N, int dh);
 int split_wt_batched(const float* params, uint16_t* out, const long long* off, const int* cin, const int* cout, int n, hipStream_t st);
 
 struct View {
@@ -619,24 +621,36 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
         BD_TRY(gn_fwd(c, x, pgw, pgb, BP(c, b_n), C, b_st, 0));
         BD_TRY(linear_fwd(c, BP(c, b_n), C, c.params + pqw, c.params + pqb, BP(c, b_qkv), 3 * C, M, 3 * C, C));
         float* qkv = BP(c, b_qkv);
-        {   // S = scale * Q K^T
-            bd_igemm_desc g = {};
-            g.A = dense(qkv, 3 * C, 1); g.A.bs_outer = (int64_t)N * 3 * C; g.A.bs_inner = dh;
-            g.B = dense(qkv + C, 3 * C, 1); g.B.bs_outer = (int64_t)N * 3 * C; g.B.bs_inner = dh;
-            g.M = N; g.N = N; g.K = dh; batched(g, c.B);
-            g.C = BP(c, b_p); g.ldc = N; g.c_bs_outer = (int64_t)heads * N * N; g.c_bs_inner = (int64_t)N * N;
-            g.alpha = sm_scale; g.out_scale = 1.f;
-            BD_TRY(igemm(c, g));
-        }
-        if (!c.dry) BD_TRY(bd_softmax_fwd(BP(c, b_p), BP(c, b_p), (int64_t)c.B * heads * N, N, (bd_stream_t)c.st));
-        {   // O = P V
-            bd_igemm_desc g = {};
-            g.A = dense(BP(c, b_p), N, 1); g.A.bs_outer = (int64_t)heads * N * N; g.A.bs_inner = (int64_t)N * N;
-            g.B = dense(qkv + 2 * C, 3 * C, 0); g.B.bs_outer = (int64_t)N * 3 * C; g.B.bs_inner = dh;
-            g.M = N; g.N = dh; g.K = N; batched(g, c.B);
-            g.C = BP(c, b_o); g.ldc = C; g.c_bs_outer = (int64_t)N * C; g.c_bs_inner = dh;
-            g.alpha = 1.f; g.out_scale = 1.f;
-            BD_TRY(igemm(c, g));
+        // Fused QK^T -> softmax -> PV (attn.hip): S / P stay on chip, P is written only when backward will need it.  OPT-IN
+        // (BD_ATTN_FUSED=1): with fp32 operands split on the way into LDS the kernel is load-latency bound and measures
+        // 80 us against 74 us for the three unfused launches at B = 128, N = 256, d = 256, so the
+        // default stays unfused until the QKV projection can hand over split planes for a DMA-fed version.
+        static const bool fuse_on = getenv("BD_ATTN_FUSED") && atoi(getenv("BD_ATTN_FUSED")) == 1;
+        if (fuse_on && cfg.compute_mode == BD_MODE_BF16X3 && attn_fwd_supported(N, dh)) {
+            bd_attn_fwd_desc a = {};
+            a.B = c.B; a.heads = heads; a.N = N; a.dh = dh; a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.ld = 3 * C;
+            a.scale = sm_scale; a.o = BP(c, b_o); a.ldo = C; a.p_out = c.training ? BP(c, b_p) : nullptr;
+            if (!c.dry) BD_TRY(attn_fwd(a, c.st));
+        } else {
+            {   // S = scale * Q K^T
+                bd_igemm_desc g = {};
+                g.A = dense(qkv, 3 * C, 1); g.A.bs_outer = (int64_t)N * 3 * C; g.A.bs_inner = dh;
+                g.B = dense(qkv + C, 3 * C, 1); g.B.bs_outer = (int64_t)N * 3 * C; g.B.bs_inner = dh;
+                g.M = N; g.N = N; g.K = dh; batched(g, c.B);
+                g.C = BP(c, b_p); g.ldc = N; g.c_bs_outer = (int64_t)heads * N * N; g.c_bs_inner = (int64_t)N * N;
+                g.alpha = sm_scale; g.out_scale = 1.f;
+                BD_TRY(igemm(c, g));
+            }
+            if (!c.dry) BD_TRY(bd_softmax_fwd(BP(c, b_p), BP(c, b_p), (int64_t)c.B * heads * N, N, (bd_stream_t)c.st));
+            {   // O = P V
+                bd_igemm_desc g = {};
+                g.A = dense(BP(c, b_p), N, 1); g.A.bs_outer = (int64_t)heads * N * N; g.A.bs_inner = (int64_t)N * N;
+                g.B = dense(qkv + 2 * C, 3 * C, 0); g.B.bs_outer = (int64_t)N * 3 * C; g.B.bs_inner = dh;
+                g.M = N; g.N = dh; g.K = N; batched(g, c.B);
+                g.C = BP(c, b_o); g.ldc = C; g.c_bs_outer = (int64_t)N * C; g.c_bs_inner = dh;
+                g.alpha = 1.f; g.out_scale = 1.f;
+                BD_TRY(igemm(c, g));
+            }
         }
         return linear_fwd(c, BP(c, b_o), C, c.params + ppw, c.params + ppb, VP(c, y), y.ld, M, C, C, VP(c, x), x.ld, inv);
     });

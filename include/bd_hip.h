@@ -316,6 +316,21 @@ int bd_sum2x2(const float* du, int64_t ldu, float* dx, int64_t lddx, int B, int 
 int bd_softmax_fwd(const float* s, float* p, int64_t rows, int n, bd_stream_t stream);
 int bd_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, int n, bd_stream_t stream);
 
+/* Fused attention forward (attention.py:148-162: scores = baddbmm(q, k^T) * scale; softmax(scores.float()); bmm(probs, v)):
+ * per (sample, head) o = softmax(scale * q k^T) v without materialising the [N, N] matrices in HBM.  q / k / v / o are
+ * [B, N, ld] fp32 views (head h at column h*dh: the three column blocks of the QKV projection's output).  p_out (optional,
+ * [B*heads, N, N] fp32) receives the probabilities for the unfused backward, lse (optional, [B*heads, N]) the row
+ * log-sum-exp.  Split-bf16 products (BD_MODE_BF16X3 arithmetic), fp32 softmax.  64 <= N <= 256, N % 64 == 0, dh % 64 == 0,
+ * dh <= 512; other shapes: BD_ERR_UNSUPPORTED (callers keep the bd_igemm + bd_softmax_fwd path). */
+typedef struct {
+    int B, heads, N, dh;
+    const float* q; const float* k; const float* v; int64_t ld;
+    float scale;
+    float* o; int64_t ldo;
+    float* p_out; float* lse;
+} bd_attn_fwd_desc;
+int bd_attn_fwd(const bd_attn_fwd_desc* d, bd_stream_t stream);
+
 /* y = x * sigmoid(x) ; dx = dy * silu'(x)  (embeddings.py:205-206, resnet.py:576) */
 int bd_silu_fwd(const float* x, float* y, int64_t n, bd_stream_t stream);
 int bd_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, int accumulate, bd_stream_t stream);

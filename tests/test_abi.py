@@ -43,7 +43,7 @@ def test_struct_layouts_match_header_sizes():
              "bd_ddim_step_desc": L.DdimStepDesc, "bd_gn_fwd_desc": L.GnFwdDesc, "bd_gn_bwd_desc": L.GnBwdDesc,
              "bd_operand": L.Operand, "bd_igemm_desc": L.IgemmDesc, "bd_conv3x3_fwd_desc": L.ConvFwdDesc,
              "bd_conv3x3_dgrad_desc": L.ConvDgradDesc, "bd_conv3x3_wgrad_desc": L.ConvWgradDesc, "bd_unet_config": L.UnetConfig,
-             "bd_conv3x3_ps_desc": L.ConvPsDesc, "bd_conv3x3_ps_wgrad_desc": L.ConvPsWgradDesc}
+             "bd_conv3x3_ps_desc": L.ConvPsDesc, "bd_conv3x3_ps_wgrad_desc": L.ConvPsWgradDesc, "bd_attn_fwd_desc": L.AttnFwdDesc}
     prog = '#include <stdio.h>\n#include "bd_hip.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     import tempfile
