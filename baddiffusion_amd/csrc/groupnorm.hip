@@ -65,6 +65,17 @@ __device__ __forceinline__ void gn_store_split4(unsigned short* row, int c, cons
     *reinterpret_cast<uint2*>(q + 32) = make_uint2(gn_pack_lo(o[0], o[1]), gn_pack_lo(o[2], o[3]));
 }
 
+// predicated 16-byte load without control flow: masked-off lanes read 16 zero bytes that live in the code object (the
+// igemm.hip idiom).  A `cond ? *p : 0` in an unrolled loop makes hipcc branch around every load and wait vmcnt(0) behind
+// it (cdna_hip_programming.md section 5, trap (c)): 16 serialised memory round trips per thread instead of 16 loads in flight.
+__device__ __attribute__((aligned(16))) const float kGnZero16[4] = {0.f, 0.f, 0.f, 0.f};
+typedef float gn_v4f __attribute__((ext_vector_type(4)));
+typedef const gn_v4f __attribute__((address_space(1))) * gn_gptr4;
+__device__ __forceinline__ float4 gn_ld4_if(const float* p, bool ok) {
+    const gn_v4f t = *(gn_gptr4)(ok ? p : kGnZero16);
+    return make_float4(t.x, t.y, t.z, t.w);
+}
+
 // ---- forward stats: per (b, split) partial (sum, sumsq) per group, in double -----------------------
 __global__ void gn_stats_kernel(const float* __restrict__ x, long long ldx, int HW, int C, int G, int r, int S,
                                 double* __restrict__ part /* [B][S][G][2] */) {
@@ -422,7 +433,7 @@ __global__ __launch_bounds__(NT) void gn_fwd_res_kernel(const float* __restrict_
     for (int i = 0; i < EMAX; ++i) {
         const int p = prow + R * i;
         const bool ok = active && i < E && p < HW;
-        v[i] = ok ? *reinterpret_cast<const float4*>(xb + (long long)p * ldx) : make_float4(0.f, 0.f, 0.f, 0.f);
+        v[i] = gn_ld4_if(xb + (long long)p * ldx, ok);
         sm[0] += v[i].x; sm[1] += v[i].y; sm[2] += v[i].z; sm[3] += v[i].w;
         sq[0] += v[i].x * v[i].x; sq[1] += v[i].y * v[i].y; sq[2] += v[i].z * v[i].z; sq[3] += v[i].w * v[i].w;
     }
@@ -514,9 +525,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_res_kernel(const float* __restrict_
     for (int i = 0; i < EMAX; ++i) {
         const int p = prow + R * i;
         const bool ok = active && i < E && p < HW;
-        const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-        xh[i] = ok ? *reinterpret_cast<const float4*>(xb + (long long)p * ldx) : z4;
-        dz[i] = ok ? *reinterpret_cast<const float4*>(db + (long long)p * lddy) : z4;
+        xh[i] = gn_ld4_if(xb + (long long)p * ldx, ok);
+        dz[i] = gn_ld4_if(db + (long long)p * lddy, ok);
     }
 #pragma unroll
     for (int i = 0; i < EMAX; ++i) {
@@ -580,22 +590,31 @@ __global__ __launch_bounds__(NT) void gn_bwd_res_kernel(const float* __restrict_
     }
     float* ob = dx + (long long)b * HW * lddx + c0 + cq * 4;
 #pragma unroll
+    for (int i = 0; i < EMAX; ++i) {      // dx term into dz[i] (xh[i] is free afterwards)
+        const float h[4] = {xh[i].x, xh[i].y, xh[i].z, xh[i].w}, d[4] = {dz[i].x, dz[i].y, dz[i].z, dz[i].w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = rs[j] * (d[j] * gg[j] - (g1[j] + h[j] * g2[j]) * inv_n);
+        dz[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+    if (dx && acc) {                      // accumulate: the existing dx values, all loads in flight at once
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) {
+            const int p = prow + R * i;
+            xh[i] = gn_ld4_if(ob + (long long)p * lddx, i < E && p < HW);
+        }
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) { dz[i].x += xh[i].x; dz[i].y += xh[i].y; dz[i].z += xh[i].z; dz[i].w += xh[i].w; }
+    }
+#pragma unroll
     for (int i = 0; i < EMAX; ++i) {
         const int p = prow + R * i;
         if (i < E && p < HW) {
-            const float h[4] = {xh[i].x, xh[i].y, xh[i].z, xh[i].w}, d[4] = {dz[i].x, dz[i].y, dz[i].z, dz[i].w};
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = rs[j] * (d[j] * gg[j] - (g1[j] + h[j] * g2[j]) * inv_n);
-            if (dx) {
-                float4* dst = reinterpret_cast<float4*>(ob + (long long)p * lddx);
-                if (acc) {
-                    const float4 e = *dst;
-                    o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
-                }
-                *dst = make_float4(o[0], o[1], o[2], o[3]);
+            if (dx) *reinterpret_cast<float4*>(ob + (long long)p * lddx) = dz[i];
+            if (dxs) {
+                const float o[4] = {dz[i].x, dz[i].y, dz[i].z, dz[i].w};
+                gn_store_split4(dxs + 2 * ((long long)b * HW + p) * lddxs, c0 + cq * 4, o);
             }
-            if (dxs) gn_store_split4(dxs + 2 * ((long long)b * HW + p) * lddxs, c0 + cq * 4, o);
         }
     }
 }

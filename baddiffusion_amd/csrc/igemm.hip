@@ -752,34 +752,77 @@ __device__ __forceinline__ WgCoord wg_coord(const IGemmParams& p) {
 }
 
 // ---- epilogue: lane holds column (n) li of rows (r&3) + 8*(r>>2) + 4*h of every 32x32 tile ---------------------
-template <int TM, int TN>
-__device__ __forceinline__ void epilogue(const IGemmParams& p, floatx16 (&acc)[TM][TN], int mw, int nw, int li, int h, int bo, int bi, int zz) {
+// predicated scalar load without control flow (see ld4_if): masked-off lanes read a zero from the code object
+typedef const float __attribute__((address_space(1))) * gptr1;
+__device__ __forceinline__ float ld1_if(const float* p, bool ok) { return *(gptr1)(ok ? p : kZero16); }
+
+// All optional addends (row bias, residual, previous C) of a 32x32 tile are LOADED FIRST -- 16 branch-free loads each, all in
+// flight together -- and only then combined and stored.  The straightforward form (per element: `if (residual) v += *r;
+// if (accumulate) v += *dst; *dst = v`) makes hipcc branch around every load and wait vmcnt(0) behind it: 32-64 serialised
+// memory round trips per thread, which dominated the short-K GEMMs that carry a residual or accumulate (guide section 5 (c)).
+// Absent addends contribute an exact + 0.0f, so the result is bit-identical to the per-element form.
+// FULL (wave-uniform: the wave's whole sub-tile lies inside M x N) drops every per-element predicate, so the 16 stores of
+// a tile are straight-line code with their own address registers; behind an exec-masked branch per element hipcc reuses
+// one address register pair and waits vmcnt(0) for the previous store before every store.
+template <int TM, int TN, bool FULL>
+__device__ __forceinline__ void epilogue_impl(const IGemmParams& p, floatx16 (&acc)[TM][TN], int mw, int nw, int li, int h, int bo, int bi, int zz) {
     const long long coff = bo * p.c_bso + bi * p.c_bsi;
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int q = 0; q < TN; ++q) {
             const int n = nw + q * 32 + li;
-            if (n >= p.N) continue;
-            const float bn = (p.ksplit == 1 && p.bias) ? p.bias[n] : 0.f;
+            const bool nok = FULL || n < p.N;
+            const int m_base = mw + i * 32 + 4 * h;
+            if (p.ksplit > 1) {   // (kernel-uniform) raw partial tile
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m >= p.M) continue;
-                float v = acc[i][q][r];
-                if (p.ksplit > 1) {
-                    p.partial[((long long)zz * p.M + m) * p.N + n] = v;
-                } else {
-                    v = v * p.alpha + bn;
-                    if (p.rowbias) v += p.rowbias[(long long)(m / p.rows_per_group) * p.ld_rowbias + n];
-                    if (p.residual) v += p.residual[coff + (long long)m * p.ldr + n];
-                    v *= p.out_scale;
-                    float* dst = p.C + coff + (long long)m * p.ldc + n;
-                    if (p.accumulate) v += *dst;
-                    *dst = v;
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_base + (r & 3) + 8 * (r >> 2);
+                    if (FULL || (nok && m < p.M)) p.partial[((long long)zz * p.M + m) * p.N + n] = acc[i][q][r];
+                }
+                continue;
+            }
+            const float bn = p.bias ? ld1_if(p.bias + n, nok) : 0.f;
+            float rb[16], rs[16], pc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { rb[r] = 0.f; rs[r] = 0.f; pc[r] = 0.f; }
+            if (p.rowbias) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_base + (r & 3) + 8 * (r >> 2);
+                    rb[r] = ld1_if(p.rowbias + (long long)(m / p.rows_per_group) * p.ld_rowbias + n, FULL || (nok && m < p.M));
                 }
             }
+            if (p.residual) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_base + (r & 3) + 8 * (r >> 2);
+                    rs[r] = ld1_if(p.residual + coff + (long long)m * p.ldr + n, FULL || (nok && m < p.M));
+                }
+            }
+            if (p.accumulate) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = m_base + (r & 3) + 8 * (r >> 2);
+                    pc[r] = ld1_if(p.C + coff + (long long)m * p.ldc + n, FULL || (nok && m < p.M));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_base + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][q][r] * p.alpha + bn;
+                v += rb[r];
+                v += rs[r];
+                v *= p.out_scale;
+                v += pc[r];
+                if (FULL || (nok && m < p.M)) p.C[coff + (long long)m * p.ldc + n] = v;
+            }
         }
+}
+template <int TM, int TN>
+__device__ __forceinline__ void epilogue(const IGemmParams& p, floatx16 (&acc)[TM][TN], int mw, int nw, int li, int h, int bo, int bi, int zz) {
+    if (mw + TM * 32 <= p.M && nw + TN * 32 <= p.N) epilogue_impl<TM, TN, true>(p, acc, mw, nw, li, h, bo, bi, zz);
+    else epilogue_impl<TM, TN, false>(p, acc, mw, nw, li, h, bo, bi, zz);
 }
 
 // ---- fused row sums of the A operand (bias gradients: A = dY^T of a wgrad) --------------------------------------------
