@@ -70,6 +70,50 @@ __device__ __forceinline__ void ps_sync() {
     __builtin_amdgcn_s_barrier();
 }
 
+// Epilogue of a wave's TM x 2 grid of 32x32 accumulator tiles: y = out_scale * (acc + bias + rowbias + residual) (+ y).
+// The addends of a tile are loaded FIRST (16 independent loads each, all in flight), then combined and stored.  FULL
+// (wave-uniform: every row of the sub-tile is < M) removes the per-element predicate: behind an exec-masked branch per
+// element hipcc reuses one address register pair and waits vmcnt(0) for the previous store before every store -- a chain
+// of ~64 serialised memory round trips per wave that used to be a large part of the per-tile overhead.
+template <int EPI, int TM, bool FULL>
+__device__ __forceinline__ void ps_epilogue(const PsParams& p, floatx16 (&acc)[TM][2], int mw, int nw, int li, int h) {
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = nw + q * 32 + li;
+            const float bn = p.bias ? p.bias[n] : 0.f;
+            const int m_base = mw + i * 32 + 4 * h;
+            float ad[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) ad[r] = 0.f;
+            float pc[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = FULL ? m_base + (r & 3) + 8 * (r >> 2) : min(m_base + (r & 3) + 8 * (r >> 2), p.M - 1);   // clamped: branch-free loads
+                if constexpr (EPI & 2) ad[r] = p.rowbias[(long long)(m >> p.lhw) * p.ld_rowbias + n];
+            }
+            float rs[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = FULL ? m_base + (r & 3) + 8 * (r >> 2) : min(m_base + (r & 3) + 8 * (r >> 2), p.M - 1);
+                rs[r] = 0.f; pc[r] = 0.f;
+                if constexpr (EPI & 1) rs[r] = p.residual[(long long)m * p.ldr + n];
+                if constexpr (EPI & 4) pc[r] = p.y[(long long)m * p.ldy + n];
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m_base + (r & 3) + 8 * (r >> 2);
+                float v = acc[i][q][r] + bn;
+                if constexpr (EPI & 2) v += ad[r];
+                if constexpr (EPI & 1) v += rs[r];
+                v *= p.out_scale;
+                if constexpr (EPI & 4) v += pc[r];
+                if (FULL || m < p.M) p.y[(long long)m * p.ldy + n] = v;
+            }
+        }
+}
+
 // EPI bits: 1 = residual, 2 = per-sample row bias, 4 = accumulate into y
 // All eight waves run in lock step, one barrier per chunk.  (A ping-pong schedule -- the two waves of a SIMD one phase
 // apart, four barriers per chunk -- and a wave-specialised form with four extra DMA-only loader waves were built and
@@ -231,26 +275,8 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps_kernel(PsParams p) {
 
     // ---- epilogue: lane holds column n = li of rows (r&3) + 8*(r>>2) + 4*h of every 32x32 tile
     const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-    const bool full = mw + 64 <= p.M;   // wave-uniform
-#pragma unroll
-    for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int n = nw + q * 32 + li;
-            const float bn = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (!full && m >= p.M) continue;
-                float v = acc[i][q][r] + bn;
-                if constexpr (EPI & 2) v += p.rowbias[(long long)(m >> p.lhw) * p.ld_rowbias + n];
-                if constexpr (EPI & 1) v += p.residual[(long long)m * p.ldr + n];
-                v *= p.out_scale;
-                float* dst = p.y + (long long)m * p.ldy + n;
-                if constexpr (EPI & 4) v += *dst;
-                *dst = v;
-            }
-        }
+    if (mw + 64 <= p.M) ps_epilogue<EPI, 2, true>(p, acc, mw, nw, li, h);    // wave-uniform: whole sub-tile inside M
+    else ps_epilogue<EPI, 2, false>(p, acc, mw, nw, li, h);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -372,36 +398,28 @@ __global__ __launch_bounds__(512, 4) void conv_ps128_kernel(PsSmallParams pp) {
         compute(smem + (c & 1) * STAGE);
     }
     const int mw = m0 + wm * 32, nw = n0 + wn * 64;
+    const bool full = mw + 32 <= p.M;     // wave-uniform
     if (pp.ksplit > 1) {
         float* out = pp.partial + (long long)zz * p.M * p.N;
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int nn = nw + q * 32 + li;
+            if (full) {
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * h;
-                if (m < p.M) out[(long long)m * p.N + nn] = acc[q][r];
+                for (int r = 0; r < 16; ++r) out[(long long)(mw + (r & 3) + 8 * (r >> 2) + 4 * h) * p.N + nn] = acc[q][r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < p.M) out[(long long)m * p.N + nn] = acc[q][r];
+                }
             }
         }
         return;
     }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        const int nn = nw + q * 32 + li;
-        const float bn = p.bias ? p.bias[nn] : 0.f;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mw + (r & 3) + 8 * (r >> 2) + 4 * h;
-            if (m >= p.M) continue;
-            float v = acc[q][r] + bn;
-            if constexpr (EPI & 2) v += p.rowbias[(long long)(m >> p.lhw) * p.ld_rowbias + nn];
-            if constexpr (EPI & 1) v += p.residual[(long long)m * p.ldr + nn];
-            v *= p.out_scale;
-            float* dst = p.y + (long long)m * p.ldy + nn;
-            if constexpr (EPI & 4) v += *dst;
-            *dst = v;
-        }
-    }
+    floatx16 a2[1][2] = {{acc[0], acc[1]}};
+    if (full) ps_epilogue<EPI, 1, true>(p, a2, mw, nw, li, h);
+    else ps_epilogue<EPI, 1, false>(p, a2, mw, nw, li, h);
 }
 
 // second pass of the K split: fixed-order sum of the slabs + the epilogue, float4 per thread (N % 4 == 0)
