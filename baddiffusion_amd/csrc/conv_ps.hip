@@ -431,6 +431,7 @@ __global__ __launch_bounds__(256) void conv_ps128_reduce(PsSmallParams pp) {
     const int m = (int)(i / n4), nn = (int)(i - (long long)m * n4) * 4;
     const long long mn = (long long)p.M * p.N, e = (long long)m * p.N + nn;
     float4 a = *reinterpret_cast<const float4*>(pp.partial + e);
+#pragma unroll 4      // four slab loads in flight; the additions keep their fixed order
     for (int s = 1; s < pp.ksplit; ++s) {
         const float4 b = *reinterpret_cast<const float4*>(pp.partial + (long long)s * mn + e);
         a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
@@ -674,6 +675,7 @@ __global__ __launch_bounds__(256) void conv_ps_wgrad_reduce(const float* __restr
     const long long n4 = mn >> 2;
     if (i < n4) {
         float4 a = *reinterpret_cast<const float4*>(part + 4 * i);
+#pragma unroll 4      // four slab loads in flight; the additions keep their fixed order
         for (int s = 1; s < ksplit; ++s) {
             const float4 b = *reinterpret_cast<const float4*>(part + (long long)s * mn + 4 * i);
             a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;

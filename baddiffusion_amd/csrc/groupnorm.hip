@@ -471,19 +471,28 @@ __global__ __launch_bounds__(NT) void gn_fwd_res_kernel(const float* __restrict_
         gg[j] = gamma[c0 + lc]; bb[j] = beta[c0 + lc];
     }
     float* yb = y + (long long)b * HW * ldy + c0 + cq * 4;
+    // all outputs first (registers only), then the stores: with the arithmetic inside the per-element store branch hipcc
+    // waited vmcnt(0) for the previous element's stores before every element
+#pragma unroll
+    for (int i = 0; i < EMAX; ++i) {
+        const float in[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float z = (in[j] - mu[j]) * rs[j] * gg[j] + bb[j];
+            o[j] = silu ? silu_dev(z) : z;
+        }
+        v[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
 #pragma unroll
     for (int i = 0; i < EMAX; ++i) {
         const int p = prow + R * i;
         if (i < E && p < HW) {
-            const float in[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
-            float o[4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const float z = (in[j] - mu[j]) * rs[j] * gg[j] + bb[j];
-                o[j] = silu ? silu_dev(z) : z;
+            if (y) *reinterpret_cast<float4*>(yb + (long long)p * ldy) = v[i];
+            if (ys) {
+                const float o[4] = {v[i].x, v[i].y, v[i].z, v[i].w};
+                gn_store_split4(ys + 2 * ((long long)b * HW + p) * ldys, c0 + cq * 4, o);
             }
-            if (y) *reinterpret_cast<float4*>(yb + (long long)p * ldy) = make_float4(o[0], o[1], o[2], o[3]);
-            if (ys) gn_store_split4(ys + 2 * ((long long)b * HW + p) * ldys, c0 + cq * 4, o);
         }
     }
 }

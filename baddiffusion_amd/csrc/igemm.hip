@@ -1107,6 +1107,7 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(IGemmParams p, int nb
     const long long mn = idx - (long long)bz * per;
     const int m = (int)(mn / p.N), n = (int)(mn - (long long)m * p.N);
     float v = 0.f;
+#pragma unroll 4      // four slab loads in flight; the additions keep their fixed order
     for (int s = 0; s < p.ksplit; ++s) v += p.partial[((long long)(bz * p.ksplit + s)) * per + mn];
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
     const long long coff = bo * p.c_bso + bi * p.c_bsi;
