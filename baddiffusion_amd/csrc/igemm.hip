@@ -1359,8 +1359,14 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
             }
             return (double)rows * d.K * 4.0;
         };
-        char name[64];
-        snprintf(name, sizeof(name), "igemm_%s_%d%s", kClsName[cls], c.tile, d.mode == BD_MODE_BF16X3 ? "_bf16x3" : "");
+        char name[128];
+        static const bool shapes = getenv("BD_PROF_SHAPES") != nullptr;   // one class per shape (tuning aid)
+        if (shapes)
+            snprintf(name, sizeof(name), "igemm_%s_%d%s M%d N%d K%d b%d ks%d e%d%d%d%d", kClsName[cls], c.tile,
+                     d.mode == BD_MODE_BF16X3 ? "_bf16x3" : "", d.M, d.N, d.K, nb, c.ksplit, d.bias ? 1 : 0, d.rowbias ? 1 : 0,
+                     d.residual ? 1 : 0, d.accumulate ? 1 : 0);
+        else
+            snprintf(name, sizeof(name), "igemm_%s_%d%s", kClsName[cls], c.tile, d.mode == BD_MODE_BF16X3 ? "_bf16x3" : "");
         rec = prof_begin(name, 2.0 * d.M * d.N * (double)d.K * nb,
                          (op_bytes(d.A, d.M) + op_bytes(d.B, d.N) + (double)d.M * d.N * 4.0) * nb, stream);
     }
