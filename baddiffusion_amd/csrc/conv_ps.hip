@@ -482,6 +482,7 @@ struct PsWgParams {
     int P;                             // pixels = K
     int tiles_m, tiles_n, ksplit, cps; // chunks (of 32 pixels) per split
     int want_db;
+    int ablate;                        // -DBD_PS_ABLATION builds only, as in PsParams
 };
 
 typedef short ps_short4 __attribute__((ext_vector_type(4)));
@@ -541,7 +542,14 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
     }
     const long long a_adv = 32 * p.lddy * 4, b_adv = 32 * p.ldx * 4;
     int q_pix = c_begin * 32;   // first pixel of the next chunk to issue
+#ifdef BD_PS_ABLATION
+    int issued = 0;
+#endif
     auto issue = [&](char* stage) {
+#ifdef BD_PS_ABLATION
+        if ((p.ablate & 1) && issued >= 2) return;
+        ++issued;
+#endif
 #pragma unroll
         for (int j = 0; j < NDMA; ++j) {
             const int pp = q_pix + kpix[j];
@@ -580,6 +588,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
             bf16x8 ah[TMW], al[TMW], bh[2], bl[2];
+#ifdef BD_PS_ABLATION
+            if (p.ablate & 4) {
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) ah[i] = al[i] = __builtin_bit_cast(bf16x8, make_float4(1.f, 1.f, (float)s, 1.f));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) bh[q] = bl[q] = __builtin_bit_cast(bf16x8, make_float4(1.f, 1.f, (float)s, 1.f));
+            } else
+#endif
+            {
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
                 ah[i] = ps_tr_frag(sa, foff(wm * TMW + i, 0, 16 * s));
@@ -590,6 +607,16 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
                 bh[q] = ps_tr_frag(sb, foff(wn * 2 + q, 0, 16 * s));
                 bl[q] = ps_tr_frag(sb, foff(wn * 2 + q, 1, 16 * s));
             }
+            }
+#ifdef BD_PS_ABLATION
+            if (p.ablate & 2) {
+#pragma unroll
+                for (int i = 0; i < TMW; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+#pragma unroll
+                for (int q = 0; q < 2; ++q) asm volatile("" ::"v"(bh[q]), "v"(bl[q]));
+                continue;
+            }
+#endif
 #pragma unroll
             for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -969,6 +996,9 @@ int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
     if (prof_on())
         rec = prof_begin("conv_ps_wgrad", 2.0 * (double)p.P * d.Cout * 9.0 * d.Cin,
                          ((double)p.P * (d.Cin + d.Cout) + 9.0 * d.Cin * d.Cout) * 4.0, st);
+#ifdef BD_PS_ABLATION
+    p.ablate = getenv("BD_PS_ABLATE") ? atoi(getenv("BD_PS_ABLATE")) : 0;
+#endif
     static const int stages = getenv("BD_PS_WG_STAGES") ? atoi(getenv("BD_PS_WG_STAGES")) : 2;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.ksplit));
     // (NW = 4 -- 2 x 2 waves of 64 x 64 -- measured within +-2 % of NW = 8 on every layer; one form is kept)

@@ -39,6 +39,13 @@ static void gn_block(int C, int& threads, int& r) {
     threads = q * r;
 }
 
+// pixel rows per block of the apply kernels: 16 rows per thread (four / eight trips of the unrolled loop), at most 65535 blocks
+static int gn_apply_rows(int HW, int r) {
+    long long per = 16LL * r;
+    while (cdiv(HW, per) > 65535) per *= 2;
+    return (int)per;
+}
+
 __device__ __forceinline__ float silu_dev(float z) { return z / (1.0f + expf(-z)); }
 __device__ __forceinline__ float silu_grad_dev(float z) {
     const float s = 1.0f / (1.0f + expf(-z));
@@ -90,10 +97,15 @@ __global__ void gn_stats_kernel(const float* __restrict__ x, long long ldx, int 
     if (p1 > HW) p1 = HW;
     float sm[4] = {0.f, 0.f, 0.f, 0.f}, sq[4] = {0.f, 0.f, 0.f, 0.f};
     const float* xb = x + (long long)b * HW * ldx + cq * 4;
-    for (int p = p0 + prow; p < p1; p += r) {
-        const float4 v = *reinterpret_cast<const float4*>(xb + (long long)p * ldx);
-        sm[0] += v.x; sm[1] += v.y; sm[2] += v.z; sm[3] += v.w;
-        sq[0] += v.x * v.x; sq[1] += v.y * v.y; sq[2] += v.z * v.z; sq[3] += v.w * v.w;
+    for (int p = p0 + prow; p < p1; p += 4 * r) {   // four rows in flight (branch-free: rows past the end read zeros)
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = gn_ld4_if(xb + (long long)(p + u * r) * ldx, p + u * r < p1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            sm[0] += v[u].x; sm[1] += v[u].y; sm[2] += v[u].z; sm[3] += v[u].w;
+            sq[0] += v[u].x * v[u].x; sq[1] += v[u].y * v[u].y; sq[2] += v[u].z * v[u].z; sq[3] += v[u].w * v[u].w;
+        }
     }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -146,38 +158,54 @@ __global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(const double* __re
     }
 }
 
-// ---- forward apply: y = silu?((x - mean) * rstd * gamma + beta); grid = (blocks per sample, B)
-__global__ __launch_bounds__(256) void gn_apply_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
-                                                     long long ldy, int HW, int C, int G, const float* __restrict__ gamma,
-                                                     const float* __restrict__ beta, const float* __restrict__ mean,
-                                                     const float* __restrict__ rstd, int silu, unsigned short* __restrict__ ys,
-                                                     long long ldys) {
-    extern __shared__ float st[];  // [G][2]
-    const int b = blockIdx.y;
-    for (int g = threadIdx.x; g < G; g += 256) {
-        st[2 * g] = mean[b * G + g];
-        st[2 * g + 1] = rstd[b * G + g];
-    }
-    __syncthreads();
+// ---- forward apply: y = silu?((x - mean) * rstd * gamma + beta); grid = (pixel ranges, B), block = (C/4) x r threads:
+// a thread keeps its four channels' constants in registers and walks its pixel rows four at a time
+__global__ void gn_apply_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y, long long ldy, int HW, int C,
+                                int G, int r, int per, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                const float* __restrict__ mean, const float* __restrict__ rstd, int silu,
+                                unsigned short* __restrict__ ys, long long ldys) {
     const int q = C / 4, cpg = C / G;
-    const long long total4 = (long long)HW * q;
-    const float* xb = x + (long long)b * HW * ldx;
-    float* yb = y + (long long)b * HW * ldy;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % q) * 4;
-        const long long pix = i / q;
-        const float4 v = *reinterpret_cast<const float4*>(xb + pix * ldx + c);
-        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 be = *reinterpret_cast<const float4*>(beta + c);
-        float in[4] = {v.x, v.y, v.z, v.w}, gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w}, o[4];
+    const int t = threadIdx.x;
+    const int cq = t % q, prow = t / q;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * per;
+    int p1 = p0 + per;
+    if (p1 > HW) p1 = HW;
+    float mu[4], rs[4], gg[4], bb[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int g = (c + j) / cpg;
-            float z = (in[j] - st[2 * g]) * st[2 * g + 1] * gg[j] + bb[j];
-            o[j] = silu ? silu_dev(z) : z;
+    for (int j = 0; j < 4; ++j) {
+        const int c = cq * 4 + j;
+        mu[j] = mean[b * G + c / cpg]; rs[j] = rstd[b * G + c / cpg];
+        gg[j] = gamma[c]; bb[j] = beta[c];
+    }
+    const float* xb = x + (long long)b * HW * ldx + cq * 4;
+    float* yb = y + (long long)b * HW * ldy + cq * 4;
+    for (int p = p0 + prow; p < p1; p += 4 * r) {
+        float4 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) v[u] = gn_ld4_if(xb + (long long)(p + u * r) * ldx, p + u * r < p1);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float z = (in[j] - mu[j]) * rs[j] * gg[j] + bb[j];
+                o[j] = silu ? silu_dev(z) : z;
+            }
+            v[u] = make_float4(o[0], o[1], o[2], o[3]);
         }
-        if (y) *reinterpret_cast<float4*>(yb + pix * ldy + c) = make_float4(o[0], o[1], o[2], o[3]);
-        if (ys) gn_store_split4(ys + 2 * ((long long)b * HW + pix) * ldys, c, o);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int pu = p + u * r;
+            if (pu < p1) {
+                if (y) *reinterpret_cast<float4*>(yb + (long long)pu * ldy) = v[u];
+                if (ys) {
+                    const float o[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    gn_store_split4(ys + 2 * ((long long)b * HW + pu) * ldys, cq * 4, o);
+                }
+            }
+        }
     }
 }
 
@@ -208,18 +236,27 @@ __global__ void gn_bwd_stats_kernel(const float* __restrict__ x, long long ldx, 
     float s0[4] = {0.f, 0.f, 0.f, 0.f}, s1[4] = {0.f, 0.f, 0.f, 0.f}, s2[4] = {0.f, 0.f, 0.f, 0.f};
     const float* xb = x + (long long)b * HW * ldx + cq * 4;
     const float* db = dy + (long long)b * HW * lddy + cq * 4;
-    for (int p = p0 + prow; p < p1; p += r) {
-        const float4 v = *reinterpret_cast<const float4*>(xb + (long long)p * ldx);
-        const float4 d = *reinterpret_cast<const float4*>(db + (long long)p * lddy);
-        const float in[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w};
+    for (int p = p0 + prow; p < p1; p += 4 * r) {   // four rows of both tensors in flight, branch-free
+        float4 v[4], d[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float xh = (in[j] - mu[j]) * rs[j];
-            float dz = dd[j];
-            if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
-            s0[j] += dz;
-            s1[j] += dz * xh;
-            s2[j] += xh;
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = p + u * r < p1;
+            v[u] = gn_ld4_if(xb + (long long)(p + u * r) * ldx, ok);
+            d[u] = gn_ld4_if(db + (long long)(p + u * r) * lddy, ok);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const bool ok = p + u * r < p1;
+            const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, dd[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = ok ? (in[j] - mu[j]) * rs[j] : 0.f;
+                float dz = dd[j];
+                if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
+                s0[j] += dz;
+                s1[j] += dz * xh;
+                s2[j] += xh;
+            }
         }
     }
 #pragma unroll
@@ -265,99 +302,117 @@ __global__ __launch_bounds__(1024) void gn_bwd_param_kernel(const float* __restr
 }
 // ---- backward group finalize: per (b, g) s1 = sum gamma*dz, s2 = sum gamma*dz*xhat from the per-channel partials
 // (fixed order, fp64); optional per-sample column sums of dx in closed form (see gn_bwd_res_kernel).  One block per sample.
+// grid = (B, ceil(G / 8)): 8 groups per block, 32 split phases per group folded with a butterfly (fixed order)
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, int HW, int C, int G, int S,
                                                             const float* __restrict__ gamma, const float* __restrict__ rstd,
                                                             float inv_n, float* __restrict__ ds /* [B][G][2] */,
                                                             float* __restrict__ dx_colsum, long long ld_colsum) {
-    extern __shared__ float sg[];  // [G][2]
-    __shared__ double red[256][2];
-    const int b = blockIdx.x;
+    __shared__ float sg[8][2];
+    const int b = blockIdx.x, g0 = blockIdx.y * 8;
     const int cpg = C / G;
-    const int ph = threadIdx.x & 7;           // 8 threads per group: interleaved split phases, folded in a fixed order
-    for (int g0 = 0; g0 < G; g0 += 32) {
-        const int g = g0 + (threadIdx.x >> 3);
-        double a = 0.0, e = 0.0;
-        if (g < G)
-            for (int sp = ph; sp < S; sp += 8)
-                for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-                    const float* p = part + ((long long)b * S + sp) * 3 * C + c;
-                    e += (double)p[0] * gamma[c];
-                    a += (double)p[C] * gamma[c];
-                }
-        red[threadIdx.x][0] = a; red[threadIdx.x][1] = e;
-        __syncthreads();
-        if (ph == 0 && g < G) {
-            a = 0.0; e = 0.0;
-            for (int k = 0; k < 8; ++k) { a += red[threadIdx.x + k][0]; e += red[threadIdx.x + k][1]; }
-            sg[2 * g] = (float)a; sg[2 * g + 1] = (float)e;
-            ds[((long long)b * G + g) * 2] = (float)a;
-            ds[((long long)b * G + g) * 2 + 1] = (float)e;
-        }
-        __syncthreads();
-    }
-    if (dx_colsum) {
-        for (int c = threadIdx.x; c < C; c += 256) {
-            float a = 0.f, h = 0.f;
-            for (int sp = 0; sp < S; ++sp) {
+    const int gl = threadIdx.x >> 5, ph = threadIdx.x & 31, g = g0 + gl;
+    double a = 0.0, e = 0.0;
+    if (g < G)
+        for (int sp = ph; sp < S; sp += 32)
+            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
                 const float* p = part + ((long long)b * S + sp) * 3 * C + c;
-                a += p[C];
-                h += p[2 * C];
+                e += (double)p[0] * gamma[c];
+                a += (double)p[C] * gamma[c];
             }
-            const int g = c / cpg;
-            dx_colsum[(long long)b * ld_colsum + c] =
-                rstd[b * G + g] * (gamma[c] * a - ((float)HW * sg[2 * g] + sg[2 * g + 1] * h) * inv_n);
+    for (int off = 1; off < 32; off <<= 1) { a += __shfl_xor(a, off); e += __shfl_xor(e, off); }
+    if (ph == 0 && g < G) {
+        sg[gl][0] = (float)a; sg[gl][1] = (float)e;
+        ds[((long long)b * G + g) * 2] = (float)a;
+        ds[((long long)b * G + g) * 2 + 1] = (float)e;
+    }
+    __syncthreads();
+    if (dx_colsum) {
+        // channels of this block's groups; tpc threads per channel (a power of two, contiguous lanes), splits strided
+        int ng = G - g0;
+        if (ng > 8) ng = 8;
+        const int nch = ng * cpg;
+        int tpc = 1;
+        while (tpc < 32 && tpc * 2 * nch <= 256) tpc *= 2;
+        const int sub = threadIdx.x % tpc;
+        for (int base = 0; base < nch; base += 256 / tpc) {   // block-uniform trip count: every lane reaches the shuffles
+            const int cl = base + threadIdx.x / tpc;
+            float sa = 0.f, sh2 = 0.f;
+            if (cl < nch)
+                for (int sp = sub; sp < S; sp += tpc) {
+                    const float* p = part + ((long long)b * S + sp) * 3 * C + g0 * cpg + cl;
+                    sa += p[C];
+                    sh2 += p[2 * C];
+                }
+            for (int off = 1; off < tpc; off <<= 1) { sa += __shfl_xor(sa, off); sh2 += __shfl_xor(sh2, off); }
+            if (cl < nch && sub == 0) {
+                const int c = g0 * cpg + cl, gi = cl / cpg;
+                dx_colsum[(long long)b * ld_colsum + c] =
+                    rstd[b * G + g0 + gi] * (gamma[c] * sa - ((float)HW * sg[gi][0] + sg[gi][1] * sh2) * inv_n);
+            }
         }
     }
 }
 
-// ---- backward apply: dx (+)= rstd * (dz*gamma - (s1 + xhat*s2)/n); grid = (blocks per sample, B)
-__global__ __launch_bounds__(256) void gn_bwd_apply_kernel(const float* __restrict__ x, long long ldx,
-                                                         const float* __restrict__ dy, long long lddy,
-                                                         float* __restrict__ dx, long long lddx, int HW, int C, int G,
-                                                         const float* __restrict__ ds, const float* __restrict__ gamma,
-                                                         const float* __restrict__ beta, const float* __restrict__ mean,
-                                                         const float* __restrict__ rstd, float inv_n, int silu, int acc,
-                                                         unsigned short* __restrict__ dxs, long long lddxs) {
-    extern __shared__ float st[];  // [G][4] = mean, rstd, s1, s2
-    const int b = blockIdx.y;
+// ---- backward apply: dx (+)= rstd * (dz*gamma - (s1 + xhat*s2)/n); grid = (pixel ranges, B), block = (C/4) x r threads
+__global__ void gn_bwd_apply_kernel(const float* __restrict__ x, long long ldx, const float* __restrict__ dy, long long lddy,
+                                    float* __restrict__ dx, long long lddx, int HW, int C, int G, int r, int per,
+                                    const float* __restrict__ ds, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, const float* __restrict__ mean,
+                                    const float* __restrict__ rstd, float inv_n, int silu, int acc,
+                                    unsigned short* __restrict__ dxs, long long lddxs) {
     const int q = C / 4, cpg = C / G;
-    for (int g = threadIdx.x; g < G; g += 256) {
-        st[4 * g] = mean[b * G + g]; st[4 * g + 1] = rstd[b * G + g];
-        st[4 * g + 2] = ds[((long long)b * G + g) * 2]; st[4 * g + 3] = ds[((long long)b * G + g) * 2 + 1];
-    }
-    __syncthreads();
-    const long long total4 = (long long)HW * q;
-    const float* xb = x + (long long)b * HW * ldx;
-    const float* db = dy + (long long)b * HW * lddy;
-    float* ob = dx + (long long)b * HW * lddx;
-    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < total4; i += (long long)gridDim.x * 256) {
-        const int c = (int)(i % q) * 4;
-        const long long pix = i / q;
-        const float4 v = *reinterpret_cast<const float4*>(xb + pix * ldx + c);
-        const float4 d = *reinterpret_cast<const float4*>(db + pix * lddy + c);
-        const float4 ga = *reinterpret_cast<const float4*>(gamma + c);
-        const float4 be = *reinterpret_cast<const float4*>(beta + c);
-        const float in[4] = {v.x, v.y, v.z, v.w}, dd[4] = {d.x, d.y, d.z, d.w};
-        const float gg[4] = {ga.x, ga.y, ga.z, ga.w}, bb[4] = {be.x, be.y, be.z, be.w};
-        float o[4];
+    const int t = threadIdx.x;
+    const int cq = t % q, prow = t / q;
+    const int b = blockIdx.y;
+    const int p0 = blockIdx.x * per;
+    int p1 = p0 + per;
+    if (p1 > HW) p1 = HW;
+    float mu[4], rs[4], gg[4], bb[4], g1[4], g2[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const int g = (c + j) / cpg;
-            const float mu = st[4 * g], rs = st[4 * g + 1], s1 = st[4 * g + 2], s2 = st[4 * g + 3];
-            const float xh = (in[j] - mu) * rs;
-            float dz = dd[j];
-            if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
-            o[j] = rs * (dz * gg[j] - (s1 + xh * s2) * inv_n);
+    for (int j = 0; j < 4; ++j) {
+        const int c = cq * 4 + j, g = c / cpg;
+        mu[j] = mean[b * G + g]; rs[j] = rstd[b * G + g];
+        g1[j] = ds[((long long)b * G + g) * 2]; g2[j] = ds[((long long)b * G + g) * 2 + 1];
+        gg[j] = gamma[c]; bb[j] = beta[c];
+    }
+    const float* xb = x + (long long)b * HW * ldx + cq * 4;
+    const float* db = dy + (long long)b * HW * lddy + cq * 4;
+    float* ob = dx + (long long)b * HW * lddx + cq * 4;
+    const bool do_acc = dx && acc;
+    for (int p = p0 + prow; p < p1; p += 2 * r) {   // two rows of up to three tensors in flight, branch-free
+        float4 v[2], d[2], e[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const bool ok = p + u * r < p1;
+            v[u] = gn_ld4_if(xb + (long long)(p + u * r) * ldx, ok);
+            d[u] = gn_ld4_if(db + (long long)(p + u * r) * lddy, ok);
+            e[u] = gn_ld4_if(ob + (long long)(p + u * r) * lddx, ok && do_acc);
         }
-        if (dx) {
-            float4* dst = reinterpret_cast<float4*>(ob + pix * lddx + c);
-            if (acc) {
-                const float4 e = *dst;
-                o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, dd[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
+            const float ee[4] = {e[u].x, e[u].y, e[u].z, e[u].w};
+            float o[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float xh = (in[j] - mu[j]) * rs[j];
+                float dz = dd[j];
+                if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
+                o[j] = rs[j] * (dz * gg[j] - (g1[j] + xh * g2[j]) * inv_n) + ee[j];
             }
-            *dst = make_float4(o[0], o[1], o[2], o[3]);
+            v[u] = make_float4(o[0], o[1], o[2], o[3]);
         }
-        if (dxs) gn_store_split4(dxs + 2 * ((long long)b * HW + pix) * lddxs, c, o);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int pu = p + u * r;
+            if (pu < p1) {
+                if (dx) *reinterpret_cast<float4*>(ob + (long long)pu * lddx) = v[u];
+                if (dxs) {
+                    const float o[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
+                    gn_store_split4(dxs + 2 * ((long long)b * HW + pu) * lddxs, cq * 4, o);
+                }
+            }
+        }
     }
 }
 
@@ -753,15 +808,12 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
                        (long long)d->ldx, d->HW, d->C, d->G, r, S_, part);
     BD_LAUNCH_CHECK("gn_stats");
     {
-        const long long per4 = (long long)d->HW * (d->C / 4);
-        long long nbx = cdiv(per4, 256 * 4);           // ~4 float4 per thread
-        if (nbx < 1) nbx = 1;
-        if (nbx > 4096) nbx = 4096;
+        const int per = gn_apply_rows(d->HW, r);
         hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(d->B), dim3(256), 0, S(stream), part, d->G, S_,
                            (double)d->HW * (d->C / d->G), d->eps, d->mean, d->rstd);
-        hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)nbx, d->B), dim3(256), (size_t)d->G * 2 * sizeof(float), S(stream), d->x,
-                           (long long)d->ldx, d->y, (long long)d->ldy, d->HW, d->C, d->G, d->gamma, d->beta, d->mean, d->rstd,
-                           d->silu, d->y_split, (long long)d->ldys);
+        hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)cdiv(d->HW, per), d->B), dim3(threads), 0, S(stream), d->x,
+                           (long long)d->ldx, d->y, (long long)d->ldy, d->HW, d->C, d->G, r, per, d->gamma, d->beta, d->mean,
+                           d->rstd, d->silu, d->y_split, (long long)d->ldys);
     }
     BD_LAUNCH_CHECK("gn_apply");
     return BD_OK;
@@ -816,16 +868,14 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
                        d->C, d->dgamma, d->dbeta);
     BD_LAUNCH_CHECK("gn_bwd_param");
     {
-        const long long per4 = (long long)d->HW * (d->C / 4);
-        long long nbx = cdiv(per4, 256 * 4);
-        if (nbx < 1) nbx = 1;
-        if (nbx > 4096) nbx = 4096;
+        const int per = gn_apply_rows(d->HW, r);
         const float inv_n = 1.0f / ((float)d->HW * (d->C / d->G));
-        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(d->B), dim3(256), (size_t)d->G * 2 * sizeof(float), S(stream), part, d->HW,
-                           d->C, d->G, S_, d->gamma, d->rstd, inv_n, ds, d->dx_colsum, (long long)d->ld_colsum);
-        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)nbx, d->B), dim3(256), (size_t)d->G * 4 * sizeof(float), S(stream), d->x,
-                           (long long)d->ldx, d->dy, (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, ds, d->gamma,
-                           d->beta, d->mean, d->rstd, inv_n, d->silu, d->accumulate_dx, d->dx_split, (long long)d->lddxs);
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(d->B, (unsigned)cdiv(d->G, 8)), dim3(256), 0, S(stream), part, d->HW, d->C, d->G,
+                           S_, d->gamma, d->rstd, inv_n, ds, d->dx_colsum, (long long)d->ld_colsum);
+        hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)cdiv(d->HW, per), d->B), dim3(threads), 0, S(stream), d->x,
+                           (long long)d->ldx, d->dy, (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, r, per, ds,
+                           d->gamma, d->beta, d->mean, d->rstd, inv_n, d->silu, d->accumulate_dx, d->dx_split,
+                           (long long)d->lddxs);
     }
     BD_LAUNCH_CHECK("gn_bwd_apply");
     return BD_OK;

@@ -1121,7 +1121,8 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
         return split_wt_batched(params, const_cast<uint16_t*>(c.wT_split), u->wt_off.data(), u->wt_cin.data(), u->wt_cout.data(),
                                 (int)u->wt_off.size(), st);
     };
-    if (!u->aux_enabled || B < 32) {
+    static const int fwd_pipes = getenv("BD_FWD_PIPES") ? atoi(getenv("BD_FWD_PIPES")) : 2;   // 1 = forward on one stream (A/B)
+    if (!u->aux_enabled || B < 32 || fwd_pipes < 2) {
         BD_TRY(transpose_weights(c.st));
         for (auto& f : u->fwd) BD_TRY(f(c));
         return BD_OK;

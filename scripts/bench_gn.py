@@ -10,7 +10,11 @@ def timeit(fn, iters=20):
     for _ in range(iters): fn()
     b.record(); torch.cuda.synchronize()
     return a.elapsed_time(b) / iters * 1e3
-for (B, HW, Cc) in [(128, 1024, 128), (128, 1024, 256), (128, 256, 256), (128, 256, 512), (128, 1024, 384), (128, 64, 256)]:
+import sys
+SHAPES = [(128, 1024, 128), (128, 1024, 256), (128, 256, 256), (128, 256, 512), (128, 1024, 384), (128, 64, 256)]
+if len(sys.argv) > 1 and sys.argv[1] == "celeba":   # the split (non-resident) kernels: B = 4 at 256^2 .. 64^2
+    SHAPES = [(4, 65536, 128), (4, 65536, 256), (4, 16384, 128), (4, 16384, 256), (4, 4096, 256), (4, 4096, 512), (4, 1024, 512)]
+for (B, HW, Cc) in SHAPES:
     x = torch.randn(B, HW, Cc, device="cuda"); dy = torch.randn(B, HW, Cc, device="cuda")
     ga = torch.ones(Cc, device="cuda"); be = torch.zeros(Cc, device="cuda")
     ys = torch.empty(B * HW, Cc // 32, 2, 32, dtype=torch.int16, device="cuda")
