@@ -861,11 +861,12 @@ static void ps_small_split(long long M, int N, int K, int& ksplit, int& cps) {
         int dev = 0, cus = 256;
         if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
         const char* e = getenv("BD_PS_SMALL_SLOTS");
-        return e ? atoi(e) : 2 * cus;
+        return e ? atoi(e) : cus;   // (2 x CUs measured 0.1-0.2 ms/step slower: twice the slab traffic for the 4x4 / 8x8 layers)
     }();
+    static const int mincps = getenv("BD_PS_SMALL_MINCPS") ? atoi(getenv("BD_PS_SMALL_MINCPS")) : 4;
     int ks = (int)(slots / tiles);
     if (ks < 1) ks = 1;
-    if (ks > nchunks / 4) ks = nchunks / 4;
+    if (ks > nchunks / mincps) ks = nchunks / mincps;
     if (ks < 1) ks = 1;
     cps = (int)cdiv(nchunks, ks);
     ksplit = (int)cdiv(nchunks, cps);
@@ -960,9 +961,10 @@ static void ps_wgrad_split(const bd_conv3x3_ps_wgrad_desc& d, int& ksplit, int& 
         const char* e = getenv("BD_PS_WG_SLOTS");
         return e ? atoi(e) : 2 * cus;   // two 64-KB workgroups per CU (two LDS stages each): the pair de-phases, 141 vs 189 us
     }();
+    static const int mincps = getenv("BD_PS_WG_MINCPS") ? atoi(getenv("BD_PS_WG_MINCPS")) : 8;   // chunks per split at least (4x4 layers: 8 slabs instead of 14; 4 / 16 measured +0.2 / +0.1 ms)
     int ks = (int)(slots / tiles);
     if (ks < 1) ks = 1;
-    if (ks > nchunks / 4) ks = nchunks / 4 > 0 ? nchunks / 4 : 1;
+    if (ks > nchunks / mincps) ks = nchunks / mincps > 0 ? nchunks / mincps : 1;
     cps = (int)cdiv(nchunks, ks);
     ksplit = (int)cdiv(nchunks, cps);
 }
@@ -1002,6 +1004,12 @@ int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
     static const int stages = getenv("BD_PS_WG_STAGES") ? atoi(getenv("BD_PS_WG_STAGES")) : 2;
     const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.ksplit));
     // (NW = 4 -- 2 x 2 waves of 64 x 64 -- measured within +-2 % of NW = 8 on every layer; one form is kept)
+#ifdef BD_PS_ABLATION
+    static const int nw = getenv("BD_PS_WG_NW") ? atoi(getenv("BD_PS_WG_NW")) : 8;
+    if (nw == 4 && stages == 2) hipLaunchKernelGGL((conv_ps_wgrad_kernel<2, 4>), grid, dim3(256), 0, st, p);
+    else if (nw == 4) hipLaunchKernelGGL((conv_ps_wgrad_kernel<3, 4>), grid, dim3(256), 0, st, p);
+    else
+#endif
     if (stages == 2) hipLaunchKernelGGL((conv_ps_wgrad_kernel<2, 8>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv_ps_wgrad_kernel<3, 8>), grid, dim3(512), 0, st, p);
     BD_LAUNCH_CHECK("conv_ps_wgrad");

@@ -62,7 +62,9 @@ def test_batch_sampling_chunks_and_png(gpu, tmp_path):
     pipe_call = lambda **kw: orig(num_inference_steps=2, **kw)
     a = batch_sampling(5, pipe_call, init=init, max_batch_n=2)
     b = batch_sampling(5, pipe_call, init=init, max_batch_n=8)
-    np.testing.assert_allclose(a, b, rtol=0, atol=1e-6)          # chunking is exact: chains are independent
+    # chains are independent, so chunking changes nothing but the K-split (summation order) the small layers pick for the
+    # chunk's batch size: fp32 reassociation noise through two UNet evaluations, far below the 1e-3 parity tolerance
+    np.testing.assert_allclose(a, b, rtol=0, atol=1e-4)
     batch_sampling_save(5, pipe_call, str(tmp_path / "o"), init=init, max_batch_n=2)
     from PIL import Image
     import os
