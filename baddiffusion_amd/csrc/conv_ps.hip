@@ -17,6 +17,8 @@
 // with the gather direction negated (sign = -1) over the TRANSPOSED weight planes Wt[ci][tap][co] (bd_split_wt).
 // Replaces aten::convolution / convolution_backward(input) of resnet.py:493,514 for the stride-1 convolutions.
 #include "common.h"
+
+#include <type_traits>
 #include <cstdlib>
 
 namespace bd {
@@ -496,6 +498,21 @@ __device__ __forceinline__ bf16x8 ps_tr_frag(const char* lds, int off) {
     return __builtin_bit_cast(bf16x8, v);
 }
 
+// The same read as inline asm, address = LDS byte offset.  hipcc puts `s_waitcnt vmcnt(0)` in front of the intrinsic form
+// whenever LDS-DMA loads are in flight (it cannot tell the stage being read from the stage being filled), so every chunk
+// waited for the NEXT chunk's DMA before its first fragment read.  The asm form is opaque to that pass; the matching
+// s_waitcnt lgkmcnt(0) is tied to the fragment registers so that no consumer can be scheduled above it.
+template <int OFF>
+__device__ __forceinline__ ps_short4 ps_tr_read(unsigned addr) {
+    ps_short4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1 offset:%2" : "=v"(v) : "v"(addr), "n"(OFF));
+    return v;
+}
+__device__ __forceinline__ bf16x8 ps_tr_join(ps_short4 v0, ps_short4 v1) {
+    const ps_short8 v = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, v);
+}
+
 // NW = 8: waves 4 x 2, 32 x 64 each.  NW = 4: waves 2 x 2, 64 x 64 each (a third fewer LDS fragment reads per MFMA, twice
 // the MFMAs between barriers, half the waves per SIMD).
 template <int STAGES, int NW>
@@ -545,21 +562,22 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
 #ifdef BD_PS_ABLATION
     int issued = 0;
 #endif
+    auto issue_j = [&](char* stage, int j) {
+        const int pp = q_pix + kpix[j];
+        const int x = pp & (p.W - 1), y = (pp >> p.lw) & (p.H - 1);
+        const bool in = pp < p.P;
+        const bool ok = in && (unsigned)(y + dyt) < (unsigned)p.H && (unsigned)(x + dxt) < (unsigned)p.W;
+        ps_dma16(in ? asrc[j] : reinterpret_cast<const char*>(kPsZero), stage + (wave + NW * j) * 1024);
+        ps_dma16(ok ? bsrc[j] : reinterpret_cast<const char*>(kPsZero), stage + WG_OP_BYTES + (wave + NW * j) * 1024);
+        asrc[j] += a_adv; bsrc[j] += b_adv;
+    };
     auto issue = [&](char* stage) {
 #ifdef BD_PS_ABLATION
         if ((p.ablate & 1) && issued >= 2) return;
         ++issued;
 #endif
 #pragma unroll
-        for (int j = 0; j < NDMA; ++j) {
-            const int pp = q_pix + kpix[j];
-            const int x = pp & (p.W - 1), y = (pp >> p.lw) & (p.H - 1);
-            const bool in = pp < p.P;
-            const bool ok = in && (unsigned)(y + dyt) < (unsigned)p.H && (unsigned)(x + dxt) < (unsigned)p.W;
-            ps_dma16(in ? asrc[j] : reinterpret_cast<const char*>(kPsZero), stage + (wave + NW * j) * 1024);
-            ps_dma16(ok ? bsrc[j] : reinterpret_cast<const char*>(kPsZero), stage + WG_OP_BYTES + (wave + NW * j) * 1024);
-            asrc[j] += a_adv; bsrc[j] += b_adv;
-        }
+        for (int j = 0; j < NDMA; ++j) issue_j(stage, j);
         q_pix += 32;
     };
 
@@ -582,92 +600,142 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-    auto compute = [&](const char* stage) {
-        const char* sa = stage;
-        const char* sb = stage + WG_OP_BYTES;
+    // stage-relative fragment addresses of this wave's tiles (the 16-pixel step and the pixel half are immediates)
+    unsigned aoff[TMW][2], boff[2][2];
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            bf16x8 ah[TMW], al[TMW], bh[2], bl[2];
+    for (int i = 0; i < TMW; ++i)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) aoff[i][pl] = (unsigned)foff(wm * TMW + i, pl, 0);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) boff[q][pl] = (unsigned)foff(wn * 2 + q, pl, 0) + WG_OP_BYTES;
+    const unsigned smem_addr = (unsigned)(uintptr_t)(lds_ptr)smem;
+
+    struct Frag { ps_short4 a0[TMW][2], a1[TMW][2], b0[2][2], b1[2][2]; };
+    auto reads = [&](auto S, unsigned sbase, Frag& f) {
+        constexpr int KOFF = decltype(S)::value * 16 * 512;
 #ifdef BD_PS_ABLATION
-            if (p.ablate & 4) {
+        if (p.ablate & 4) {
 #pragma unroll
-                for (int i = 0; i < TMW; ++i) ah[i] = al[i] = __builtin_bit_cast(bf16x8, make_float4(1.f, 1.f, (float)s, 1.f));
+            for (int i = 0; i < TMW; ++i)
 #pragma unroll
-                for (int q = 0; q < 2; ++q) bh[q] = bl[q] = __builtin_bit_cast(bf16x8, make_float4(1.f, 1.f, (float)s, 1.f));
-            } else
+                for (int pl = 0; pl < 2; ++pl) f.a0[i][pl] = f.a1[i][pl] = ps_short4{0x3f80, 0x3f80, 0x3f80, 0x3f80};
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) f.b0[q][pl] = f.b1[q][pl] = ps_short4{0x3f80, 0x3f80, 0x3f80, 0x3f80};
+            return;
+        }
 #endif
-            {
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                f.a0[i][pl] = ps_tr_read<KOFF>(sbase + aoff[i][pl]);
+                f.a1[i][pl] = ps_tr_read<KOFF + 4 * 512>(sbase + aoff[i][pl]);
+            }
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                f.b0[q][pl] = ps_tr_read<KOFF>(sbase + boff[q][pl]);
+                f.b1[q][pl] = ps_tr_read<KOFF + 4 * 512>(sbase + boff[q][pl]);
+            }
+    };
+    // all LDS reads of this wave have returned; the fragment registers pass through the asm so no MFMA can move above it
+    auto wait = [&](Frag& f) {
+        if constexpr (TMW == 1)
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f.a0[0][0]), "+v"(f.a1[0][0]), "+v"(f.a0[0][1]), "+v"(f.a1[0][1]), "+v"(f.b0[0][0]), "+v"(f.b1[0][0]),
+                           "+v"(f.b0[0][1]), "+v"(f.b1[0][1]), "+v"(f.b0[1][0]), "+v"(f.b1[1][0]), "+v"(f.b0[1][1]), "+v"(f.b1[1][1]));
+        else
+            asm volatile("s_waitcnt lgkmcnt(0)"
+                         : "+v"(f.a0[0][0]), "+v"(f.a1[0][0]), "+v"(f.a0[0][1]), "+v"(f.a1[0][1]), "+v"(f.a0[TMW - 1][0]),
+                           "+v"(f.a1[TMW - 1][0]), "+v"(f.a0[TMW - 1][1]), "+v"(f.a1[TMW - 1][1]), "+v"(f.b0[0][0]), "+v"(f.b1[0][0]),
+                           "+v"(f.b0[0][1]), "+v"(f.b1[0][1]), "+v"(f.b0[1][0]), "+v"(f.b1[1][0]), "+v"(f.b0[1][1]), "+v"(f.b1[1][1]));
+    };
+    auto mfmas = [&](const Frag& f) {
+        bf16x8 ah[TMW], al[TMW], bh[2], bl[2];
+#pragma unroll
+        for (int i = 0; i < TMW; ++i) { ah[i] = ps_tr_join(f.a0[i][0], f.a1[i][0]); al[i] = ps_tr_join(f.a0[i][1], f.a1[i][1]); }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { bh[q] = ps_tr_join(f.b0[q][0], f.b1[q][0]); bl[q] = ps_tr_join(f.b0[q][1], f.b1[q][1]); }
+#ifdef BD_PS_ABLATION
+        if (p.ablate & 2) {
+#pragma unroll
+            for (int i = 0; i < TMW; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
+#pragma unroll
+            for (int q = 0; q < 2; ++q) asm volatile("" ::"v"(bh[q]), "v"(bl[q]));
+            return;
+        }
+#endif
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < TMW; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
+        if (do_db) {
 #pragma unroll
             for (int i = 0; i < TMW; ++i) {
-                ah[i] = ps_tr_frag(sa, foff(wm * TMW + i, 0, 16 * s));
-                al[i] = ps_tr_frag(sa, foff(wm * TMW + i, 1, 16 * s));
-            }
-#pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                bh[q] = ps_tr_frag(sb, foff(wn * 2 + q, 0, 16 * s));
-                bl[q] = ps_tr_frag(sb, foff(wn * 2 + q, 1, 16 * s));
-            }
-            }
-#ifdef BD_PS_ABLATION
-            if (p.ablate & 2) {
-#pragma unroll
-                for (int i = 0; i < TMW; ++i) asm volatile("" ::"v"(ah[i]), "v"(al[i]));
-#pragma unroll
-                for (int q = 0; q < 2; ++q) asm volatile("" ::"v"(bh[q]), "v"(bl[q]));
-                continue;
-            }
-#endif
-#pragma unroll
-            for (int i = 0; i < TMW; ++i)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[q], acc[i][q], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TMW; ++i)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[q], acc[i][q], 0, 0, 0);
-#pragma unroll
-            for (int i = 0; i < TMW; ++i)
-#pragma unroll
-                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
-            if (do_db) {
-#pragma unroll
-                for (int i = 0; i < TMW; ++i) {
-                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], ones, accb[i], 0, 0, 0);
-                    accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], ones, accb[i], 0, 0, 0);
-                }
+                accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], ones, accb[i], 0, 0, 0);
+                accb[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], ones, accb[i], 0, 0, 0);
             }
         }
+    };
+    // one chunk: the second 16-pixel step's fragments are read while the first step's MFMAs run, and the next chunk's DMA
+    // pieces are issued between the groups (next == nullptr: nothing left to fetch)
+    auto chunk = [&](const char* stage, char* next) {
+        const unsigned sbase = smem_addr + (unsigned)(stage - smem);
+        Frag f0, f1;
+        reads(std::integral_constant<int, 0>{}, sbase, f0);
+#ifdef BD_PS_ABLATION
+        if ((p.ablate & 1) && issued >= 2) next = nullptr;
+        if (next) ++issued;
+#endif
+        if (next) issue_j(next, 0);
+        wait(f0);
+        reads(std::integral_constant<int, 1>{}, sbase, f1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(f0);
+        if (next) {
+#pragma unroll
+            for (int j = 1; j < NDMA; ++j) issue_j(next, j);
+            q_pix += 32;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        wait(f1);
+        mfmas(f1);
     };
 
     const int n = c_end - c_begin;
     if constexpr (STAGES == 3) {
-        // ring of three: chunk c+2 is issued behind the barrier that frees chunk c-1's stage; 4 DMAs per wave and chunk
-        char* st[3] = {smem, smem + WG_STAGE_BYTES, smem + 2 * WG_STAGE_BYTES};
-        if (n > 0) issue(st[0]);
-        if (n > 1) issue(st[1]);
-        int c = 0;
-        for (; c + 2 < n; ++c) {   // steady state: two chunks in flight behind the one being waited for
-            if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+        // ring of three: chunk c+2 is issued behind the barrier that frees chunk c-1's stage
+        if (n > 0) issue(smem);
+        if (n > 1) issue(smem + WG_STAGE_BYTES);
+        for (int c = 0; c < n; ++c) {
+            if (c + 1 < n) {
+                if constexpr (NW == 8) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+                else asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            } else {
+                asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            }
             __builtin_amdgcn_s_barrier();
-            const int cur = c % 3, nxt = (c + 2) % 3;
-            issue(smem + nxt * WG_STAGE_BYTES);
-            compute(smem + cur * WG_STAGE_BYTES);
-        }
-        for (; c < n; ++c) {
-            if (c + 1 < n && NW == 8) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
-            else if (c + 1 < n) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            compute(smem + (c % 3) * WG_STAGE_BYTES);
+            chunk(smem + (c % 3) * WG_STAGE_BYTES, c + 2 < n ? smem + ((c + 2) % 3) * WG_STAGE_BYTES : nullptr);
         }
     } else {
         if (n > 0) issue(smem);
         for (int c = 0; c < n; ++c) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
-            if (c + 1 < n) issue(smem + ((c + 1) & 1) * WG_STAGE_BYTES);
-            compute(smem + (c & 1) * WG_STAGE_BYTES);
+            chunk(smem + (c & 1) * WG_STAGE_BYTES, c + 1 < n ? smem + ((c + 1) & 1) * WG_STAGE_BYTES : nullptr);
         }
     }
 
