@@ -388,6 +388,9 @@ def main():
                                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
                                    "mfma_flops_per_algorithmic_flop": 1 if args.mode == "f32" else 3,
                                    "mfma_dense_peak": FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS,
+                                   # scripts/probe/mfma_probe.hip: register-operand v_mfma_f32_32x32x16_bf16 only, random bf16
+                                   # data -> 1850 TFLOP/s at the 1400 W board limit (2470 with constant operands); DESIGN.md s.3
+                                   "mfma_power_limited_peak_measured": None if args.mode == "f32" else 1850.0,
                                    "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                                    "launches_per_step": d["launches"] / prof_steps, "sampled_steps": prof_steps,
                                    "avg_launch_us": d["ms"] * 1e3 / d["launches"],
