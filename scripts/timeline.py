@@ -44,3 +44,19 @@ for t, d, c in pts:
     cnt[c] += d; last = t
 segs.sort(reverse=True)
 print("  longest stretches without an MFMA kernel:", [(round(a / 1e3), round(b / 1e6, 2), c) for a, b, c in segs[:12]], "(us, at ms, kind)")
+# merge adjacent non-MFMA stretches (gaps < 3 us) and name the kernels inside the longest ones
+segs2 = []
+cnt = [0, 0]; last = t0; cur = None
+for t, d, c in pts:
+    if not cnt[0] and t > last:
+        if cur and last - cur[1] < 3000: cur[1] = t
+        else:
+            if cur: segs2.append(tuple(cur))
+            cur = [last, t]
+    cnt[c] += d; last = t
+if cur: segs2.append(tuple(cur))
+segs2.sort(key=lambda ab: ab[0] - ab[1])
+print("  merged stretches without an MFMA kernel in flight (total %.2f ms):" % (sum(b - a for a, b in segs2) / 1e6))
+for a, b in segs2[:10]:
+    names = [n.split("(")[0].replace("void bd::", "").replace("bd::", "")[:28] for s_, e_, n, q in win if s_ < b and e_ > a and not mf(n)]
+    print(f"    {(b - a) / 1e3:6.0f} us at {(a - t0) / 1e6:6.2f} ms: {names[:8]}")
