@@ -480,7 +480,7 @@ __device__ __forceinline__ void gn_fwd_group_stats(double a, double c2, double n
 }
 
 template <int EMAX, int NT>
-__global__ __launch_bounds__(NT) void gn_fwd_res_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
+__global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void gn_fwd_res_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y,
                                                        long long ldy, int HW, int C, int G, int cb, int q, int R, int E,
                                                        float eps, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float* __restrict__ mean,
