@@ -52,7 +52,11 @@ class GnBwdDesc(C.Structure):
                 ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp),
                 ("dy", vp), ("lddy", i64), ("dx", vp), ("lddx", i64), ("accumulate_dx", i32),
                 ("dgamma", vp), ("dbeta", vp), ("workspace", vp), ("workspace_bytes", sz),
-                ("dx_colsum", vp), ("ld_colsum", i64), ("dx_split", vp), ("lddxs", i64)]
+                ("dx_colsum", vp), ("ld_colsum", i64), ("dx_split", vp), ("lddxs", i64), ("param_partials", vp)]
+
+
+class GnParamItem(C.Structure):
+    _fields_ = [("partials", vp), ("C", i32), ("dgamma", vp), ("dbeta", vp)]
 
 
 class Operand(C.Structure):
@@ -135,6 +139,8 @@ SIGNATURES = {
     "bd_gn_workspace_bytes": (sz, [i32, i32]),
     "bd_gn_fwd": (i32, [C.POINTER(GnFwdDesc), vp]),
     "bd_gn_bwd": (i32, [C.POINTER(GnBwdDesc), vp]),
+    "bd_gn_bwd_defers": (i32, [i32, i32, i32, i32]),
+    "bd_gn_bwd_params": (i32, [C.POINTER(GnParamItem), i32, i32, vp]),
     "bd_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),
     "bd_igemm": (i32, [C.POINTER(IgemmDesc), vp]),
     "bd_split_bf16": (i32, [vp, i64, vp, vp]),

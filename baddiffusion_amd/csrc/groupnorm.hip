@@ -300,6 +300,33 @@ __global__ __launch_bounds__(1024) void gn_bwd_param_kernel(const float* __restr
         if (n < C) dgamma[n] = v; else dbeta[n - C] = v;
     }
 }
+// (a') the same fold for up to GN_PARAM_MAX layers whose per-sample partials [B][2][C] were left to the caller
+// (bd_gn_bwd_desc.param_partials): one launch per backward segment instead of one per GroupNorm
+constexpr int GN_PARAM_MAX = 32;
+struct GnParamTable {
+    const float* part[GN_PARAM_MAX]; float* dg[GN_PARAM_MAX]; float* db[GN_PARAM_MAX];
+    int C[GN_PARAM_MAX]; int blk0[GN_PARAM_MAX + 1]; int n;
+};
+__global__ __launch_bounds__(1024) void gn_bwd_param_batched_kernel(GnParamTable t, int rows) {
+    __shared__ double red[16][64];
+    int i = 0;
+    while (i + 1 < t.n && (int)blockIdx.x >= t.blk0[i + 1]) ++i;
+    const int C = t.C[i];
+    const float* part = t.part[i];
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    const int n = ((int)blockIdx.x - t.blk0[i]) * 64 + tx;
+    double s = 0.0;
+    if (n < 2 * C)
+        for (int r = ty; r < rows; r += 16) s += (double)part[(long long)r * 2 * C + n];
+    red[ty][tx] = s;
+    __syncthreads();
+    if (ty == 0 && n < 2 * C) {
+        double v = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) v += red[k][tx];
+        if (n < C) t.dg[i][n] = (float)v; else t.db[i][n - C] = (float)v;
+    }
+}
 // ---- backward group finalize: per (b, g) s1 = sum gamma*dz, s2 = sum gamma*dz*xhat from the per-channel partials
 // (fixed order, fp64); optional per-sample column sums of dx in closed form (see gn_bwd_res_kernel).  One block per sample.
 // grid = (B, ceil(G / 8)): 8 groups per block, 32 split phases per group folded with a butterfly (fixed order)
@@ -819,6 +846,30 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
     return BD_OK;
 }
 
+extern "C" int bd_gn_bwd_defers(int B, int HW, int C, int G) {
+    GnRes rp;
+    return B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && (C & 3) == 0 && gn_resident_plan(B, HW, C, G, rp, true) ? 1 : 0;
+}
+
+extern "C" int bd_gn_bwd_params(const bd_gn_param_item* items, int n, int B, bd_stream_t stream) {
+    BD_CHECK(items && n > 0 && B > 0, BD_ERR_INVALID, "bd_gn_bwd_params: bad arguments");
+    for (int i0 = 0; i0 < n; i0 += GN_PARAM_MAX) {
+        GnParamTable t;
+        t.n = n - i0 < GN_PARAM_MAX ? n - i0 : GN_PARAM_MAX;
+        int blk = 0;
+        for (int i = 0; i < t.n; ++i) {
+            const bd_gn_param_item& it = items[i0 + i];
+            BD_CHECK(it.partials && it.dgamma && it.dbeta && it.C > 0, BD_ERR_INVALID, "bd_gn_bwd_params: item %d", i0 + i);
+            t.part[i] = it.partials; t.dg[i] = it.dgamma; t.db[i] = it.dbeta; t.C[i] = it.C; t.blk0[i] = blk;
+            blk += (int)cdiv(2 * it.C, 64);
+        }
+        t.blk0[t.n] = blk;
+        hipLaunchKernelGGL(gn_bwd_param_batched_kernel, dim3((unsigned)blk), dim3(1024), 0, S(stream), t, B);
+        BD_LAUNCH_CHECK("gn_bwd_param_batched");
+    }
+    return BD_OK;
+}
+
 extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
     BD_CHECK(d, BD_ERR_INVALID, "bd_gn_bwd: null descriptor");
     BD_TRY(gn_common_checks("bd_gn_bwd", d->B, d->HW, d->C, d->G, d->x, d->ldx));
@@ -832,9 +883,9 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
     BD_CHECK(!(d->dx_colsum && d->accumulate_dx), BD_ERR_INVALID, "bd_gn_bwd: dx_colsum is the column sum of the written dx");
     GnRes rp;
     if (gn_resident_plan(d->B, d->HW, d->C, d->G, rp, true)) {
-        const size_t need_r = (size_t)d->B * d->C * 2 * sizeof(float);
+        const size_t need_r = d->param_partials ? 0 : (size_t)d->B * d->C * 2 * sizeof(float);
         BD_CHECK(d->workspace_bytes >= need_r, BD_ERR_WORKSPACE, "bd_gn_bwd: workspace %zu < %zu", d->workspace_bytes, need_r);
-        float* part_r = reinterpret_cast<float*>(d->workspace);
+        float* part_r = d->param_partials ? d->param_partials : reinterpret_cast<float*>(d->workspace);
         const dim3 grid((unsigned)rp.nblk * (unsigned)d->B);
 #define BD_GN_BWD_RES(EM, NT)                                                                                              \
     hipLaunchKernelGGL((gn_bwd_res_kernel<EM, NT>), grid, dim3(NT), 0, S(stream), d->x, (long long)d->ldx, d->dy,            \
@@ -847,6 +898,7 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
         else BD_GN_BWD_RES(GN_RES_EMAX, 256);
 #undef BD_GN_BWD_RES
         BD_LAUNCH_CHECK("gn_bwd_res");
+        if (d->param_partials) return BD_OK;   // the caller folds them (bd_gn_bwd_params)
         hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(1024), 0, S(stream), part_r, d->B, 2 * d->C,
                            d->C, d->dgamma, d->dbeta);
         BD_LAUNCH_CHECK("gn_bwd_param");

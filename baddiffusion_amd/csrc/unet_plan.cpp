@@ -80,6 +80,22 @@ struct Ctx {
     const uint16_t* w_split = nullptr;   // pre-split weights (BF16X3, bd_split_bf16 layout): element e of params <-> 2*e here
     const uint16_t* wT_split = nullptr;  // transposed split planes Wt[ci][tap][co] of the 3x3 conv weights, same element offsets
     std::vector<char> ginit;
+    // GroupNorm weight / bias gradients: the layers leave their per-sample partials in `gnpart` and ONE launch per
+    // backward call folds them (bd_gn_bwd_params) -- 51 small launches off the dgrad chain of the CIFAR step
+    float* gnpart = nullptr; size_t gnpart_floats = 0, gnpart_used = 0, gnpart_need = 0;
+    std::vector<bd_gn_param_item> gn_items;
+    // hands a GroupNorm backward its slot (or nothing: the layer then reduces its own parameters as before)
+    float* gn_slot(int B, int HW, int C, int G, float* dgamma, float* dbeta) {
+        if (!bd_gn_bwd_defers(B, HW, C, G)) return nullptr;
+        const size_t n = ((size_t)B * 2 * C + 63) / 64 * 64;
+        if (dry) { gnpart_need += n; return nullptr; }
+        if (!gnpart || gnpart_used + n > gnpart_floats) return nullptr;
+        float* p = gnpart + gnpart_used;
+        gnpart_used += n;
+        bd_gn_param_item it; it.partials = p; it.C = C; it.dgamma = dgamma; it.dbeta = dbeta;
+        gn_items.push_back(it);
+        return p;
+    }
 };
 
 typedef std::function<int(Ctx&)> Step;
@@ -108,7 +124,7 @@ struct bd_unet {
     // layout cache
     int lay_B = -1, lay_train = -1;
     int64_t value_floats = 0, grad_floats = 0, scratch_floats = 0;
-    size_t opws_bytes = 0;
+    size_t opws_bytes = 0, gnpart_floats = 0;
     int T = 0, sumC = 0;     // time-embed dim, total time_emb_proj rows
     int64_t p_tw = 0, p_tb = 0;  // offsets of the batched time_emb_proj weight / bias
     int b_tproj = -1, b_dtproj = -1, b_embs = -1;
@@ -276,6 +292,7 @@ struct bd_unet {
         c.ginit[x.buf] = 1;
         d.dgamma = c.grads + pg; d.dbeta = c.grads + pb;
         d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
+        d.param_partials = c.gn_slot(d.B, d.HW, d.C, d.G, d.dgamma, d.dbeta);
         if (c.dry) return BD_OK;
         return bd_gn_bwd(&d, (bd_stream_t)c.st);
     }
@@ -553,6 +570,7 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             // time-embedding gradient = per-sample column sums of dh1, out of the same launch
             d.dx_colsum = BP(c, b_dtproj) + toff; d.ld_colsum = sumC_;
             if (ps1) { d.dx_split = U16(BP(c, b_dh1S)); d.lddxs = Cout; }
+            d.param_partials = c.gn_slot(d.B, d.HW, d.C, d.G, d.dgamma, d.dbeta);
             if (!c.dry) BD_TRY(bd_gn_bwd(&d, (bd_stream_t)c.st));
         }
         // this resnet's rows of the batched time_emb_proj weight / bias gradient: dW = dtproj[:, rows]^T embs (resnet.py:571)
@@ -996,6 +1014,7 @@ void bd_unet::layout(int B, int training) {
     for (auto& f : fwd) f(c);
     if (training) for (auto it = bwd.rbegin(); it != bwd.rend(); ++it) it->fn(c);
     opws_bytes = align_up(c.opws_need, 256);
+    gnpart_floats = training ? c.gnpart_need : 0;
     lay_B = B; lay_train = training;
 }
 
@@ -1068,7 +1087,8 @@ extern "C" size_t bd_unet_workspace_bytes(bd_unet* u, int B, int training) {
     if (!u || B <= 0) return 0;
     u->layout(B, training);
     return (size_t)(u->value_floats + u->grad_floats + u->scratch_floats) * sizeof(float) + u->opws_bytes + 256 +
-           2 * wsplit_bytes(u) + align_up(u->opws_bytes, 256);   // + transposed conv-weight planes + the side stream's op workspace
+           2 * wsplit_bytes(u) + align_up(u->opws_bytes, 256) +   // + transposed conv-weight planes + the side stream's op workspace
+           align_up(u->gnpart_floats * sizeof(float), 256);      // + GroupNorm parameter partials of one backward
 }
 
 static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, size_t workspace_bytes) {
@@ -1086,6 +1106,8 @@ static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, si
         c.w_split = reinterpret_cast<const uint16_t*>(c.opws + align_up(u->opws_bytes, 256));
     }
     c.opws2 = c.opws + align_up(u->opws_bytes, 256) + 2 * wsplit_bytes(u);
+    c.gnpart = u->gnpart_floats ? reinterpret_cast<float*>(c.opws2 + align_up(u->opws_bytes, 256)) : nullptr;
+    c.gnpart_floats = u->gnpart_floats; c.gnpart_used = 0;
     if (c.w_split) c.wT_split = reinterpret_cast<const uint16_t*>(c.opws + align_up(u->opws_bytes, 256) + wsplit_bytes(u));
     c.ginit.assign(u->bufs.size(), 0);
     return BD_OK;
@@ -1198,6 +1220,7 @@ extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float*
         if (s != BD_OK) return s;
         if (run) BD_TRY(bd_unet::aux_mark(c, par));
     }
+    if (!c.gn_items.empty()) BD_TRY(bd_gn_bwd_params(c.gn_items.data(), (int)c.gn_items.size(), c.B, (bd_stream_t)c.st));
     BD_TRY(bd_unet::aux_wait(c, 0));   // every weight gradient of this call is ordered before what the caller enqueues next
     BD_TRY(bd_unet::aux_wait(c, 1));
     if (seg >= 0) {

@@ -154,8 +154,22 @@ typedef struct {
                                                the time-embedding gradient of resnet.py:571            */
     uint16_t* dx_split; int64_t lddxs;      /* optional: this launch's dx term also / only (dx == NULL) as split
                                                planes (not accumulated)                                            */
+    float* param_partials;                  /* optional [B][2][C], caller storage: if set and bd_gn_bwd_defers(B, HW, C, G),
+                                               the per-sample partial sums of (dgamma, dbeta) are left here and dgamma /
+                                               dbeta are NOT written -- fold many layers later with ONE bd_gn_bwd_params
+                                               launch (51 GroupNorms per CIFAR backward, one launch per segment)      */
 } bd_gn_bwd_desc;
 int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream);
+/* 1 if this shape takes the single-pass kernel that can leave its parameter partials to the caller, else 0 */
+int bd_gn_bwd_defers(int B, int HW, int C, int G);
+typedef struct {
+    const float* partials;                  /* [B][2][C] as written through bd_gn_bwd_desc.param_partials */
+    int C;
+    float* dgamma; float* dbeta;            /* [C], written */
+} bd_gn_param_item;
+/* dgamma[c] / dbeta[c] = sum over the B samples of the partials, fixed order, for n layers in one launch
+ * (the reduction over the batch of aten::native_group_norm_backward's weight / bias gradients, resnet.py:559,591) */
+int bd_gn_bwd_params(const bd_gn_param_item* items, int n, int B, bd_stream_t stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Implicit-GEMM engine on f32 MFMA (v_mfma_f32_32x32x2_f32: exact fp32 products/accumulate).

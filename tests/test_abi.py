@@ -40,7 +40,7 @@ def test_struct_layouts_match_header_sizes():
     """ctypes mirrors vs sizeof() computed by the C compiler from the header."""
     from baddiffusion_amd import _lib as L
     names = {"bd_poison_qsample_desc": L.PoisonQsampleDesc, "bd_qsample_desc": L.QsampleDesc, "bd_ddpm_step_desc": L.DdpmStepDesc,
-             "bd_ddim_step_desc": L.DdimStepDesc, "bd_gn_fwd_desc": L.GnFwdDesc, "bd_gn_bwd_desc": L.GnBwdDesc,
+             "bd_ddim_step_desc": L.DdimStepDesc, "bd_gn_fwd_desc": L.GnFwdDesc, "bd_gn_bwd_desc": L.GnBwdDesc, "bd_gn_param_item": L.GnParamItem,
              "bd_operand": L.Operand, "bd_igemm_desc": L.IgemmDesc, "bd_conv3x3_fwd_desc": L.ConvFwdDesc,
              "bd_conv3x3_dgrad_desc": L.ConvDgradDesc, "bd_conv3x3_wgrad_desc": L.ConvWgradDesc, "bd_unet_config": L.UnetConfig,
              "bd_conv3x3_ps_desc": L.ConvPsDesc, "bd_conv3x3_ps_wgrad_desc": L.ConvPsWgradDesc, "bd_attn_fwd_desc": L.AttnFwdDesc}

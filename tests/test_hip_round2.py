@@ -505,3 +505,45 @@ def test_fused_attention_forward(gpu, B, N, Cc, heads):
     assert relerr(pm, P64) < 1e-4 and relerr(o, O64) < 1e-4
     assert relerr(lse, torch.logsumexp(S64, -1)) < 1e-5
     assert abs(float(pm.sum(-1).mean()) - 1.0) < 1e-5
+
+
+def test_gn_bwd_deferred_param_fold_equals_per_layer(gpu):
+    """bd_gn_bwd_desc.param_partials + one bd_gn_bwd_params launch for several layers == the per-layer parameter
+    reduction of bd_gn_bwd (same fixed summation order, so bit-identical); dx is untouched by the option."""
+    import ctypes as CT
+    from baddiffusion_amd import _lib as L, ops
+    lib = L.load()
+    torch.manual_seed(5)
+    B, G = 6, 32
+    layers = [(64, 64), (256, 128), (16, 256)]           # (HW, C): all take the single-pass kernel at this batch
+    items = (L.GnParamItem * len(layers))()
+    keep, want = [], []
+    for i, (HW, Cc) in enumerate(layers):
+        assert lib.bd_gn_bwd_defers(B, HW, Cc, G) == 1
+        x = torch.randn(B, HW, Cc, device=gpu); dy = torch.randn(B, HW, Cc, device=gpu)
+        ga = torch.randn(Cc, device=gpu); be = torch.randn(Cc, device=gpu)
+        st = torch.empty(2, B, G, device=gpu)
+        ws = ops.workspace(lib.bd_gn_workspace_bytes(B, Cc), x.device)
+        y = torch.empty_like(x)
+        f = L.GnFwdDesc(B=B, HW=HW, C=Cc, G=G, eps=1e-6, silu=1, x=L.ptr(x), ldx=Cc, gamma=L.ptr(ga), beta=L.ptr(be), y=L.ptr(y), ldy=Cc,
+                        mean=L.ptr(st[0]), rstd=L.ptr(st[1]), workspace=L.ptr(ws), workspace_bytes=ws.numel())
+        L.check(lib.bd_gn_fwd(CT.byref(f), L.stream()))
+        outs = []
+        for deferred in (False, True):
+            dx = torch.empty_like(x); dg = torch.full((Cc,), float("nan"), device=gpu); db = torch.full((Cc,), float("nan"), device=gpu)
+            part = torch.empty(B, 2, Cc, device=gpu)
+            d = L.GnBwdDesc(B=B, HW=HW, C=Cc, G=G, silu=1, x=L.ptr(x), ldx=Cc, gamma=L.ptr(ga), beta=L.ptr(be), mean=L.ptr(st[0]),
+                            rstd=L.ptr(st[1]), dy=L.ptr(dy), lddy=Cc, dx=L.ptr(dx), lddx=Cc, accumulate_dx=0, dgamma=L.ptr(dg),
+                            dbeta=L.ptr(db), workspace=L.ptr(ws), workspace_bytes=ws.numel(), param_partials=L.ptr(part) if deferred else None)
+            L.check(lib.bd_gn_bwd(CT.byref(d), L.stream()))
+            outs.append((dx, dg, db, part))
+        (dx0, dg0, db0, _), (dx1, dg1, db1, part1) = outs
+        assert torch.equal(dx0, dx1)
+        assert torch.isnan(dg1).all() and torch.isnan(db1).all()          # deferred: not written by the layer
+        items[i].partials = L.ptr(part1); items[i].C = Cc; items[i].dgamma = L.ptr(dg1); items[i].dbeta = L.ptr(db1)
+        keep.append((x, dy, ga, be, st, ws, part1, dx1)); want.append((dg0, db0, dg1, db1))
+    L.check(lib.bd_gn_bwd_params(items, len(layers), B, L.stream()))
+    torch.cuda.synchronize()
+    for dg0, db0, dg1, db1 in want:
+        assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
+    assert lib.bd_gn_bwd_defers(4, 65536, 128, 32) == 0                  # large images take the split path: no deferral
