@@ -52,7 +52,8 @@ class GnBwdDesc(C.Structure):
                 ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp), ("mean", vp), ("rstd", vp),
                 ("dy", vp), ("lddy", i64), ("dx", vp), ("lddx", i64), ("accumulate_dx", i32),
                 ("dgamma", vp), ("dbeta", vp), ("workspace", vp), ("workspace_bytes", sz),
-                ("dx_colsum", vp), ("ld_colsum", i64), ("dx_split", vp), ("lddxs", i64), ("param_partials", vp)]
+                ("dx_colsum", vp), ("ld_colsum", i64), ("dx_split", vp), ("lddxs", i64),
+                ("dx_add", vp), ("ld_add", i64), ("param_partials", vp)]
 
 
 class GnParamItem(C.Structure):

@@ -386,7 +386,8 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, long long ldx, 
                                     const float* __restrict__ ds, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, float inv_n, int silu, int acc,
-                                    unsigned short* __restrict__ dxs, long long lddxs) {
+                                    unsigned short* __restrict__ dxs, long long lddxs, const float* __restrict__ addp,
+                                    long long ldadd) {
     const int q = C / 4, cpg = C / G;
     const int t = threadIdx.x;
     const int cq = t % q, prow = t / q;
@@ -406,26 +407,28 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, long long ldx, 
     const float* db = dy + (long long)b * HW * lddy + cq * 4;
     float* ob = dx + (long long)b * HW * lddx + cq * 4;
     const bool do_acc = dx && acc;
-    for (int p = p0 + prow; p < p1; p += 2 * r) {   // two rows of up to three tensors in flight, branch-free
-        float4 v[2], d[2], e[2];
+    const float* ab = addp ? addp + (long long)b * HW * ldadd + cq * 4 : xb;
+    for (int p = p0 + prow; p < p1; p += 2 * r) {   // two rows of up to four tensors in flight, branch-free
+        float4 v[2], d[2], e[2], a2[2];
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const bool ok = p + u * r < p1;
             v[u] = gn_ld4_if(xb + (long long)(p + u * r) * ldx, ok);
             d[u] = gn_ld4_if(db + (long long)(p + u * r) * lddy, ok);
             e[u] = gn_ld4_if(ob + (long long)(p + u * r) * lddx, ok && do_acc);
+            a2[u] = gn_ld4_if(ab + (long long)(p + u * r) * ldadd, ok && addp != nullptr);
         }
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
             const float in[4] = {v[u].x, v[u].y, v[u].z, v[u].w}, dd[4] = {d[u].x, d[u].y, d[u].z, d[u].w};
-            const float ee[4] = {e[u].x, e[u].y, e[u].z, e[u].w};
+            const float ee[4] = {e[u].x, e[u].y, e[u].z, e[u].w}, aa[4] = {a2[u].x, a2[u].y, a2[u].z, a2[u].w};
             float o[4];
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float xh = (in[j] - mu[j]) * rs[j];
                 float dz = dd[j];
                 if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
-                o[j] = rs[j] * (dz * gg[j] - (g1[j] + xh * g2[j]) * inv_n) + ee[j];
+                o[j] = (rs[j] * (dz * gg[j] - (g1[j] + xh * g2[j]) * inv_n) + ee[j]) + aa[j];
             }
             v[u] = make_float4(o[0], o[1], o[2], o[3]);
         }
@@ -631,7 +634,8 @@ __global__ __launch_bounds__(NT) void gn_bwd_res_kernel(const float* __restrict_
                                                        const float* __restrict__ mean, const float* __restrict__ rstd,
                                                        int silu, int acc, float* __restrict__ part,
                                                        float* __restrict__ dx_colsum, long long ld_colsum,
-                                                       unsigned short* __restrict__ dxs, long long lddxs) {
+                                                       unsigned short* __restrict__ dxs, long long lddxs,
+                                                       const float* __restrict__ addp, long long ldadd) {
     __shared__ float sh[3 * 4 * NT];   // [R][cb][3]: sum dz, sum dz*xhat, sum xhat
     __shared__ float ch[3 * 4 * NT];   // [cb][3] channel totals (cb <= 4*NT)
     __shared__ float sg[2 * 256];    // per group: s1, s2
@@ -767,6 +771,16 @@ __global__ __launch_bounds__(NT) void gn_bwd_res_kernel(const float* __restrict_
 #pragma unroll
         for (int i = 0; i < EMAX; ++i) { dz[i].x += xh[i].x; dz[i].y += xh[i].y; dz[i].z += xh[i].z; dz[i].w += xh[i].w; }
     }
+    if (addp) {                           // + a second gradient (the resnet's identity shortcut), after the accumulation
+        const float* ab = addp + (long long)b * HW * ldadd + c0 + cq * 4;
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) {
+            const int p = prow + R * i;
+            xh[i] = gn_ld4_if(ab + (long long)p * ldadd, i < E && p < HW);
+        }
+#pragma unroll
+        for (int i = 0; i < EMAX; ++i) { dz[i].x += xh[i].x; dz[i].y += xh[i].y; dz[i].z += xh[i].z; dz[i].w += xh[i].w; }
+    }
 #pragma unroll
     for (int i = 0; i < EMAX; ++i) {
         const int p = prow + R * i;
@@ -880,7 +894,8 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
     BD_CHECK(d->dx || !d->accumulate_dx, BD_ERR_INVALID, "bd_gn_bwd: accumulate_dx needs dx");
     BD_CHECK((d->lddy & 3) == 0 && (d->lddx & 3) == 0 && aligned16(d->dy) && aligned16(d->dx) && aligned16(d->gamma) &&
                  aligned16(d->beta), BD_ERR_UNSUPPORTED, "bd_gn_bwd: pointers must be 16B aligned, ld multiples of 4");
-    BD_CHECK(!(d->dx_colsum && d->accumulate_dx), BD_ERR_INVALID, "bd_gn_bwd: dx_colsum is the column sum of the written dx");
+    BD_CHECK(!(d->dx_colsum && (d->accumulate_dx || d->dx_add)), BD_ERR_INVALID, "bd_gn_bwd: dx_colsum is the column sum of this launch's dx term alone");
+    BD_CHECK(!d->dx_add || (d->dx && (d->ld_add & 3) == 0 && aligned16(d->dx_add)), BD_ERR_INVALID, "bd_gn_bwd: dx_add needs dx, a 16B-aligned pointer and ld_add %% 4 == 0");
     GnRes rp;
     if (gn_resident_plan(d->B, d->HW, d->C, d->G, rp, true)) {
         const size_t need_r = d->param_partials ? 0 : (size_t)d->B * d->C * 2 * sizeof(float);
@@ -891,7 +906,7 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
     hipLaunchKernelGGL((gn_bwd_res_kernel<EM, NT>), grid, dim3(NT), 0, S(stream), d->x, (long long)d->ldx, d->dy,            \
                        (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->gamma,     \
                        d->beta, d->mean, d->rstd, d->silu, d->accumulate_dx, part_r, d->dx_colsum, (long long)d->ld_colsum, \
-                       d->dx_split, (long long)d->lddxs)
+                       d->dx_split, (long long)d->lddxs, d->dx_add, (long long)d->ld_add)
         if (rp.nt == 512 && rp.E <= 8) BD_GN_BWD_RES(8, 512);
         else if (rp.nt == 512) BD_GN_BWD_RES(GN_RES_EMAX, 512);
         else if (rp.E <= 4) BD_GN_BWD_RES(4, 256);
@@ -927,7 +942,7 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)cdiv(d->HW, per), d->B), dim3(threads), 0, S(stream), d->x,
                            (long long)d->ldx, d->dy, (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, r, per, ds,
                            d->gamma, d->beta, d->mean, d->rstd, inv_n, d->silu, d->accumulate_dx, d->dx_split,
-                           (long long)d->lddxs);
+                           (long long)d->lddxs, d->dx_add, (long long)d->ld_add);
     }
     BD_LAUNCH_CHECK("gn_bwd_apply");
     return BD_OK;

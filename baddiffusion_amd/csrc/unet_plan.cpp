@@ -282,8 +282,10 @@ struct bd_unet {
         }
         return bd_gn_fwd(&d, (bd_stream_t)c.st);
     }
-    int gn_bwd(Ctx& c, const View& x, int64_t pg, int64_t pb, int stats_buf, const float* dy, int64_t lddy, int silu) {
+    int gn_bwd(Ctx& c, const View& x, int64_t pg, int64_t pb, int stats_buf, const float* dy, int64_t lddy, int silu,
+               const float* dx_add = nullptr, int64_t ld_add = 0) {
         bd_gn_bwd_desc d = {};
+        d.dx_add = dx_add; d.ld_add = ld_add;
         d.B = c.B; d.HW = x.H * x.W; d.C = x.C; d.G = cfg.norm_num_groups; d.silu = silu;
         d.x = VP(c, x); d.ldx = x.ld; d.gamma = c.params + pg; d.beta = c.params + pb;
         d.mean = MEANP(c, stats_buf, d.G); d.rstd = RSTDP(c, stats_buf, d.G);
@@ -597,13 +599,11 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             g1.dy = BP(c, b_dh1); g1.lddy = Cout; g1.w = c.params + pc1w; g1.dx = BP(c, b_da1); g1.lddx = Cin;
             BD_TRY(conv_d(c, g1));
         }
-        BD_TRY(gn_bwd(c, x, pn1w, pn1b, b_st1, BP(c, b_da1), Cin, 1));
-        // residual path
-        if (shortcut) {
+        // norm1 backward; the identity shortcut's gradient (dy itself) is added in the same store
+        BD_TRY(gn_bwd(c, x, pn1w, pn1b, b_st1, BP(c, b_da1), Cin, 1, shortcut ? nullptr : dy, lddy));
+        if (shortcut) {   // 1x1 shortcut convolution
             BD_TRY(linear_wgrad(c, dy, lddy, VP(c, x), x.ld, c.grads + psw, M, Cout, Cin, c.grads + psb));
             BD_TRY(linear_dgrad(c, dy, lddy, c.params + psw, GP(c, x), x.ld, M, Cout, Cin, 1));
-        } else {
-            BD_TRY(add(c, dy, lddy, GP(c, x), x.ld, M, Cout, 1.f, 1));
         }
         return (int)BD_OK;
     });

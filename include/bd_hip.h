@@ -154,6 +154,8 @@ typedef struct {
                                                the time-embedding gradient of resnet.py:571            */
     uint16_t* dx_split; int64_t lddxs;      /* optional: this launch's dx term also / only (dx == NULL) as split
                                                planes (not accumulated)                                            */
+    const float* dx_add; int64_t ld_add;    /* optional: dx = (term (+ dx)) + dx_add, a second gradient of the same tensor
+                                               folded into the store (the identity shortcut of resnet.py:596-600)     */
     float* param_partials;                  /* optional [B][2][C], caller storage: if set and bd_gn_bwd_defers(B, HW, C, G),
                                                the per-sample partial sums of (dgamma, dbeta) are left here and dgamma /
                                                dbeta are NOT written -- fold many layers later with ONE bd_gn_bwd_params

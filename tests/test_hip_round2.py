@@ -547,3 +547,35 @@ def test_gn_bwd_deferred_param_fold_equals_per_layer(gpu):
     for dg0, db0, dg1, db1 in want:
         assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
     assert lib.bd_gn_bwd_defers(4, 65536, 128, 32) == 0                  # large images take the split path: no deferral
+
+
+def test_gn_bwd_dx_add_equals_separate_add(gpu):
+    """bd_gn_bwd_desc.dx_add: dx = (term + existing dx) + dx_add in one store == the same launch followed by an add
+    (bit-identical: same order of additions), on the single-pass and on the split (large image) kernels."""
+    import ctypes as CT
+    from baddiffusion_amd import _lib as L, ops
+    lib = L.load()
+    torch.manual_seed(9)
+    for (B, HW, Cc) in [(6, 256, 128), (3, 1024, 96), (2, 16384, 64)]:
+        G = 32
+        x = torch.randn(B, HW, Cc, device=gpu); dy = torch.randn(B, HW, Cc, device=gpu); extra = torch.randn(B, HW, Cc + 32, device=gpu)
+        ga = torch.randn(Cc, device=gpu); be = torch.randn(Cc, device=gpu); st = torch.empty(2, B, G, device=gpu)
+        ws = ops.workspace(lib.bd_gn_workspace_bytes(B, Cc), x.device)
+        y = torch.empty_like(x)
+        f = L.GnFwdDesc(B=B, HW=HW, C=Cc, G=G, eps=1e-6, silu=1, x=L.ptr(x), ldx=Cc, gamma=L.ptr(ga), beta=L.ptr(be), y=L.ptr(y), ldy=Cc,
+                        mean=L.ptr(st[0]), rstd=L.ptr(st[1]), workspace=L.ptr(ws), workspace_bytes=ws.numel())
+        L.check(lib.bd_gn_fwd(CT.byref(f), L.stream()))
+        prev = torch.randn(B, HW, Cc, device=gpu)
+        res = []
+        for fused in (False, True):
+            dx = prev.clone(); dg = torch.empty(Cc, device=gpu); db = torch.empty(Cc, device=gpu)
+            d = L.GnBwdDesc(B=B, HW=HW, C=Cc, G=G, silu=1, x=L.ptr(x), ldx=Cc, gamma=L.ptr(ga), beta=L.ptr(be), mean=L.ptr(st[0]),
+                            rstd=L.ptr(st[1]), dy=L.ptr(dy), lddy=Cc, dx=L.ptr(dx), lddx=Cc, accumulate_dx=1, dgamma=L.ptr(dg),
+                            dbeta=L.ptr(db), workspace=L.ptr(ws), workspace_bytes=ws.numel(),
+                            dx_add=L.ptr(extra) if fused else None, ld_add=Cc + 32)
+            L.check(lib.bd_gn_bwd(CT.byref(d), L.stream()))
+            if not fused:
+                dx = dx + extra[:, :, :Cc]
+            res.append((dx, dg, db))
+        assert torch.equal(res[0][0], res[1][0]), (B, HW, Cc)
+        assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
