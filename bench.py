@@ -391,6 +391,7 @@ def main():
                                    # scripts/probe/mfma_probe.hip: register-operand v_mfma_f32_32x32x16_bf16 only, random bf16
                                    # data -> 1850 TFLOP/s at the 1400 W board limit (2470 with constant operands); DESIGN.md s.3
                                    "mfma_power_limited_peak_measured": None if args.mode == "f32" else 1850.0,
+                                   "frac_of_power_limited_peak": None if args.mode == "f32" else ach / (1850.0 / 3),
                                    "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                                    "launches_per_step": d["launches"] / prof_steps, "sampled_steps": prof_steps,
                                    "avg_launch_us": d["ms"] * 1e3 / d["launches"],
@@ -402,6 +403,7 @@ def main():
                 if iso:   # the same kernel class with the side stream off (stand-alone launch durations, untimed steps)
                     ai = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
                     out["roofline"]["standalone"] = {"achieved": ai, "frac": ai / peak, "avg_launch_us": iso["ms"] * 1e3 / iso["launches"],
+                                                     "frac_of_power_limited_peak": None if args.mode == "f32" else ai / (1850.0 / 3),
                                                      "note": "2 extra untimed steps with bd_unet_set_aux_stream(0): no overlap with other kernels"}
                 out["kernel_classes_standalone"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in classes_iso]
                 out["kernel_classes"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in classes]
