@@ -140,6 +140,8 @@ SIGNATURES = {
     "bd_gn_workspace_bytes": (sz, [i32, i32]),
     "bd_gn_fwd": (i32, [C.POINTER(GnFwdDesc), vp]),
     "bd_gn_bwd": (i32, [C.POINTER(GnBwdDesc), vp]),
+    "bd_ssim_workspace_bytes": (sz, [i32, i32, i32, i32]),
+    "bd_ssim": (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp, vp, sz, vp]),
     "bd_gn_bwd_defers": (i32, [i32, i32, i32, i32]),
     "bd_gn_bwd_params": (i32, [C.POINTER(GnParamItem), i32, i32, vp]),
     "bd_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),

@@ -22,6 +22,7 @@ SOURCES = [  # (file, extra flags)
     ("igemm.hip", []),
     ("conv_ps.hip", []),
     ("attn.hip", []),
+    ("metrics.hip", ["-ffp-contract=off"]),
     ("conv.cpp", ["-x", "hip"]),
     ("conv_thin.hip", []),
     ("unet_plan.cpp", ["-x", "hip"]),

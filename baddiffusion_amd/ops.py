@@ -457,6 +457,34 @@ def loss_fwd_bwd(pred, target, loss_type="l2", grad_scale=1.0, want_grad=True):
     return loss, dp
 
 
+def ssim(preds, target, data_range=1.0):
+    """Mean SSIM (torchmetrics defaults, see bd_hip.h) of two [N,C,H,W] float32 GPU tensors with identical strides (any
+    layout: a permuted NHWC buffer is fine).  Returns a 0-dim device tensor; batches with N*C > 65535 are chunked."""
+    lib = L.load(); _need_cuda(preds, target)
+    if preds.shape != target.shape or preds.dim() != 4:
+        raise ValueError(f"expected two [N,C,H,W] tensors of the same shape, got {tuple(preds.shape)} and {tuple(target.shape)}")
+    if preds.dtype != torch.float32 or target.dtype != torch.float32:
+        raise TypeError("ssim: float32 tensors required")
+    if preds.stride() != target.stride():
+        target = target.contiguous(); preds = preds.contiguous()
+    N, Cc, H, W = preds.shape
+    per = max(1, 65535 // Cc)
+    total = torch.zeros((), dtype=torch.float64, device=preds.device)
+    for s0 in range(0, N, per):
+        pc, tc = preds[s0:s0 + per], target[s0:s0 + per]
+        n = pc.shape[0]
+        nbytes = lib.bd_ssim_workspace_bytes(n, Cc, H, W)
+        ws = workspace(nbytes, preds.device, "ssim")
+        out = torch.empty((), device=preds.device)
+        sn, sc, sh, sw = pc.stride()
+        L.check(lib.bd_ssim(L.ptr(pc), L.ptr(tc), n, Cc, H, W, sn, sc, sh, sw, float(data_range), L.ptr(out), L.ptr(ws), nbytes, L.stream()),
+                "bd_ssim")
+        if n == N:
+            return out
+        total += out.double() * n
+    return (total / N).float()
+
+
 def sumsq(g, out=None):
     lib = L.load(); _need_cuda(g)
     if out is None:

@@ -359,6 +359,15 @@ int bd_loss_fwd_bwd(const float* pred, int64_t ldp, const float* target, int64_t
                     int loss_type, float grad_scale, float* loss, float* dpred, int64_t lddp,
                     void* workspace, bd_stream_t stream);
 
+/* f-3: mean structural similarity of two [N,C,H,W] image batches in [0, data_range] given by element strides (NCHW or
+ * NHWC storage alike): StructuralSimilarityIndexMeasure(data_range=1.0) of baddiffusion.py:536-547 with the torchmetrics
+ * defaults (11x11 Gaussian, sigma 1.5, k1 0.01, k2 0.03, reflect padding, cropped border, mean over C,H,W then batch).
+ * out: device float scalar, written.  workspace >= bd_ssim_workspace_bytes(N, C, H, W).  Needs H, W > 10, N*C <= 65535. */
+size_t bd_ssim_workspace_bytes(int N, int C, int H, int W);
+int bd_ssim(const float* preds, const float* target, int N, int C, int H, int W, int64_t stride_n, int64_t stride_c,
+            int64_t stride_h, int64_t stride_w, float data_range, float* out, void* workspace, size_t workspace_bytes,
+            bd_stream_t stream);
+
 /* a-8: global-norm clip + Adam over one flat fp32 buffer (baddiffusion.py:320, 611-615).
  * bd_sumsq: sumsq (device double scalar) = sum g^2.  bd_adam_clip reads it:
  *   coef = min(1, max_norm / (sqrt(sumsq) + 1e-6));  g *= coef;  Adam(b1,b2,eps), bias correction from

@@ -579,3 +579,24 @@ def test_gn_bwd_dx_add_equals_separate_add(gpu):
             res.append((dx, dg, db))
         assert torch.equal(res[0][0], res[1][0]), (B, HW, Cc)
         assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
+
+
+def test_ssim_kernel_matches_cpu_restatement(gpu):
+    """bd_ssim (HIP) vs baddiffusion_amd.metrics.ssim on CPU (the torchmetrics-defaults restatement): CIFAR-size batches,
+    a ragged non-square size (tiles of 32 with remainders), NHWC-strided views, identical images (== 1) and a measure-style
+    comparison against a constant target."""
+    from baddiffusion_amd import metrics, ops
+    torch.manual_seed(11)
+    for shape in [(8, 3, 32, 32), (2, 3, 75, 44), (3, 1, 12, 64)]:
+        a = torch.rand(shape); b = (a + 0.2 * torch.randn(shape)).clamp(0, 1)
+        want = metrics.ssim(a, b)
+        got = metrics.ssim(a.to(gpu), b.to(gpu))                       # dispatches to the HIP kernel
+        assert abs(got - want) < 2e-5, (shape, got, want)
+        # NHWC storage viewed as NCHW (what the pipelines hand over)
+        an = a.permute(0, 2, 3, 1).contiguous().to(gpu).permute(0, 3, 1, 2); bn = b.permute(0, 2, 3, 1).contiguous().to(gpu).permute(0, 3, 1, 2)
+        got2 = float(ops.ssim(an, bn))
+        assert abs(got2 - want) < 2e-5, (shape, got2, want)
+    a = torch.rand(4, 3, 32, 32, device=gpu)
+    assert abs(metrics.ssim(a, a.clone()) - 1.0) < 1e-6
+    tgt = torch.rand(1, 3, 32, 32).expand(4, 3, 32, 32).contiguous()
+    assert abs(metrics.ssim(a, tgt.to(gpu)) - metrics.ssim(a.cpu(), tgt)) < 2e-5
