@@ -600,3 +600,32 @@ def test_ssim_kernel_matches_cpu_restatement(gpu):
     assert abs(metrics.ssim(a, a.clone()) - 1.0) < 1e-6
     tgt = torch.rand(1, 3, 32, 32).expand(4, 3, 32, 32).contiguous()
     assert abs(metrics.ssim(a, tgt.to(gpu)) - metrics.ssim(a.cpu(), tgt)) < 2e-5
+
+
+def test_full_batch_train_steps_bitwise_reproducible(gpu):
+    """Run-to-run determinism of the product step at BASELINE configs[1] size (B = 128, two-stream schedule, K-split slabs
+    folded in fixed order, no atomics anywhere): two independent engines fed the same three batches end with bit-identical
+    weights, Adam moments, losses and gradient norms."""
+    from baddiffusion_amd.dataset import Backdoor
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    cfg = U.CIFAR10_32
+    B, S = 128, 32
+    bd = Backdoor(root=None)
+    trig = bd.get_trigger("BOX_14", 3, S).cuda(); tgt = bd.get_target("CORNER", trig.cpu()).cuda()
+    pois = (torch.arange(B) % 10 == 0).cuda()
+    batches = [(_u8_batch(B, S, 40 + i).cuda(), torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(50 + i)).cuda(),
+                torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(60 + i)).cuda()) for i in range(3)]
+    runs = []
+    for _ in range(2):
+        m = make_model(cfg, 0, gpu)
+        e = TrainEngine(m, DDPMScheduler(), lr=2e-4)
+        hist = []
+        for u8, eps, t in batches:
+            loss = e.train_step(u8, pois, trig, tgt, eps, t)
+            hist.append((loss.clone(), e.grad_norm.clone()))
+        torch.cuda.synchronize()
+        runs.append((m.flat.detach().clone(), e.m.clone(), e.v.clone(), hist))
+    (w0, m0, v0, h0), (w1, m1, v1, h1) = runs
+    assert torch.equal(w0, w1) and torch.equal(m0, m1) and torch.equal(v0, v1)
+    assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(h0, h1))
