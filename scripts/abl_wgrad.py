@@ -1,4 +1,5 @@
-"""timing only (ablation builds give wrong numbers by design): split-plane wgrad at the step's main shapes"""
+"""Ablation timings: needs a library built with -DBD_PS_ABLATION on conv_ps.hip, BD_PS_ABLATE=<bits> selects what is
+removed (1 steady-state DMA, 2 MFMAs, 4 LDS fragment reads).  Timing only, results are wrong by design: split-plane wgrad at the step's main shapes"""
 import torch
 from baddiffusion_amd import ops
 dev = "cuda"

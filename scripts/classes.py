@@ -1,3 +1,5 @@
+"""bench.py JSON line on stdin -> one row per kernel class (with BD_PROF_SHAPES=1: one per GEMM shape).
+usage: BD_PROF_SHAPES=1 python bench.py ... | python scripts/classes.py [kernel_classes|kernel_classes_standalone]"""
 import sys,json
 d=json.loads(sys.stdin.read().strip().splitlines()[-1])
 print(d['ms_per_step'])
