@@ -289,3 +289,24 @@ def test_ssim_properties():
     s = metrics.ssim(torch.full((1, 3, 32, 32), u), torch.full((1, 3, 32, 32), v))
     assert abs(s - (2 * u * v + 1e-4) / (u * u + v * v + 1e-4)) < 5e-4     # E[x^2] - mu^2 cancels in fp32 against c2 = 9e-4
     assert abs(metrics.mse(a, b) - float(((a - b) ** 2).mean())) < 1e-9
+
+
+def test_ssim_against_independent_scipy_formulation():
+    """The SSIM restatement (torch, banded matrix products) against an independent evaluation of the published formula
+    with scipy.ndimage: Gaussian window sigma 1.5 truncated to 11 taps (truncate 3.5), mirror boundary (= F.pad "reflect"),
+    local moments -> SSIM map, the 5-pixel border cropped, mean.  Two code paths, two libraries, same number."""
+    from scipy import ndimage
+    from baddiffusion_amd import metrics
+    rng = np.random.default_rng(3)
+    for shape in [(4, 3, 32, 32), (2, 1, 40, 27)]:
+        a = rng.random(shape).astype(np.float32)
+        b = np.clip(a + 0.15 * rng.standard_normal(shape).astype(np.float32), 0, 1)
+        def blur(x):
+            return ndimage.gaussian_filter(x.astype(np.float64), sigma=(0, 0, 1.5, 1.5), truncate=3.5, mode="mirror")
+        mp, mt = blur(a), blur(b)
+        vp, vt, cv = blur(a * a) - mp * mp, blur(b * b) - mt * mt, blur(a * b) - mp * mt
+        c1, c2 = 0.01 ** 2, 0.03 ** 2
+        m = ((2 * mp * mt + c1) * (2 * cv + c2)) / ((mp * mp + mt * mt + c1) * (vp + vt + c2))
+        want = float(m[..., 5:-5, 5:-5].mean())
+        got = metrics.ssim(torch.from_numpy(a), torch.from_numpy(b))
+        assert abs(got - want) < 2e-5, (shape, got, want)
