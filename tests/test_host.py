@@ -217,3 +217,29 @@ def test_reference_checkpoint_layout(tmp_path):
     assert sorted(({"key": k, "shape": list(v.shape), "dtype": str(v.dtype), "contiguous": bool(v.is_contiguous())} for k, v in sd2.items()),
                   key=key) == sorted(man["state_dict"], key=key)
     assert all(torch.equal(sd2[k], P[k]) for k in P)
+
+
+@pytest.mark.skipif(not os.path.exists("/root/reference/static/fedora-hat.png"),
+                    reason="the reference's static/ image assets are not redistributed (build container only)")
+def test_image_file_triggers_match_reference_fixture():
+    """GLASSES / STOP_SIGN triggers and HAT / CAT targets (dataset.py:428-497, 576-597, 643-655): the product's
+    Backdoor, reading the reference's assets in place, against tests/golden/img_triggers.npz -- outputs of the reference's
+    own Backdoor class (generator: tests/golden/make_trigger_fixture.py; its header states what the torchvision stand-in
+    does and does not pin).  BASELINE configs[1]'s HAT target and configs[3]'s GLASSES -> CAT pair are among them."""
+    from baddiffusion_amd.dataset import Backdoor
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "img_triggers.npz"))
+    bd = Backdoor(root="/root/reference")
+    n = 0
+    for key in g.files:
+        kind, name = key.split("_", 1)
+        name, c, s = name.rsplit("_", 2)
+        ch, size = int(c[1:]), int(s[1:])
+        if kind == "trigger":
+            got = bd.get_trigger(name, ch, size)
+        else:
+            got = bd.get_target(name, bd.get_trigger("BOX_14", ch, size))
+        want = torch.from_numpy(g[key])
+        assert got.shape == want.shape and got.dtype == want.dtype, key
+        assert torch.equal(got, want), (key, float((got - want).abs().max()))
+        n += 1
+    assert n == 8
