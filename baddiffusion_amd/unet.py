@@ -11,6 +11,8 @@ is `bd_unet_backward`.  There is no PyTorch implementation of the network here: 
 library or without a GPU tensor, forward raises.
 """
 import os
+
+import numpy as np
 import ctypes as C
 import math
 from collections import OrderedDict
@@ -156,6 +158,15 @@ class UNet2DModel(nn.Module):
             L.check(lib.bd_unet_param_info(h, i, C.byref(name), C.byref(off), C.byref(rank), shp, C.byref(lay)))
             self._table[name.value.decode()] = (off.value, tuple(shp[: rank.value]), lay.value)
         self.num_flat = lib.bd_unet_num_params(h)
+        # alignment pads between / behind the tensors: the only elements of a gradient buffer that backward does not write
+        ivals = sorted((off, off + int(np.prod(shp))) for off, shp, _ in self._table.values())
+        self._pads, end = [], 0
+        for lo, hi in ivals:
+            if lo > end:
+                self._pads.append((end, lo))
+            end = max(end, hi)
+        if end < self.num_flat:
+            self._pads.append((end, self.num_flat))
         if os.environ.get("BD_AUX_STREAM", "1") == "0":
             lib.bd_unet_set_aux_stream(h, 0)
         self.flat = nn.Parameter(torch.zeros(self.num_flat))
@@ -300,8 +311,10 @@ class UNet2DModel(nn.Module):
 
     def _run_backward(self, flat, x_nhwc, dout, ws, grads=None):
         B = x_nhwc.shape[0]
-        if grads is None:
-            grads = torch.zeros(self.num_flat, device=flat.device)
+        if grads is None:   # backward writes every parameter's gradient exactly once: only the alignment pads need zeros
+            grads = torch.empty(self.num_flat, device=flat.device)
+            for lo, hi in self._pads:
+                grads[lo:hi].zero_()
         L.check(self._lib.bd_unet_backward(self._plan, B, flat.data_ptr(), x_nhwc.data_ptr(), x_nhwc.shape[-1],
                                            dout.data_ptr(), dout.shape[-1], grads.data_ptr(), ws.data_ptr(), ws.numel(),
                                            L.stream()), "bd_unet_backward")
