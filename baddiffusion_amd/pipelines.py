@@ -101,9 +101,11 @@ class DDPMPipeline(_PipelineBase):
         image, shape = self._start(batch_size, generator, init)
         self.scheduler.set_timesteps(num_inference_steps)
         mov = [self._to_numpy(image, shape)] if save_every_step else []
-        for t in self.progress_bar(self.scheduler.timesteps[start_from:]):
+        ts_host = self.scheduler.timesteps[start_from:]
+        ts_dev = torch.as_tensor(ts_host, dtype=torch.int64).to(self.device)    # one H2D copy for the whole chain
+        for i, t in enumerate(self.progress_bar(ts_host)):
             t = int(t)
-            eps = self.unet(image.permute(0, 3, 1, 2), t).sample.permute(0, 2, 3, 1)        # NHWC storage
+            eps = self.unet(image.permute(0, 3, 1, 2), ts_dev[i]).sample.permute(0, 2, 3, 1)        # NHWC storage
             noise = None
             if t > 0:   # same draw order / shape as randn_tensor(model_output.shape) in the reference
                 noise = randn_tensor(shape, generator=generator, device=self.device)
@@ -141,9 +143,10 @@ class DDIMPipeline(_PipelineBase):
         image, shape = self._start(batch_size, generator, init)
         self.scheduler.set_timesteps(num_inference_steps)
         mov = [self._to_numpy(image, shape)] if save_every_step else []
-        for t in self.progress_bar(self.scheduler.timesteps):
+        ts_dev = torch.as_tensor(self.scheduler.timesteps, dtype=torch.int64).to(self.device)   # one H2D copy for the whole chain
+        for i, t in enumerate(self.progress_bar(self.scheduler.timesteps)):
             t = int(t)
-            eps = self.unet(image.permute(0, 3, 1, 2), t).sample
+            eps = self.unet(image.permute(0, 3, 1, 2), ts_dev[i]).sample
             image = self.scheduler.step(eps, t, image.permute(0, 3, 1, 2), eta=eta,
                                         use_clipped_model_output=bool(use_clipped_model_output),
                                         generator=generator).prev_sample.permute(0, 2, 3, 1)
