@@ -140,6 +140,7 @@ SIGNATURES = {
     "bd_gn_workspace_bytes": (sz, [i32, i32]),
     "bd_gn_fwd": (i32, [C.POINTER(GnFwdDesc), vp]),
     "bd_gn_bwd": (i32, [C.POINTER(GnBwdDesc), vp]),
+    "bd_lincomb": (i32, [i32, C.POINTER(vp), C.POINTER(f32), i64, i32, f32, vp, vp]),
     "bd_ssim_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "bd_ssim": (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp, vp, sz, vp]),
     "bd_gn_bwd_defers": (i32, [i32, i32, i32, i32]),

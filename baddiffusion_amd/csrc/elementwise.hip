@@ -396,6 +396,37 @@ __global__ __launch_bounds__(TPB) void adam_clip_kernel(float* p, const float* g
     }
 }
 
+
+// f-4 (PNDM family): out = clamp(sum_j c[j] * term[j]) over up to BD_LINCOMB_MAX dense fp32 tensors of one layout.
+// Every PRK / PLMS update of scheduling_pndm.py:236-397 is such a combination of the running sample, the stored model
+// outputs and the running accumulator, with host-computed scalar coefficients; the pipeline's post-step clip
+// (pipeline_pndm.py:108-109) rides along.
+struct LincombArgs { const float* t[BD_LINCOMB_MAX]; float c[BD_LINCOMB_MAX]; int k; int clip; float range; };
+__global__ __launch_bounds__(TPB) void lincomb_kernel(LincombArgs a, float* __restrict__ out, int64_t n4, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * TPB + threadIdx.x; i < n4; i += (int64_t)gridDim.x * TPB) {
+        float4 v[BD_LINCOMB_MAX];
+#pragma unroll
+        for (int j = 0; j < BD_LINCOMB_MAX; ++j)
+            v[j] = j < a.k ? reinterpret_cast<const float4*>(a.t[j])[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        float4 r = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int j = 0; j < BD_LINCOMB_MAX; ++j)
+            if (j < a.k) { r.x += a.c[j] * v[j].x; r.y += a.c[j] * v[j].y; r.z += a.c[j] * v[j].z; r.w += a.c[j] * v[j].w; }
+        if (a.clip) {
+            r.x = fminf(fmaxf(r.x, -a.range), a.range); r.y = fminf(fmaxf(r.y, -a.range), a.range);
+            r.z = fminf(fmaxf(r.z, -a.range), a.range); r.w = fminf(fmaxf(r.w, -a.range), a.range);
+        }
+        reinterpret_cast<float4*>(out)[i] = r;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {   // tail (n % 4 elements)
+        const int64_t i = (n & ~(int64_t)3) + threadIdx.x;
+        float r = 0.f;
+        for (int j = 0; j < a.k; ++j) r += a.c[j] * a.t[j][i];
+        if (a.clip) r = fminf(fmaxf(r, -a.range), a.range);
+        out[i] = r;
+    }
+}
+
 }  // namespace bd
 
 using namespace bd;
@@ -449,6 +480,20 @@ extern "C" int bd_ddpm_step(const bd_ddpm_step_desc* d, bd_stream_t stream) {
              "bd_ddpm_step: variance_type must be fixed_small(0) or fixed_large(1)");
     hipLaunchKernelGGL(ddpm_step_kernel, dim3(nblocks(d->n, TPB, 4096)), dim3(TPB), 0, S(stream), *d);
     BD_LAUNCH_CHECK("ddpm_step");
+    return BD_OK;
+}
+extern "C" int bd_lincomb(int k, const float* const* terms, const float* coeffs, int64_t n, int clip, float clip_range, float* out,
+                          bd_stream_t stream) {
+    BD_CHECK(k >= 1 && k <= BD_LINCOMB_MAX && terms && coeffs && out && n > 0, BD_ERR_INVALID, "bd_lincomb: bad args (k=%d)", k);
+    LincombArgs a = {};
+    a.k = k; a.clip = clip; a.range = clip_range;
+    for (int j = 0; j < k; ++j) {
+        BD_CHECK(terms[j] && aligned16(terms[j]), BD_ERR_INVALID, "bd_lincomb: term %d is null or not 16-byte aligned", j);
+        a.t[j] = terms[j]; a.c[j] = coeffs[j];
+    }
+    BD_CHECK(aligned16(out), BD_ERR_INVALID, "bd_lincomb: out must be 16-byte aligned");
+    hipLaunchKernelGGL(lincomb_kernel, dim3(nblocks(cdiv(n, 4), TPB, 4096)), dim3(TPB), 0, S(stream), a, out, n / 4, n);
+    BD_LAUNCH_CHECK("lincomb");
     return BD_OK;
 }
 extern "C" int bd_ddim_step(const bd_ddim_step_desc* d, bd_stream_t stream) {

@@ -9,13 +9,14 @@ weights are not available the documented topology is built with default init and
 """
 import json
 import os
+from functools import partial
 from typing import Union
 
 import numpy as np
 import torch
 
-from .pipelines import DDIMPipeline, DDPMPipeline
-from .schedulers import DDIMScheduler, DDPMScheduler
+from .pipelines import DDIMPipeline, DDPMPipeline, PNDMPipeline
+from .schedulers import DDIMScheduler, DDPMScheduler, PNDMScheduler, SchedulerConfigCarrier
 from .unet import UNet2DModel
 
 WEIGHTS_NAME = "diffusion_pytorch_model.bin"
@@ -210,9 +211,15 @@ class DiffuserModelSched:
     LDM_CELEBA_HQ_256 = "LDM-CELEBA-HQ-256"
     DDPM_SCHED = "DDPM-SCHED"
     DDIM_SCHED = "DDIM-SCHED"
-    _OTHER_SCHEDS = ("DPM_SOLVER_PP_O1-SCHED", "DPM_SOLVER_O1-SCHED", "DPM_SOLVER_PP_O2-SCHED", "DPM_SOLVER_O2-SCHED",
-                     "DPM_SOLVER_PP_O3-SCHED", "DPM_SOLVER_O3-SCHED", "UNIPC-SCHED", "PNDM-SCHED", "DEIS-SCHED", "HEUN-SCHED",
-                     "LMSD-SCHED", "LDM-SCHED", "SCORE-SDE-VE-SCHED", "EDM-VE-SCHED", "EDM-VE-ODE-SCHED", "EDM-VE-SDE-SCHED")
+    # model.py:598-630: these build their own scheduler object but sample through PNDMPipeline, which converts it to a
+    # PNDMScheduler (pipeline_pndm.py:46) -- value = the reference class the returned config stands for
+    _PNDM_SCHEDS = {"DPM_SOLVER_PP_O1-SCHED": "DPMSolverMultistepScheduler", "DPM_SOLVER_O1-SCHED": "DPMSolverMultistepScheduler",
+                    "DPM_SOLVER_PP_O2-SCHED": "DPMSolverMultistepScheduler", "DPM_SOLVER_O2-SCHED": "DPMSolverMultistepScheduler",
+                    "DPM_SOLVER_PP_O3-SCHED": "DPMSolverMultistepScheduler", "DPM_SOLVER_O3-SCHED": "DPMSolverMultistepScheduler",
+                    "UNIPC-SCHED": "UniPCMultistepScheduler", "PNDM-SCHED": "PNDMScheduler", "DEIS-SCHED": "DEISMultistepScheduler",
+                    "HEUN-SCHED": "HeunDiscreteScheduler", "LMSD-SCHED": "LMSDiscreteScheduler"}
+    # named in model.py:556-563 but not handled by its __get_model_sched either (it raises NotImplementedError)
+    _OTHER_SCHEDS = ("LDM-SCHED", "SCORE-SDE-VE-SCHED", "EDM-VE-SCHED", "EDM-VE-ODE-SCHED", "EDM-VE-SDE-SCHED")
     _HUB = {DDPM_CIFAR10_32: "google/ddpm-cifar10-32", DDPM_CELEBA_HQ_256: "google/ddpm-ema-celebahq-256",
             DDPM_CHURCH_256: "google/ddpm-ema-church-256", DDPM_BEDROOM_256: "google/ddpm-ema-bedroom-256",
             LDM_CELEBA_HQ_256: "CompVis/ldm-celebahq-256"}
@@ -261,9 +268,15 @@ class DiffuserModelSched:
         elif noise_sched_type is None:
             noise_sched = ckpt_sched
             get_pipeline = DiffuserModelSched._pipeline_generator(DDPMPipeline)
+        elif noise_sched_type in DiffuserModelSched._PNDM_SCHEDS:
+            # SURVEY f-4: training uses only the betas of this object; sampling = PNDMPipeline with the post-step clip
+            if noise_sched_type == "PNDM-SCHED":
+                noise_sched = PNDMScheduler(**kw)
+            else:
+                noise_sched = SchedulerConfigCarrier(DiffuserModelSched._PNDM_SCHEDS[noise_sched_type], **kw)
+            get_pipeline = DiffuserModelSched._pipeline_generator(partial(PNDMPipeline, clip_sample=clip_used))
         elif noise_sched_type in DiffuserModelSched._OTHER_SCHEDS:
-            raise NotImplementedError(f"{noise_sched_type}: only DDPM-SCHED / DDIM-SCHED are on the BadDiffusion hot path "
-                                      "(SURVEY f-4; `--sched` is inert in the reference at this commit, Appendix D-3)")
+            raise NotImplementedError(f"{noise_sched_type}: not handled by the reference's model.py:577-643 either")
         else:
             raise NotImplementedError()
         if clip_used is not None:

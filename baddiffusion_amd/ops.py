@@ -457,6 +457,27 @@ def loss_fwd_bwd(pred, target, loss_type="l2", grad_scale=1.0, want_grad=True):
     return loss, dp
 
 
+def lincomb(terms, coeffs, clip=None, out=None):
+    """out = clamp?(sum_j coeffs[j] * terms[j]) (bd_lincomb): up to 6 dense float32 GPU tensors of one shape and layout."""
+    lib = L.load(); _need_cuda(*terms)
+    k = len(terms)
+    if k < 1 or k > 6 or len(coeffs) != k:
+        raise ValueError("lincomb: 1..6 terms with one coefficient each")
+    t0 = terms[0]
+    for t in terms:
+        if t.shape != t0.shape or t.stride() != t0.stride() or t.dtype != torch.float32:
+            raise ValueError("lincomb: terms must share shape, strides and dtype float32")
+    if not t0.permute(*sorted(range(t0.dim()), key=lambda d: -t0.stride(d))).is_contiguous():
+        raise ValueError("lincomb: terms must be dense")
+    if out is None:
+        out = torch.empty_like(t0)
+    ptrs = (C.c_void_p * k)(*[t.data_ptr() for t in terms])
+    cs = (C.c_float * k)(*[float(c) for c in coeffs])
+    L.check(lib.bd_lincomb(k, ptrs, cs, t0.numel(), 0 if clip is None else 1, 0.0 if clip is None else float(clip), L.ptr(out),
+                           L.stream()), "bd_lincomb")
+    return out
+
+
 def ssim(preds, target, data_range=1.0):
     """Mean SSIM (torchmetrics defaults, see bd_hip.h) of two [N,C,H,W] float32 GPU tensors with identical strides (any
     layout: a permuted NHWC buffer is fine).  Returns a 0-dim device tensor; batches with N*C > 65535 are chunked."""

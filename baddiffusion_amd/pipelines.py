@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import ops
-from .schedulers import DDIMScheduler, DDPMScheduler, randn_tensor
+from .schedulers import DDIMScheduler, PNDMScheduler, DDPMScheduler, randn_tensor
 
 
 class ImagePipelineOutput:
@@ -150,6 +150,50 @@ class DDIMPipeline(_PipelineBase):
             image = self.scheduler.step(eps, t, image.permute(0, 3, 1, 2), eta=eta,
                                         use_clipped_model_output=bool(use_clipped_model_output),
                                         generator=generator).prev_sample.permute(0, 2, 3, 1)
+            if save_every_step:
+                mov.append(self._to_numpy(image, shape))
+        if output_type == "u8":
+            images = self._to_u8(image, shape)
+            return ImagePipelineOutput(images=images, movie=mov) if return_dict else (images,)
+        images = self._to_numpy(image, shape)
+        if output_type == "pil":
+            images = self.numpy_to_pil(images)
+            if save_every_step:
+                mov = list(map(self.numpy_to_pil, mov))
+        if not return_dict:
+            return (images,)
+        return ImagePipelineOutput(images=images, movie=mov)
+
+
+class PNDMPipeline(_PipelineBase):
+    """pipelines/pndm/pipeline_pndm.py:39-122 (the reference's modified copy: `clip_sample` / `clip_sample_range`, `init`,
+    `start_from`, `save_every_step`).  Whatever scheduler it is given is converted to a PNDMScheduler from its config
+    (:46) -- which is how every `--sched` other than DDPM / DDIM samples in the reference.  The post-step clamp (:108-109)
+    is folded into the scheduler's update kernel."""
+
+    def __init__(self, unet, scheduler, clip_sample=False, clip_sample_range=1.0):
+        super().__init__(unet, PNDMScheduler.from_config(scheduler.config))
+        self.clip_sample = clip_sample
+        self.clip_sample_range = clip_sample_range
+
+    def encode(self, image, *args, **kwargs):
+        return image
+
+    def decode(self, image, *args, **kwargs):
+        return image
+
+    @torch.no_grad()
+    def __call__(self, batch_size=1, num_inference_steps=50, start_from=0, generator=None, output_type="pil", init=None,
+                 save_every_step=False, return_dict=True, **kwargs):
+        image, shape = self._start(batch_size, generator, init)
+        mov = [self._to_numpy(image, shape)] if save_every_step else []
+        self.scheduler.set_timesteps(num_inference_steps)
+        ts_host = self.scheduler.timesteps[int(start_from):]
+        ts_dev = torch.as_tensor(ts_host, dtype=torch.int64).to(self.device)
+        clip = float(self.clip_sample_range) if self.clip_sample else None
+        for i, t in enumerate(self.progress_bar(ts_host)):
+            eps = self.unet(image.permute(0, 3, 1, 2), ts_dev[i]).sample
+            image = self.scheduler.step(eps, int(t), image.permute(0, 3, 1, 2), clip=clip).prev_sample.permute(0, 2, 3, 1)
             if save_every_step:
                 mov.append(self._to_numpy(image, shape))
         if output_type == "u8":

@@ -251,3 +251,134 @@ class DDIMScheduler(_Base):
         if not return_dict:
             return (prev,)
         return SchedulerOutput(prev_sample=prev, pred_original_sample=x0)
+
+
+class PNDMScheduler(_Base):
+    """Pseudo numerical method scheduler (scheduling_pndm.py:60-426) on the GPU: 12 Runge-Kutta warm-up evaluations, then a
+    4-step Adams-Bashforth tail, every update being `sample_coeff * x + eps_coeff * (combination of stored model outputs)`
+    with formula (9) of the PNDM paper for the two scalars -- one fused `bd_lincomb` launch per update (plus one for the
+    Runge-Kutta accumulator), coefficients computed on the host in fp32 like the reference's scalar tensor arithmetic.
+    This is the scheduler every `--sched` other than DDPM / DDIM ends up as: PNDMPipeline re-creates it from whatever
+    scheduler config it is given (pipeline_pndm.py:46).  `step(..., clip=r)` folds the pipeline's post-step clamp in."""
+    order = 1
+
+    def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear", trained_betas=None,
+                 skip_prk_steps=False, set_alpha_to_one=False, prediction_type="epsilon", steps_offset=0, **unused):
+        self.config = FrozenConfig(num_train_timesteps=num_train_timesteps, beta_start=beta_start, beta_end=beta_end,
+                                   beta_schedule=beta_schedule, trained_betas=trained_betas, skip_prk_steps=skip_prk_steps,
+                                   set_alpha_to_one=set_alpha_to_one, prediction_type=prediction_type, steps_offset=steps_offset)
+        self._make_tables(num_train_timesteps, beta_start, beta_end, beta_schedule, trained_betas)
+        self.final_alpha_cumprod = torch.tensor(1.0) if set_alpha_to_one else self.alphas_cumprod[0]
+        self.pndm_order = 4
+        self.num_inference_steps = None
+        self.prk_timesteps = self.plms_timesteps = None
+        self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy().astype(np.int64))
+        self._reset()
+
+    _KEYS = ("num_train_timesteps", "beta_start", "beta_end", "beta_schedule", "trained_betas", "skip_prk_steps",
+             "set_alpha_to_one", "prediction_type", "steps_offset")
+
+    @classmethod
+    def from_config(cls, config):
+        return cls(**{k: config[k] for k in cls._KEYS if k in config})
+
+    def _reset(self):
+        self.counter, self.ets, self.cur_sample, self._acc = 0, [], None, None
+
+    def set_timesteps(self, num_inference_steps, device=None):
+        # scheduling_pndm.py:150-190
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps // num_inference_steps
+        base = (np.arange(0, num_inference_steps) * ratio).round() + self.config.steps_offset
+        if self.config.skip_prk_steps:
+            self.prk_timesteps = np.array([])
+            self.plms_timesteps = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1].copy()
+        else:
+            stages = np.array(base[-self.pndm_order:]).repeat(2) + np.tile(np.array([0, ratio // 2]), self.pndm_order)
+            self.prk_timesteps = (stages[:-1].repeat(2)[1:-1])[::-1].copy()
+            self.plms_timesteps = base[:-3][::-1].copy()
+        self.timesteps = torch.from_numpy(np.concatenate([self.prk_timesteps, self.plms_timesteps]).astype(np.int64)).to(device)
+        self._reset()
+
+    def _coeffs(self, t, prev_t):
+        """(sample_coeff, eps_coeff) of formula (9) as fp32 scalars (scheduling_pndm.py:366-397)"""
+        a_t = self.alphas_cumprod[t]
+        a_p = self.alphas_cumprod[prev_t] if prev_t >= 0 else self.final_alpha_cumprod
+        b_t, b_p = 1 - a_t, 1 - a_p
+        denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
+        return float((a_p / a_t) ** 0.5), float(-(a_p - a_t) / denom)
+
+    def step(self, model_output, timestep, sample, return_dict=True, clip=None):
+        if self.num_inference_steps is None:
+            raise ValueError("Number of inference steps is 'None', you need to run 'set_timesteps' after creating the scheduler")
+        if self.config.prediction_type != "epsilon":
+            raise ValueError(f"prediction_type given as {self.config.prediction_type} must be `epsilon` on the HIP path")
+        if not model_output.is_cuda:
+            raise RuntimeError("PNDMScheduler.step runs on the GPU only")
+        (eps, x), restore = self._align(model_output, sample)
+        t = int(timestep)
+        ratio = self.config.num_train_timesteps // self.num_inference_steps
+        if self.counter < len(self.prk_timesteps) and not self.config.skip_prk_steps:
+            # Runge-Kutta stage r of the current transition: weights 1/6, 1/3, 1/3, 1/6
+            r = self.counter % 4
+            prev_t = t - (0 if self.counter % 2 else ratio // 2)
+            t0 = int(self.prk_timesteps[self.counter // 4 * 4])
+            sc, ec = self._coeffs(t0, prev_t)
+            if r == 0:
+                self._acc = ops.lincomb([eps], [1.0 / 6.0])
+                self.ets.append(eps)
+                self.cur_sample = x
+            base = self.cur_sample if self.cur_sample is not None else x
+            if r in (1, 2):
+                self._acc = ops.lincomb([self._acc, eps], [1.0, 1.0 / 3.0])
+            if r == 3:
+                prev = ops.lincomb([base, self._acc, eps], [sc, ec, ec / 6.0], clip=clip)
+                self._acc = None
+            else:
+                prev = ops.lincomb([base, eps], [sc, ec], clip=clip)
+        else:
+            # linear multistep (Adams-Bashforth) on the stored model outputs
+            if not self.config.skip_prk_steps and len(self.ets) < 3:
+                raise ValueError(f"{self.__class__} can only be run AFTER scheduler has been run in 'prk' mode for at least 12 "
+                                 "iterations See: https://github.com/huggingface/diffusers/blob/main/src/diffusers/pipelines/"
+                                 "pipeline_pndm.py for more information.")
+            prev_t = t - ratio
+            if self.counter != 1:
+                self.ets = self.ets[-3:] + [eps]
+            else:
+                prev_t, t = t, t + ratio
+            k = len(self.ets)
+            if k == 1 and self.counter == 0:
+                terms, w = [eps], [1.0]
+                self.cur_sample = x
+            elif k == 1 and self.counter == 1:
+                terms, w = [eps, self.ets[-1]], [0.5, 0.5]
+                x, self.cur_sample = self.cur_sample, None
+            elif k == 2:
+                terms, w = [self.ets[-1], self.ets[-2]], [1.5, -0.5]
+            elif k == 3:
+                terms, w = [self.ets[-1], self.ets[-2], self.ets[-3]], [23.0 / 12.0, -16.0 / 12.0, 5.0 / 12.0]
+            else:
+                terms, w = [self.ets[-1], self.ets[-2], self.ets[-3], self.ets[-4]], [55.0 / 24.0, -59.0 / 24.0, 37.0 / 24.0, -9.0 / 24.0]
+            sc, ec = self._coeffs(t, prev_t)
+            prev = ops.lincomb([x] + terms, [sc] + [ec * wi for wi in w], clip=clip)
+        self.counter += 1
+        prev = restore(prev)
+        if not return_dict:
+            return (prev,)
+        return SchedulerOutput(prev_sample=prev)
+
+
+class SchedulerConfigCarrier(DDPMScheduler):
+    """What DiffuserModelSched returns as `noise_sched` for the `--sched` types the reference constructs but never steps
+    (model.py:598-630: DPM-Solver(++), UniPC, DEIS, Heun, LMS): training only uses its betas (`add_noise`,
+    `alphas_cumprod`, `config.num_train_timesteps`) and sampling goes through PNDMPipeline, which rebuilds a PNDMScheduler
+    from this config.  `class_name` records which reference class the config stands for."""
+
+    def __init__(self, class_name, **kw):
+        super().__init__(**kw)
+        self.class_name = class_name
+
+    def step(self, *a, **k):
+        raise NotImplementedError(f"{self.class_name}.step is never called by the reference either: PNDMPipeline converts the "
+                                  "scheduler to PNDMScheduler (pipeline_pndm.py:46)")

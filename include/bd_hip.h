@@ -111,6 +111,14 @@ typedef struct {
 } bd_ddim_step_desc;
 int bd_ddim_step(const bd_ddim_step_desc* d, bd_stream_t stream);
 
+/* f-4: out = clamp?(sum_j coeffs[j] * terms[j]) over k <= BD_LINCOMB_MAX dense fp32 tensors of n elements (one common
+ * layout; `terms` / `coeffs` are HOST arrays read at call time).  All PRK / PLMS updates of PNDMScheduler
+ * (scheduling_pndm.py:236-397: running sample, stored model outputs, Runge-Kutta accumulator; formula (9) in
+ * _get_prev_sample) are such combinations, and the post-step clip of pipeline_pndm.py:108-109 is the clamp. */
+#define BD_LINCOMB_MAX 6
+int bd_lincomb(int k, const float* const* terms, const float* coeffs, int64_t n, int clip, float clip_range, float* out,
+               bd_stream_t stream);
+
 /* (x/2+0.5).clamp(0,1): NCHW or NHWC(ld) in -> NHWC float [B,H,W,C] and/or uint8 round(255 x). */
 int bd_to_image(const float* x, int src_is_nhwc, int64_t ld, int B, int C, int H, int W,
                 float* out_f32, uint8_t* out_u8, bd_stream_t stream);

@@ -110,3 +110,80 @@ def add_noise(alphas_cumprod, x0, noise, timesteps):
 def to_image(x):
     # pipeline_ddpm.py:115-116  -> NHWC float32 in [0,1]
     return (x / 2 + 0.5).clamp(0, 1).permute(0, 2, 3, 1).contiguous()
+
+
+# ---- PNDM (SURVEY f-4): scheduling_pndm.py:150-190 (set_timesteps), :236-289 (Runge-Kutta warm-up), :291-353 (linear
+# multistep), :366-397 (formula (9) of the PNDM paper).  Every `--sched` other than DDPM / DDIM reaches this scheduler:
+# pipelines/pndm/pipeline_pndm.py:46 rebuilds a PNDMScheduler from the config of whatever scheduler it is handed. --------
+def pndm_timesteps(num_inference_steps, num_train_timesteps=1000, steps_offset=0, skip_prk_steps=False):
+    """(prk_timesteps, plms_timesteps): the 12 warm-up evaluations (4 Runge-Kutta stages for each of the last... first 3
+    transitions, the two middle stages sharing the half-step time) followed by the multistep tail."""
+    ratio = num_train_timesteps // num_inference_steps
+    base = (np.arange(0, num_inference_steps) * ratio).round() + steps_offset
+    if skip_prk_steps:
+        prk = np.array([])
+        plms = np.concatenate([base[:-1], base[-2:-1], base[-1:]])[::-1].copy()
+    else:
+        stages = np.array(base[-4:]).repeat(2) + np.tile(np.array([0, ratio // 2]), 4)
+        prk = (stages[:-1].repeat(2)[1:-1])[::-1].copy()
+        plms = base[:-3][::-1].copy()
+    return prk.astype(np.int64), plms.astype(np.int64)
+
+
+def pndm_transfer(alphas_cumprod, sample, t, prev_t, eps, final_alpha_cumprod=None):
+    """x_{t-d} from x_t and an epsilon estimate, formula (9): both coefficients are fp32 scalars"""
+    a_t = alphas_cumprod[t]
+    a_p = alphas_cumprod[prev_t] if prev_t >= 0 else (alphas_cumprod[0] if final_alpha_cumprod is None else final_alpha_cumprod)
+    b_t, b_p = 1 - a_t, 1 - a_p
+    sample_coeff = (a_p / a_t) ** 0.5
+    denom = a_t * b_p ** 0.5 + (a_t * b_t * a_p) ** 0.5
+    return sample_coeff * sample - (a_p - a_t) * eps / denom
+
+
+class PNDMRef:
+    """State machine of the pseudo numerical method: feed it (model_output, t, sample) in the order of `timesteps`."""
+
+    def __init__(self, alphas_cumprod, num_inference_steps, num_train_timesteps=1000, skip_prk_steps=False, steps_offset=0):
+        self.ac, self.n, self.T, self.skip = alphas_cumprod, num_inference_steps, num_train_timesteps, skip_prk_steps
+        self.prk, self.plms = pndm_timesteps(num_inference_steps, num_train_timesteps, steps_offset, skip_prk_steps)
+        self.timesteps = np.concatenate([self.prk, self.plms]).astype(np.int64)
+        self.counter, self.acc, self.cur_sample, self.ets = 0, 0, None, []
+
+    def step(self, eps, t, sample):
+        t = int(t)
+        ratio = self.T // self.n
+        if self.counter < len(self.prk) and not self.skip:          # Runge-Kutta stage (counter % 4)
+            prev_t = t - (0 if self.counter % 2 else ratio // 2)
+            t0 = int(self.prk[self.counter // 4 * 4])
+            r = self.counter % 4
+            if r == 0:
+                self.acc = self.acc + eps / 6
+                self.ets.append(eps)
+                self.cur_sample = sample
+            elif r in (1, 2):
+                self.acc = self.acc + eps / 3
+            else:
+                eps = self.acc + eps / 6
+                self.acc = 0
+            out = pndm_transfer(self.ac, self.cur_sample, t0, prev_t, eps)
+        else:                                                         # Adams-Bashforth on the stored estimates
+            prev_t = t - ratio
+            if self.counter != 1:
+                self.ets = self.ets[-3:] + [eps]
+            else:
+                prev_t, t = t, t + ratio
+            k = len(self.ets)
+            if k == 1 and self.counter == 0:
+                self.cur_sample = sample
+            elif k == 1 and self.counter == 1:
+                eps = (eps + self.ets[-1]) / 2
+                sample, self.cur_sample = self.cur_sample, None
+            elif k == 2:
+                eps = (3 * self.ets[-1] - self.ets[-2]) / 2
+            elif k == 3:
+                eps = (23 * self.ets[-1] - 16 * self.ets[-2] + 5 * self.ets[-3]) / 12
+            else:
+                eps = (55 * self.ets[-1] - 59 * self.ets[-2] + 37 * self.ets[-3] - 9 * self.ets[-4]) / 24
+            out = pndm_transfer(self.ac, sample, t, prev_t, eps)
+        self.counter += 1
+        return out

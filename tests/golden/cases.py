@@ -131,3 +131,20 @@ def train_inputs(cfg, B):
 
 def pipeline_init(cfg, n=2):
     return torch.randn(n, 3, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(0))
+
+
+# ---- G9: PNDM (f-4) ------------------------------------------------------------------------------------------
+PNDM_STEPS = (50, 20, 7)
+
+
+def pndm_fake_model(x, t):
+    """deterministic stand-in for the UNet in the scheduler-level PNDM chains: elementwise, so the reference run (CPU)
+    and the test run (any device) evaluate exactly the same function"""
+    import torch
+    tt = float(t) / 1000.0
+    return 0.6 * x + 0.25 * torch.sin(3.0 * x + tt) - 0.1 * tt
+
+
+def pndm_init():
+    import torch
+    return torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(77))

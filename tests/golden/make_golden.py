@@ -15,6 +15,8 @@ Fixtures:
   modules.npz   G5  ResnetBlock2D / AttentionBlock / Downsample2D / Upsample2D fwd + bwd
   unet_small.npz G6 two-level UNet fwd/bwd + 2/3-step DDPM and DDIM pipeline images
   unet_cifar.npz G7 full DDPM-CIFAR10-32 topology, B=2: output, loss, grad norms, one Adam step
+  pndm.npz      G9  PNDMScheduler timesteps + full chains with a stand-in model, the scheduler every `--sched` other than
+                    DDPM / DDIM ends up as (pipeline_pndm.py:46 converts whatever it is given), PNDMPipeline images
 """
 import os, sys, importlib.util, math
 sys.dont_write_bytecode = True
@@ -282,7 +284,53 @@ def g8():
     save("fid.npz", **out)
 
 
+# ---- G9 PNDM: scheduling_pndm.py, pipelines/pndm/pipeline_pndm.py (SURVEY f-4) ----------------------------------
+def g9():
+    from diffusers import PNDMScheduler, PNDMPipeline, DPMSolverMultistepScheduler, UniPCMultistepScheduler
+    out = {}
+    x0 = pndm_init()
+    for n in PNDM_STEPS:
+        s = PNDMScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02)
+        s.set_timesteps(n)
+        out[f"timesteps_{n}"] = s.timesteps
+        x = x0.clone()
+        xs = []
+        for t in s.timesteps:
+            x = s.step(pndm_fake_model(x, t), t, x).prev_sample
+            xs.append(x.clone())
+        out[f"chain_{n}"] = torch.stack(xs)
+    # what model.py:598-630 hands to PNDMPipeline is converted with PNDMScheduler.from_config(other.config)
+    for name, other in (("dpmpp2", DPMSolverMultistepScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02,
+                                                               solver_order=2, algorithm_type="dpmsolver++")),
+                        ("unipc", UniPCMultistepScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02))):
+        s = PNDMScheduler.from_config(other.config)
+        s.set_timesteps(20)
+        out[f"converted_{name}_timesteps_20"] = s.timesteps
+        out[f"converted_{name}_final_alpha"] = s.final_alpha_cumprod
+        out[f"converted_{name}_skip_prk"] = np.int64(bool(s.config.skip_prk_steps))
+    # skip_prk_steps variant (PLMS start-up branches of step_plms)
+    s = PNDMScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, skip_prk_steps=True)
+    s.set_timesteps(10)
+    out["skip_timesteps_10"] = s.timesteps
+    x = x0.clone(); xs = []
+    for t in s.timesteps:
+        x = s.step(pndm_fake_model(x, t), t, x).prev_sample
+        xs.append(x.clone())
+    out["skip_chain_10"] = torch.stack(xs)
+    # the pipeline over the small UNet (same weights / init as G6), with and without the post-step clip
+    cfg = SMALL_CFGS["small"]
+    m = ref_unet(cfg, U.gen_params(cfg, 7)).eval()
+    init = pipeline_init(cfg)
+    for clip in (True, False):
+        pipe = PNDMPipeline(m, DPMSolverMultistepScheduler(num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02),
+                            clip_sample=clip)
+        pipe.set_progress_bar_config(disable=True)
+        r = pipe(batch_size=init.shape[0], init=init, output_type=None, num_inference_steps=6)
+        out[f"pipe6_{int(clip)}"] = r.images
+    save("pndm.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
     for w in which:
         globals()[w]()

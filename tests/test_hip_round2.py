@@ -629,3 +629,50 @@ def test_full_batch_train_steps_bitwise_reproducible(gpu):
     (w0, m0, v0, h0), (w1, m1, v1, h1) = runs
     assert torch.equal(w0, w1) and torch.equal(m0, m1) and torch.equal(v0, v1)
     assert all(torch.equal(a[0], b[0]) and torch.equal(a[1], b[1]) for a, b in zip(h0, h1))
+
+
+def test_pndm_scheduler_and_pipeline_vs_reference(gpu, golden):
+    """SURVEY f-4, G9: the product's PNDMScheduler (bd_lincomb updates) against the reference's chains -- timesteps, the 12
+    Runge-Kutta warm-up evaluations + Adams-Bashforth tail for 50 / 20 / 7 steps, the skip_prk_steps start-up branches --
+    and PNDMPipeline (built from a DPM-Solver config carrier, as model.py:598-630 does) on the small UNet with and without
+    the post-step clip, vs the images the reference's PNDMPipeline produced."""
+    from baddiffusion_amd import ops
+    from baddiffusion_amd.model import DiffuserModelSched
+    from baddiffusion_amd.pipelines import PNDMPipeline
+    from baddiffusion_amd.schedulers import PNDMScheduler, SchedulerConfigCarrier
+    g = golden("pndm")
+    x0 = C.pndm_init()
+    for n in C.PNDM_STEPS:
+        s = PNDMScheduler()
+        s.set_timesteps(n)
+        assert np.array_equal(s.timesteps.numpy(), g[f"timesteps_{n}"])
+        x = x0.to(gpu)
+        for i, t in enumerate(s.timesteps):
+            x = s.step(C.pndm_fake_model(x, t), t, x).prev_sample
+            ref = torch.from_numpy(g[f"chain_{n}"][i])
+            assert float((x.cpu() - ref).abs().max()) <= 4e-6 * float(ref.abs().max()), (n, i)
+    s = PNDMScheduler(skip_prk_steps=True)
+    s.set_timesteps(10)
+    assert np.array_equal(s.timesteps.numpy(), g["skip_timesteps_10"])
+    x = x0.to(gpu)
+    for i, t in enumerate(s.timesteps):
+        x = s.step(C.pndm_fake_model(x, t), t, x).prev_sample
+        ref = torch.from_numpy(g["skip_chain_10"][i])
+        assert float((x.cpu() - ref).abs().max()) <= 4e-6 * float(ref.abs().max()), i
+    # the fused clamp == clamping afterwards
+    a, b = torch.randn(2, 3, 8, 8, device=gpu) * 2, torch.randn(2, 3, 8, 8, device=gpu)
+    assert torch.equal(ops.lincomb([a, b], [0.7, -1.3], clip=1.0), ops.lincomb([a, b], [0.7, -1.3]).clamp(-1, 1))
+    odd = torch.randn(7, device=gpu)                                   # n % 4 != 0 tail
+    assert torch.allclose(ops.lincomb([odd, odd], [2.0, 0.5]), 2.5 * odd, rtol=1e-6, atol=1e-6)
+    # pipeline on the small UNet
+    cfg = C.SMALL_CFGS["small"]
+    m = make_model(cfg, 7, gpu)
+    init = C.pipeline_init(cfg)
+    carrier = SchedulerConfigCarrier("DPMSolverMultistepScheduler", num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02)
+    for clip in (True, False):
+        pipe = PNDMPipeline(m, carrier, clip_sample=clip)
+        r = pipe(batch_size=init.shape[0], init=init, output_type=None, num_inference_steps=6)
+        ref = g[f"pipe6_{int(clip)}"]
+        assert r.images.shape == ref.shape
+        assert float(np.abs(r.images - ref).max()) < 2e-3, (clip, float(np.abs(r.images - ref).max()))
+    assert set(DiffuserModelSched._PNDM_SCHEDS) >= {"DPM_SOLVER_PP_O2-SCHED", "UNIPC-SCHED", "PNDM-SCHED", "HEUN-SCHED"}

@@ -135,8 +135,19 @@ def test_checkpoint_layout_roundtrip(tmp_path):
     assert torch.equal(m2.flat, model.flat)
     m3, s3, _ = DiffuserModelSched.get_trained(d, clip_sample=None)
     assert torch.equal(m3.flat, model.flat) and s3.config.clip_sample is False and m3.pretrained
+    # SURVEY f-4 (model.py:598-630): the other `--sched` types return a config carrier + a PNDMPipeline factory
+    from baddiffusion_amd.pipelines import PNDMPipeline
+    from baddiffusion_amd.schedulers import PNDMScheduler
+    m4, s4, gp4 = DiffuserModelSched.get_pretrained("DDPM-CIFAR10-32", noise_sched_type="UNIPC-SCHED", allow_random_init=True)
+    assert s4.class_name == "UniPCMultistepScheduler" and s4.config.num_train_timesteps == 1000 and s4.config.clip_sample is False
+    p4 = gp4(m4, s4)
+    assert isinstance(p4, PNDMPipeline) and isinstance(p4.scheduler, PNDMScheduler) and p4.clip_sample is False
     with pytest.raises(NotImplementedError):
-        DiffuserModelSched.get_pretrained("DDPM-CIFAR10-32", noise_sched_type="UNIPC-SCHED", allow_random_init=True)
+        s4.step(None, 0, None)
+    _, s5, _ = DiffuserModelSched.get_pretrained("DDPM-CIFAR10-32", noise_sched_type="PNDM-SCHED", allow_random_init=True)
+    assert isinstance(s5, PNDMScheduler)
+    with pytest.raises(NotImplementedError):     # named in model.py:556-563, rejected by its __get_model_sched as well
+        DiffuserModelSched.get_pretrained("DDPM-CIFAR10-32", noise_sched_type="EDM-VE-SCHED", allow_random_init=True)
 
 
 def test_dataset_modes_and_rank_sharding():

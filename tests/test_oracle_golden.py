@@ -310,3 +310,29 @@ def test_ssim_against_independent_scipy_formulation():
         want = float(m[..., 5:-5, 5:-5].mean())
         got = metrics.ssim(torch.from_numpy(a), torch.from_numpy(b))
         assert abs(got - want) < 2e-5, (shape, got, want)
+
+
+def test_pndm_oracle_matches_reference_chains(golden):
+    """G9: PNDMScheduler timesteps (also after from_config of a DPM-Solver++ / UniPC scheduler, which is what model.py:598-630
+    effectively selects) and full chains with the stand-in model, incl. the skip_prk_steps start-up branches."""
+    g = golden("pndm")
+    _, _, ac = sched_ref.make_tables()
+    x0 = C.pndm_init()
+    for n in C.PNDM_STEPS:
+        r = sched_ref.PNDMRef(ac, n)
+        assert np.array_equal(r.timesteps, g[f"timesteps_{n}"])
+        x = x0.clone()
+        for i, t in enumerate(r.timesteps):
+            x = r.step(C.pndm_fake_model(x, t), t, x)
+            ref = torch.from_numpy(g[f"chain_{n}"][i])
+            assert float((x - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), (n, i)   # fp32 rounding over up to 59 steps
+    for name in ("dpmpp2", "unipc"):
+        assert np.array_equal(sched_ref.PNDMRef(ac, 20).timesteps, g[f"converted_{name}_timesteps_20"])
+        assert int(g[f"converted_{name}_skip_prk"]) == 0 and float(g[f"converted_{name}_final_alpha"]) == float(ac[0])
+    r = sched_ref.PNDMRef(ac, 10, skip_prk_steps=True)
+    assert np.array_equal(r.timesteps, g["skip_timesteps_10"])
+    x = x0.clone()
+    for i, t in enumerate(r.timesteps):
+        x = r.step(C.pndm_fake_model(x, t), t, x)
+        ref = torch.from_numpy(g["skip_chain_10"][i])
+        assert float((x - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), i
