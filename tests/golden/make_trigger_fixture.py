@@ -73,7 +73,7 @@ bd = ref_dataset.Backdoor(root="/tmp")
 out = {}
 for name, ch, size in [("GLASSES", 3, 64), ("GLASSES", 3, 256), ("STOP_SIGN_14", 3, 32), ("STOP_SIGN_8", 3, 32), ("STOP_SIGN_14", 1, 32)]:
     out[f"trigger_{name}_c{ch}_s{size}"] = bd.get_trigger(type=name, channel=ch, image_size=size).numpy()
-for name, ch, size in [("HAT", 3, 32), ("CAT", 3, 64), ("HAT", 1, 32)]:
+for name, ch, size in [("HAT", 3, 32), ("CAT", 3, 64), ("HAT", 1, 32), ("CAT", 3, 256)]:
     trig = bd.get_trigger(type="BOX_14", channel=ch, image_size=size)
     out[f"target_{name}_c{ch}_s{size}"] = bd.get_target(type=name, trigger=trig).numpy()
 path = os.path.join(HERE, "img_triggers.npz")

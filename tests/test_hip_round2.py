@@ -676,3 +676,35 @@ def test_pndm_scheduler_and_pipeline_vs_reference(gpu, golden):
         assert r.images.shape == ref.shape
         assert float(np.abs(r.images - ref).max()) < 2e-3, (clip, float(np.abs(r.images - ref).max()))
     assert set(DiffuserModelSched._PNDM_SCHEDS) >= {"DPM_SOLVER_PP_O2-SCHED", "UNIPC-SCHED", "PNDM-SCHED", "HEUN-SCHED"}
+
+
+def test_celeba256_glasses_to_cat_poisoned_step(gpu, golden):
+    """BASELINE configs[3] per-GPU share with ITS backdoor: 256x256, batch 4, GLASSES trigger -> CAT target (the
+    reference's own Backdoor outputs on its static assets, tests/golden/img_triggers.npz), one row poisoned.  The fused
+    uint8 entry point's (R, x0) against the oracle's collated batch (dataset.py:288-315: int mask, blend), and the whole
+    fused train step == the collated calling convention on the 256x256 network (finite loss, identical weights)."""
+    from baddiffusion_amd import ops
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    g = golden("img_triggers")
+    trig = torch.from_numpy(g["trigger_GLASSES_c3_s256"]); tgt = torch.from_numpy(g["target_CAT_c3_s256"])
+    assert trig.shape == (3, 256, 256) and float(trig.min()) == -1.0 and float(trig.max()) <= 1.0
+    B, S = 4, 256
+    u8 = _u8_batch(B, S, 31)
+    pois = torch.tensor([False, True, False, False])
+    eps = torch.randn(B, 3, S, S, generator=torch.Generator().manual_seed(32))
+    t = torch.randint(0, 1000, (B,), generator=torch.Generator().manual_seed(33))
+    m1, m2 = make_model(U.CELEBA_HQ_256, 5, gpu), make_model(U.CELEBA_HQ_256, 5, gpu)
+    e1, e2 = TrainEngine(m1, DDPMScheduler(), lr=6e-5), TrainEngine(m2, DDPMScheduler(), lr=6e-5)
+    # poison + q_sample vs the oracle's collated batch
+    _, _, R, x0 = ops.poison_qsample(u8.cuda(), pois.cuda(), trig.cuda(), tgt.cuda(), eps.cuda(), t.cuda(), e1.alphas, e1.alphas_cumprod,
+                                     want_batch=True)
+    x = torch.stack([BD.image_u8_to_float(u8[i]) for i in range(B)])
+    Rr, x0r = BD.make_batch(x, pois, trig, tgt)
+    to_nchw = lambda v: v.permute(0, 3, 1, 2) if v.shape[-1] == 3 else v
+    assert float((to_nchw(R).cpu() - Rr).abs().max()) <= 1e-6 and float((to_nchw(x0).cpu() - x0r).abs().max()) <= 1e-6
+    assert float(Rr[1].abs().max()) > 0 and float(Rr[0].abs().max()) == 0      # only the poisoned row carries a residual
+    l1 = e1.train_step(u8.cuda(), pois.cuda(), trig.cuda(), tgt.cuda(), eps.cuda(), t.cuda())
+    l2 = e2.train_step_batch(x0, R, eps.cuda(), t.cuda())
+    assert torch.isfinite(l1) and float(l1) > 0 and abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l2))
+    assert relerr(m1.flat, m2.flat) < 1e-6 and torch.isfinite(m1.flat).all()

@@ -253,4 +253,4 @@ def test_image_file_triggers_match_reference_fixture():
         assert got.shape == want.shape and got.dtype == want.dtype, key
         assert torch.equal(got, want), (key, float((got - want).abs().max()))
         n += 1
-    assert n == 8
+    assert n == 9
