@@ -169,14 +169,15 @@ def bench_sampling(args, world, rank, dev):
     """SURVEY 8(d) sampling metric: the full DDIM-50 / DDPM-1000 loop (UNet forward + scheduler step per timestep) over one
     chunk of --batch initial noises per GPU; chains are independent, ranks shard the rows, no collective (8e)."""
     from baddiffusion_amd.model import KNOWN_TOPOLOGIES
-    from baddiffusion_amd.pipelines import DDIMPipeline, DDPMPipeline
+    from baddiffusion_amd.pipelines import DDIMPipeline, DDPMPipeline, PNDMPipeline
     from baddiffusion_amd.schedulers import DDPMScheduler
     from baddiffusion_amd.unet import UNet2DModel
     model = UNet2DModel(**KNOWN_TOPOLOGIES["google/ddpm-cifar10-32"], compute_mode=args.mode).to(dev)
     n = args.batch if args.batch > 0 else 512
     ddim = args.workload == "ddim50"
-    steps = 50 if ddim else 1000
-    pipe = (DDIMPipeline if ddim else DDPMPipeline)(model, DDPMScheduler(num_train_timesteps=1000))
+    pndm = args.workload == "pndm50"     # what every other --sched resolves to (SURVEY f-4): 50 steps = 59 UNet evaluations
+    steps = 50 if (ddim or pndm) else 1000
+    pipe = (PNDMPipeline if pndm else DDIMPipeline if ddim else DDPMPipeline)(model, DDPMScheduler(num_train_timesteps=1000))
     pipe.set_progress_bar_config(disable=True) if hasattr(pipe, "set_progress_bar_config") else None
     init = torch.randn(n, 3, 32, 32, generator=torch.Generator().manual_seed(rank)).to(dev)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
@@ -197,14 +198,15 @@ def bench_sampling(args, world, rank, dev):
         dist.destroy_process_group()
     if rank == 0:
         img = out.images
-        gf = 12.444 * steps                               # GFLOP per sample
+        evals = len(pipe.scheduler.timesteps) if pndm else steps
+        gf = 12.444 * evals                               # GFLOP per sample
         print(json.dumps({
-            "metric": f"{'DDIM 50' if ddim else 'DDPM 1000'}-step samples/sec (32x32 UNet, DDPM-CIFAR10-32 topology)",
+            "metric": f"{'PNDM 50' if pndm else 'DDIM 50' if ddim else 'DDPM 1000'}-step samples/sec (32x32 UNet, DDPM-CIFAR10-32 topology)",
             "value": world * n / dt, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": 5,
             "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if args.mode == "f32" else "f32 (split-bf16 hi+lo products, fp32 accumulate)",
             "data": "synthetic (seeded N(0,1) init, seeded default-init weights)",
-            "config": {"workload": f"BASELINE configs[4]-style sampling: {steps}-step {'DDIM (eta 0)' if ddim else 'DDPM'} loop, "
+            "config": {"workload": f"BASELINE configs[4]-style sampling: {steps}-step {'PNDM (59 UNet evaluations)' if pndm else 'DDIM (eta 0)' if ddim else 'DDPM'} loop, "
                                    f"{n} samples per GPU in one chunk, images to float NHWC at the end, no PNG I/O",
                        "global_batch": world * n, "parallelism": f"replicas x{world} (rows sharded, no collective)"},
             "seconds_per_loop": dt, "step_tflops": gf * n * world / dt / 1e3,
@@ -219,7 +221,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 128 for cifar, 4 for celeba)")
-    ap.add_argument("--workload", default="cifar", choices=["cifar", "celeba", "ddim50", "ddpm1000"],
+    ap.add_argument("--workload", default="cifar", choices=["cifar", "celeba", "ddim50", "ddpm1000", "pndm50"],
                     help="cifar = BASELINE configs[1] (the metric); celeba = the 256x256 DDPM-CELEBA-HQ-256 topology; "
                          "ddim50 / ddpm1000 = CIFAR sampling loops (samples/s, --batch samples per GPU, --steps ignored) -- side measurements")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -259,7 +261,7 @@ def main():
     # DDPM-CIFAR10-32 topology, torch default init with seed 0 (no hub weights offline)
     torch.manual_seed(0)
     from baddiffusion_amd.model import KNOWN_TOPOLOGIES
-    if args.workload in ("ddim50", "ddpm1000"):
+    if args.workload in ("ddim50", "ddpm1000", "pndm50"):
         return bench_sampling(args, world, rank, dev)
     celeba = args.workload == "celeba"      # BASELINE configs[3] topology (256x256, 113.7 M params), a side measurement
     topo = KNOWN_TOPOLOGIES["google/ddpm-ema-celebahq-256" if celeba else "google/ddpm-cifar10-32"]

@@ -16,6 +16,7 @@ head -12 $out/${tag}_train_step_b128_kernel_stats.txt | cut -c1-140
 cut -c1-400 $out/${tag}_bench.json
 cd $GRAFT_REPO_ROOT && python bench.py --workload ddim50 --batch 2048 2>/dev/null | tail -1 > $out/${tag}_bench_ddim50.json
 cd $GRAFT_REPO_ROOT && python bench.py --workload ddpm1000 --batch 256 2>/dev/null | tail -1 > $out/${tag}_bench_ddpm1000.json
+cd $GRAFT_REPO_ROOT && python bench.py --workload pndm50 --batch 2048 2>/dev/null | tail -1 > $out/${tag}_bench_pndm50.json
 # stand-alone kernel durations (side stream off) for the kernel table in DESIGN.md
 cd /tmp && rm -rf /tmp/rp2 && BD_AUX_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/rp2 -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-prof > /tmp/rp2.log 2>&1
 python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/rp2 -name "*.db" | head -1) 10 > $out/${tag}_train_step_b128_single_stream_kernel_stats.txt
