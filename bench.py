@@ -282,9 +282,15 @@ def main():
     target_name = "CORNER"
     target = bd.get_target("CORNER", trigger.cpu())
     hat = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "img_triggers.npz")
-    if not celeba and os.path.exists(hat):
+    trigger_name = "BOX_14"
+    if os.path.exists(hat):
         import numpy as np
-        target, target_name = torch.from_numpy(np.load(hat)["target_HAT_c3_s32"]), "HAT"
+        gv = np.load(hat)
+        if not celeba:
+            target, target_name = torch.from_numpy(gv["target_HAT_c3_s32"]), "HAT"
+        else:   # BASELINE configs[3]: GLASSES -> CAT
+            trigger, trigger_name = torch.from_numpy(gv["trigger_GLASSES_c3_s256"]).to(dev), "GLASSES"
+            target, target_name = torch.from_numpy(gv["target_CAT_c3_s256"]), "CAT"
     target = target.to(dev)
     NIMG = 256 if celeba else 8192
     g = torch.Generator().manual_seed(1000 + rank)
@@ -370,8 +376,8 @@ def main():
         hbm_floor_ms = (16688e6 * B + 6.65e9 if celeba else 452.3e6 * B + 2.25e9) / 8e12 * 1e3   # eager-level bytes / 8 TB/s
         if celeba:
             metric = f"train images/sec (256x256 UNet, DDPM-CELEBA-HQ-256 topology, bs{B}/GPU, poison_rate 0.1)"
-            workload = (f"BASELINE configs[3] topology: DDPM-CELEBA-HQ-256 train step, batch {B}/GPU, poison_rate 0.1, BOX_14 trigger, "
-                        "CORNER target, clip 1.0 + Adam (side measurement, not the headline metric)")
+            workload = (f"BASELINE configs[3] topology: DDPM-CELEBA-HQ-256 train step, batch {B}/GPU, poison_rate 0.1, {trigger_name} trigger, "
+                        f"{target_name} target, clip 1.0 + Adam (side measurement, not the headline metric)")
         else:
             metric = "train images/sec (32x32 UNet, DDPM-CIFAR10-32 topology, bs128/GPU, poison_rate 0.1)"
             workload = ("BASELINE configs[1]: CIFAR10 DDPM-CIFAR10-32 train step, batch 128/GPU, poison_rate 0.1, "
