@@ -68,3 +68,18 @@ def test_error_reporting_without_gpu():
     h = ctypes.c_void_p()
     assert lib.bd_unet_create(ctypes.byref(cfg), ctypes.byref(h)) == -1
     assert b"num_blocks" in lib.bd_last_error()
+
+
+def test_round2_entry_points_reject_bad_arguments_without_gpu():
+    """argument checks of the entry points added in round 2 run on the host before any launch: they must fail loudly with a
+    message (negative status + bd_last_error), never touch the device"""
+    from baddiffusion_amd import _lib as L
+    lib = L.load()
+    assert lib.bd_lincomb(0, None, None, 16, 0, 0.0, None, None) < 0 and b"bd_lincomb" in lib.bd_last_error()
+    assert lib.bd_lincomb(7, None, None, 16, 0, 0.0, None, None) < 0
+    assert lib.bd_ssim(None, None, 1, 3, 32, 32, 0, 0, 0, 0, 1.0, None, None, 0, None) < 0 and b"bd_ssim" in lib.bd_last_error()
+    assert lib.bd_ssim_workspace_bytes(2, 3, 32, 32) == 2 * 3 * 8 and lib.bd_ssim_workspace_bytes(2, 3, 75, 44) == 2 * 3 * 3 * 2 * 8
+    assert lib.bd_gn_bwd_params(None, 0, 4, None) < 0 and b"bd_gn_bwd_params" in lib.bd_last_error()
+    assert lib.bd_gn_bwd_defers(128, 1024, 128, 32) == 1 and lib.bd_gn_bwd_defers(4, 65536, 128, 32) == 0
+    assert lib.bd_gn_bwd_defers(4, 64, 130, 32) == 0                      # C not divisible by G
+    assert lib.bd_conv3x3_ps(None, None) < 0 and lib.bd_conv3x3_ps_wgrad(None, None) < 0 and lib.bd_attn_fwd(None, None) < 0
