@@ -722,8 +722,8 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
         }
         BD_TRY(linear_wgrad(c, dqkv, 3 * C, BP(c, b_n), C, c.grads + pqw, M, 3 * C, C, c.grads + pqb));
         BD_TRY(linear_dgrad(c, dqkv, 3 * C, c.params + pqw, BP(c, b_dn), C, M, 3 * C, C, 0));
-        BD_TRY(gn_bwd(c, x, pgw, pgb, b_st, BP(c, b_dn), C, 0));
-        return add(c, dy, lddy, GP(c, x), x.ld, M, C, 1.f, 1);
+        // group-norm backward; the residual connection's gradient (dy itself) is added in the same store
+        return gn_bwd(c, x, pgw, pgb, b_st, BP(c, b_dn), C, 0, dy, lddy);
     });
 }
 
