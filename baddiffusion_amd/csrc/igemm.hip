@@ -1121,6 +1121,56 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(IGemmParams p, int nb
     *dst = v;
 }
 
+// the same pass four outputs per thread (float4 slab loads, four slabs in flight): same per-element summation order, so
+// bit-identical to the scalar form; needs N, ldc, ldr and the batch strides of C to be multiples of 4 and C 16-byte aligned
+__global__ __launch_bounds__(256) void igemm_splitk_reduce4(IGemmParams p, int nbatch) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long per = (long long)p.M * p.N, per4 = per >> 2;
+    if (idx >= per4 * nbatch) {   // tail threads: the fused A column sums (batch 1 only)
+        const long long m = idx - per4 * nbatch;
+        if (p.a_colsum && m < p.M) {
+            float v = 0.f;
+            for (int s = 0; s < p.ksplit; ++s) v += p.partial[(long long)p.ksplit * per + (long long)s * p.M + m];
+            p.a_colsum[m] = v;
+        }
+        return;
+    }
+    const int bz = (int)(idx / per4);
+    const long long mn = (idx - (long long)bz * per4) << 2;
+    const int m = (int)(mn / p.N), n = (int)(mn - (long long)m * p.N);
+    const float* src = p.partial + (long long)bz * p.ksplit * per + mn;
+    float4 v = *reinterpret_cast<const float4*>(src);
+#pragma unroll 4
+    for (int s = 1; s < p.ksplit; ++s) {
+        const float4 b = *reinterpret_cast<const float4*>(src + (long long)s * per);
+        v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
+    }
+    const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
+    const long long coff = bo * p.c_bso + bi * p.c_bsi;
+    float o[4] = {v.x * p.alpha, v.y * p.alpha, v.z * p.alpha, v.w * p.alpha};
+    if (p.bias) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += p.bias[n + j];
+    }
+    if (p.rowbias) {
+        const float* rb = p.rowbias + (long long)(m / p.rows_per_group) * p.ld_rowbias + n;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] += rb[j];
+    }
+    if (p.residual) {
+        const float4 r = *reinterpret_cast<const float4*>(p.residual + coff + (long long)m * p.ldr + n);
+        o[0] += r.x; o[1] += r.y; o[2] += r.z; o[3] += r.w;
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] *= p.out_scale;
+    float4* dst = reinterpret_cast<float4*>(p.C + coff + (long long)m * p.ldc + n);
+    if (p.accumulate) {
+        const float4 e = *dst;
+        o[0] += e.x; o[1] += e.y; o[2] += e.z; o[3] += e.w;
+    }
+    *dst = make_float4(o[0], o[1], o[2], o[3]);
+}
+
 // ------------------------------------------------------------------------------------------------
 static bool operand_vec_ok(const bd_operand& o, int rows, int K) {
     if (!aligned16(o.p) || (o.ld & 3) || (o.bs_outer & 3) || (o.bs_inner & 3)) return false;
@@ -1379,6 +1429,15 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
     }
     BD_LAUNCH_CHECK("igemm");
     if (c.ksplit > 1) {
+        const bool vec4 = (d.N & 3) == 0 && (d.ldc & 3) == 0 && (d.c_bs_outer & 3) == 0 && (d.c_bs_inner & 3) == 0 && aligned16(d.C) &&
+                          aligned16(d.workspace) && (!d.residual || ((d.ldr & 3) == 0 && aligned16(d.residual)));
+        if (vec4) {
+            const long long total4 = (long long)d.M * d.N / 4 * nb + (d.a_colsum ? d.M : 0);
+            hipLaunchKernelGGL(igemm_splitk_reduce4, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, stream, p, nb);
+            BD_LAUNCH_CHECK("igemm_splitk_reduce4");
+            prof_end(rec, stream);
+            return BD_OK;
+        }
         long long total = (long long)d.M * d.N * nb + (d.a_colsum ? d.M : 0);
         hipLaunchKernelGGL(igemm_splitk_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, stream, p, nb);
         BD_LAUNCH_CHECK("igemm_splitk_reduce");
