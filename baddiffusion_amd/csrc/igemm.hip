@@ -1121,17 +1121,23 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce(IGemmParams p, int nb
     *dst = v;
 }
 
-// the same pass four outputs per thread (float4 slab loads, four slabs in flight): same per-element summation order, so
-// bit-identical to the scalar form; needs N, ldc, ldr and the batch strides of C to be multiples of 4 and C 16-byte aligned
+// the same pass on float4 slab loads.  LANES = 8: eight adjacent lanes share one output float4, each sums every eighth
+// slab and a butterfly folds them -- few outputs times many slabs (the weight-gradient GEMMs: 50-200 K outputs, 32-128
+// slabs) otherwise leave most of the chip idle behind one thread's serial loads.  Fixed order either way (deterministic).
+// Needs N, ldc, ldr and the batch strides of C to be multiples of 4 and C 16-byte aligned.
+template <int LANES>
 __global__ __launch_bounds__(256) void igemm_splitk_reduce4(IGemmParams p, int nbatch) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long gid = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long idx = gid / LANES;
+    const int sub = (int)(gid - idx * LANES);
     const long long per = (long long)p.M * p.N, per4 = per >> 2;
-    if (idx >= per4 * nbatch) {   // tail threads: the fused A column sums (batch 1 only)
+    if (idx >= per4 * nbatch) {   // tail: the fused A column sums (batch 1 only), one lane group per row
         const long long m = idx - per4 * nbatch;
         if (p.a_colsum && m < p.M) {
             float v = 0.f;
-            for (int s = 0; s < p.ksplit; ++s) v += p.partial[(long long)p.ksplit * per + (long long)s * p.M + m];
-            p.a_colsum[m] = v;
+            for (int s = sub; s < p.ksplit; s += LANES) v += p.partial[(long long)p.ksplit * per + (long long)s * p.M + m];
+            for (int off = 1; off < LANES; off <<= 1) v += __shfl_xor(v, off);
+            if (sub == 0) p.a_colsum[m] = v;
         }
         return;
     }
@@ -1139,12 +1145,16 @@ __global__ __launch_bounds__(256) void igemm_splitk_reduce4(IGemmParams p, int n
     const long long mn = (idx - (long long)bz * per4) << 2;
     const int m = (int)(mn / p.N), n = (int)(mn - (long long)m * p.N);
     const float* src = p.partial + (long long)bz * p.ksplit * per + mn;
-    float4 v = *reinterpret_cast<const float4*>(src);
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll 4
-    for (int s = 1; s < p.ksplit; ++s) {
+    for (int s = sub; s < p.ksplit; s += LANES) {
         const float4 b = *reinterpret_cast<const float4*>(src + (long long)s * per);
         v.x += b.x; v.y += b.y; v.z += b.z; v.w += b.w;
     }
+    for (int off = 1; off < LANES; off <<= 1) {
+        v.x += __shfl_xor(v.x, off); v.y += __shfl_xor(v.y, off); v.z += __shfl_xor(v.z, off); v.w += __shfl_xor(v.w, off);
+    }
+    if (sub != 0) return;
     const int bo = bz / p.batch_inner, bi = bz - bo * p.batch_inner;
     const long long coff = bo * p.c_bso + bi * p.c_bsi;
     float o[4] = {v.x * p.alpha, v.y * p.alpha, v.z * p.alpha, v.w * p.alpha};
@@ -1433,7 +1443,11 @@ int igemm_launch(const bd_igemm_desc& d, hipStream_t stream) {
                           aligned16(d.workspace) && (!d.residual || ((d.ldr & 3) == 0 && aligned16(d.residual)));
         if (vec4) {
             const long long total4 = (long long)d.M * d.N / 4 * nb + (d.a_colsum ? d.M : 0);
-            hipLaunchKernelGGL(igemm_splitk_reduce4, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, stream, p, nb);
+            // many slabs over few outputs: eight lanes per output (the butterfly needs whole groups: 256 % 8 == 0)
+            if (c.ksplit >= 16 && total4 < (1 << 20))
+                hipLaunchKernelGGL(igemm_splitk_reduce4<8>, dim3((unsigned)cdiv(total4 * 8, 256)), dim3(256), 0, stream, p, nb);
+            else
+                hipLaunchKernelGGL(igemm_splitk_reduce4<1>, dim3((unsigned)cdiv(total4, 256)), dim3(256), 0, stream, p, nb);
             BD_LAUNCH_CHECK("igemm_splitk_reduce4");
             prof_end(rec, stream);
             return BD_OK;
