@@ -270,7 +270,12 @@ def sampling(config, file_name, pipeline, dsl):
         gen(noise + dsl.trigger.unsqueeze(0), "backdoor_samples")       # raw trigger incl. its -1 background (:417)
 
 
-def update_score_file(config, score_file, fid_sc, mse_sc, ssim_sc):
+FID_UNAVAILABLE = ("pytorch_fid's InceptionV3 pool3 weights (pt_inception-2015-12-05) are a third-party asset that is not in the "
+                   "reference repository and cannot be fetched here; activation statistics + Frechet distance are "
+                   "baddiffusion_amd.metrics.fid_from_features(features_a, features_b) once a feature extractor is supplied")
+
+
+def update_score_file(config, score_file, fid_sc, mse_sc, ssim_sc, fid_reason=None):
     def key(k):
         r = f"{k}_ep{config.sample_ep}" if config.sample_ep is not None else k
         return r + ("_noclip" if not config.clip else "")
@@ -282,6 +287,10 @@ def update_score_file(config, score_file, fid_sc, mse_sc, ssim_sc):
     for k, v in (("FID", fid_sc), ("MSE", mse_sc), ("SSIM", ssim_sc)):
         if v is not None or key(k) not in sc:
             sc[key(k)] = v
+    if sc.get(key("FID")) is None:
+        sc[key("FID_reason")] = fid_reason or FID_UNAVAILABLE      # a null FID is never silent
+    else:
+        sc.pop(key("FID_reason"), None)
     with open(path, "w") as f:
         json.dump(sc, f, indent=2, sort_keys=True)
     return sc
@@ -326,7 +335,7 @@ def measure(config, dsl, folder_name, pipeline, rank=0, world=1):
     # FID needs pool3 features of pytorch_fid's InceptionV3 (weights do not travel); with a feature extractor the rest of
     # the path is metrics.fid_from_features(...) -> ActivationStats on the device + Frechet distance (pinned by G8)
     print(f"[{config.sample_ep}] FID: None (pytorch_fid Inception weights unavailable), MSE: {mse_sc}, SSIM: {ssim_sc}")
-    return update_score_file(config, "score.json", None, mse_sc, ssim_sc)
+    return update_score_file(config, "score.json", None, mse_sc, ssim_sc, fid_reason=FID_UNAVAILABLE)
 
 
 def checkpoint(config, engine, pipeline, cur_epoch, cur_step):
@@ -342,9 +351,21 @@ def checkpoint(config, engine, pipeline, cur_epoch, cur_step):
         pipeline.save_pretrained(os.path.join(config.output_dir, config.ep_model_dir, f"ep{cur_epoch}"))
 
 
-def restore_training_state(config, engine):
+def save_rank_rng(config, rank):
+    """ranks > 0: their own random-number state next to rank 0's data.ckpt (every rank draws its own noise / timesteps, so a
+    resumed multi-rank run needs one state per rank; rank 0's lives in data.ckpt itself, written by checkpoint())"""
+    if rank == 0:
+        return
+    torch.save({"cpu_rng": torch.get_rng_state(), "cuda_rng": torch.cuda.get_rng_state() if torch.cuda.is_available() else None},
+               f"{config.data_ckpt_path}.rank{rank}")
+
+
+def restore_training_state(config, engine, rank=0):
     """baddiffusion.py:336-342 (accelerator.load_state): Adam moments, optimizer step counters and the RNG state written by
-    checkpoint(); the weights themselves come from the diffusers-layout directory (get_trained).  Returns (epoch, step)."""
+    checkpoint(); the weights themselves come from the diffusers-layout directory (get_trained).  Returns (epoch, step).
+    The random-number state is per rank (data.ckpt for rank 0, data.ckpt.rank<r> otherwise): a resumed run continues
+    bit-identically for any world size that matches the checkpointed one; a rank without a state file of its own (the run was
+    checkpointed with fewer ranks) is re-seeded with seed + rank and says so."""
     opt_file = os.path.join(config.ckpt_path, "optimizer.bin")
     if os.path.exists(opt_file):
         st = torch.load(opt_file, map_location="cpu")
@@ -354,6 +375,14 @@ def restore_training_state(config, engine):
     if os.path.exists(config.data_ckpt_path):
         st = torch.load(config.data_ckpt_path, map_location="cpu")
         epoch, step = st["epoch"], st["step"]
+        if rank > 0:
+            own = f"{config.data_ckpt_path}.rank{rank}"
+            if os.path.exists(own):
+                st = torch.load(own, map_location="cpu")
+            else:
+                print(f"[rank {rank}] no RNG state of its own in the checkpoint: re-seeding with seed + rank (not bit-identical)")
+                torch.manual_seed(config.seed + rank)
+                st = {}
         if st.get("cpu_rng") is not None:
             torch.set_rng_state(st["cpu_rng"])
         if st.get("cuda_rng") is not None and torch.cuda.is_available():
@@ -369,7 +398,7 @@ def train_loop(config, model, noise_sched, get_pipeline, dsl, device, world, ran
                          num_training_steps=num_batch * config.epoch // config.gradient_accumulation_steps,
                          grad_accum_steps=config.gradient_accumulation_steps)
     if config.mode == MODE_RESUME:
-        restore_training_state(config, engine)
+        restore_training_state(config, engine, rank)
     dsl.to_device(device)
     trigger, target = dsl.trigger.to(device), dsl.target.to(device)
     log = open(os.path.join(config.output_dir, "log.jsonl"), "a") if rank == 0 else None
@@ -394,6 +423,8 @@ def train_loop(config, model, noise_sched, get_pipeline, dsl, device, world, ran
                     sampling(config, epoch, pipeline, dsl)
                 if (epoch + 1) % config.save_model_epochs == 0 or epoch == config.epoch - 1:
                     checkpoint(config, engine, pipeline, epoch, cur_step)
+            elif (epoch + 1) % config.save_model_epochs == 0 or epoch == config.epoch - 1:
+                save_rank_rng(config, rank)
     except Exception:
         traceback.print_exc()          # the reference swallows the exception too (:635-637) but we re-raise below
         raise
@@ -401,6 +432,8 @@ def train_loop(config, model, noise_sched, get_pipeline, dsl, device, world, ran
         if rank == 0:
             pipeline = get_pipeline(unet=model, scheduler=noise_sched)
             checkpoint(config, engine, pipeline, epoch, cur_step)
+        else:
+            save_rank_rng(config, rank)
         if log is not None:
             log.close()
     return get_pipeline(unet=model, scheduler=noise_sched)

@@ -175,6 +175,7 @@ SIGNATURES = {
     "bd_prof_reset": (i32, []),
     "bd_prof_num_classes": (i32, []),
     "bd_prof_get": (i32, [i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(f64), C.POINTER(f64), C.POINTER(f64)]),
+    "bd_mfma_probe": (i32, [i32, i32, i32, C.POINTER(f64), vp]),
     "bd_axpy": (i32, [vp, vp, i64, f32, i32, vp]),
     "bd_adam_clip_dev": (i32, [vp, vp, vp, vp, i64, vp, f64, vp, f64, f64, f64, vp, vp]),
     "bd_unet_create": (i32, [C.POINTER(UnetConfig), C.POINTER(vp)]),

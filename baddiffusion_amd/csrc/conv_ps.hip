@@ -955,6 +955,13 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
     BD_CHECK(d.ldx % 32 == 0 && ((uintptr_t)d.x_split & 127) == 0 && ((uintptr_t)d.w_split & 127) == 0, BD_ERR_UNSUPPORTED,
              "conv3x3_ps: split planes need ld %% 32 == 0 and 128-byte aligned bases");
     BD_CHECK(d.direction == 1 || d.direction == -1, BD_ERR_INVALID, "conv3x3_ps: direction must be +1 or -1");
+    // the epilogues and the split-K second pass move float4: every fp32 operand needs 16-byte rows
+    BD_CHECK(d.ldy % 4 == 0 && ((uintptr_t)d.y & 15) == 0, BD_ERR_UNSUPPORTED, "conv3x3_ps: y needs ldy %% 4 == 0 and a 16-byte aligned base");
+    BD_CHECK(!d.residual || (d.ldr % 4 == 0 && ((uintptr_t)d.residual & 15) == 0), BD_ERR_UNSUPPORTED,
+             "conv3x3_ps: residual needs ldr %% 4 == 0 and a 16-byte aligned base");
+    BD_CHECK(!d.rowbias || (d.ld_rowbias % 4 == 0 && ((uintptr_t)d.rowbias & 15) == 0), BD_ERR_UNSUPPORTED,
+             "conv3x3_ps: rowbias needs ld_rowbias %% 4 == 0 and a 16-byte aligned base");
+    BD_CHECK(!d.bias || ((uintptr_t)d.bias & 15) == 0, BD_ERR_UNSUPPORTED, "conv3x3_ps: bias needs a 16-byte aligned base");
     const long long M = (long long)d.B * d.H * d.W;
     BD_CHECK(M < (1ll << 31), BD_ERR_UNSUPPORTED, "conv3x3_ps: pixel count overflows int32");
     BD_CHECK((long long)(d.W + 1) * d.ldx * 4 < (1ll << 31), BD_ERR_UNSUPPORTED, "conv3x3_ps: row pitch too large");
@@ -979,11 +986,14 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
         p.ablate = getenv("BD_PS_ABLATE") ? atoi(getenv("BD_PS_ABLATE")) : 0;
 #endif
 #define PS_LAUNCH(E) hipLaunchKernelGGL((conv_ps_kernel<E>), grid, block, 0, st, p)
-        switch (epi) {
+        switch (epi) {          // every combination has its own instantiation: the epilogue's addends are compile-time
             case 0: PS_LAUNCH(0); break;
             case 1: PS_LAUNCH(1); break;
             case 2: PS_LAUNCH(2); break;
+            case 3: PS_LAUNCH(3); break;
             case 4: PS_LAUNCH(4); break;
+            case 5: PS_LAUNCH(5); break;
+            case 6: PS_LAUNCH(6); break;
             default: PS_LAUNCH(7); break;
         }
 #undef PS_LAUNCH
@@ -1004,7 +1014,10 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
             case 0: hipLaunchKernelGGL(conv_ps128_kernel<0>, grid, block, 0, st, pp); break;
             case 1: hipLaunchKernelGGL(conv_ps128_kernel<1>, grid, block, 0, st, pp); break;
             case 2: hipLaunchKernelGGL(conv_ps128_kernel<2>, grid, block, 0, st, pp); break;
+            case 3: hipLaunchKernelGGL(conv_ps128_kernel<3>, grid, block, 0, st, pp); break;
             case 4: hipLaunchKernelGGL(conv_ps128_kernel<4>, grid, block, 0, st, pp); break;
+            case 5: hipLaunchKernelGGL(conv_ps128_kernel<5>, grid, block, 0, st, pp); break;
+            case 6: hipLaunchKernelGGL(conv_ps128_kernel<6>, grid, block, 0, st, pp); break;
             default: hipLaunchKernelGGL(conv_ps128_kernel<7>, grid, block, 0, st, pp); break;
         }
         BD_LAUNCH_CHECK("conv_ps128");

@@ -5,63 +5,42 @@ Reference call sites: baddiffusion.py:536-547 (`nn.MSELoss`, `StructuralSimilari
 * `ActivationStats` accumulates sum and sum of outer products in fp64 ON THE GPU, batch by batch (no [N, 2048] host
   array); `frechet_distance` then needs one matrix square root of a d x d product, which stays on scipy / CPU.
 * SSIM follows the published torchmetrics defaults the reference relies on (11x11 Gaussian, sigma 1.5, k1 0.01,
-  k2 0.03, reflect padding, border crop, mean over C,H,W then over the batch).  torchmetrics is not installed in the
-  build container, so SSIM parity is UNPINNED; Frechet / statistics are pinned by G8.
+  k2 0.03, reflect padding, border crop, mean over C,H,W then over the batch) and exists only as the HIP kernel bd_ssim
+  (csrc/metrics.hip).  torchmetrics is not installed in the build container, so SSIM parity against torchmetrics itself is
+  UNPINNED; the kernel is checked against the independent fp64 scipy statement in oracle/metrics_ref.py.
+  Frechet / statistics are pinned by G8.
 * The Inception pool3 network (pytorch_fid weights) is an asset that does not travel: callers pass any feature
   extractor `f(images) -> [n, d]`.
 """
 import numpy as np
 import torch
-import torch.nn.functional as F   # F.pad only
 
 
 def mse(a, b):
-    """nn.MSELoss(reduction='mean') (baddiffusion.py:545).  GPU tensors: the fused l2-loss kernel (bd_loss_fwd_bwd, fp64
-    partial sums); CPU tensors (tests): the same formula in fp64."""
-    if a.is_cuda and b.is_cuda and a.shape == b.shape and a.shape[-1] % 1 == 0:
-        from . import ops
-        a32, b32 = a.float().contiguous(), b.float().contiguous()
-        loss, _ = ops.loss_fwd_bwd(a32.reshape(-1, a32.shape[-1]), b32.reshape(-1, b32.shape[-1]), "l2", want_grad=False)
-        return float(loss)
-    return float(((a.double() - b.double()) ** 2).mean())
+    """nn.MSELoss(reduction='mean') (baddiffusion.py:545) through the fused l2-loss kernel (bd_loss_fwd_bwd): the difference
+    is taken in fp32, its squares are accumulated in fp64 partial sums folded in fixed order.  Device tensors only: there is
+    no CPU path (tests pin the kernel against the fp64 formula in oracle/metrics_ref.py, |err| <= 1e-6 relative)."""
+    if not (a.is_cuda and b.is_cuda):
+        raise RuntimeError("metrics.mse: device tensors required (the measure path runs on the GPU; no CPU fallback)")
+    if a.shape != b.shape:
+        raise ValueError(f"mse: shapes differ: {tuple(a.shape)} vs {tuple(b.shape)}")
+    from . import ops
+    a32, b32 = a.float().contiguous(), b.float().contiguous()
+    loss, _ = ops.loss_fwd_bwd(a32.reshape(-1, a32.shape[-1]), b32.reshape(-1, b32.shape[-1]), "l2", want_grad=False)
+    return float(loss)
 
 
-def _gauss1d(k, sigma, device, dtype):
-    x = torch.arange(k, device=device, dtype=dtype) - (k - 1) / 2
-    g = torch.exp(-(x / sigma) ** 2 / 2)
-    return g / g.sum()
-
-
-def ssim(preds, target, data_range=1.0, kernel_size=11, sigma=1.5, k1=0.01, k2=0.03):
-    """Mean SSIM of two [N,C,H,W] batches.  GPU tensors with the reference's defaults run the HIP kernel bd_ssim; CPU tensors
-    (tests, and the statement the kernel is checked against) run the torch restatement below."""
+def ssim(preds, target, data_range=1.0):
+    """Mean SSIM of two [N,C,H,W] batches with the torchmetrics defaults the reference relies on (baddiffusion.py:260,546):
+    the HIP kernel bd_ssim.  Device tensors only; images must be larger than the 11-tap window."""
     if preds.shape != target.shape or preds.dim() != 4:
         raise ValueError(f"expected two [N,C,H,W] tensors of the same shape, got {tuple(preds.shape)} and {tuple(target.shape)}")
-    if preds.is_cuda and target.is_cuda and (kernel_size, sigma, k1, k2) == (11, 1.5, 0.01, 0.03) and min(preds.shape[-2:]) > 10:
-        from . import ops                     # the HIP kernel (bd_ssim): the reference's defaults, no aten compute
-        return float(ops.ssim(preds.float(), target.float(), data_range))
-    p, t = preds.float(), target.float()
-    C = p.shape[1]
-    c1, c2 = (k1 * data_range) ** 2, (k2 * data_range) ** 2
-    g = _gauss1d(kernel_size, sigma, p.device, p.dtype)
-    pad = (kernel_size - 1) // 2
-    p = F.pad(p, (pad, pad, pad, pad), mode="reflect")
-    t = F.pad(t, (pad, pad, pad, pad), mode="reflect")
-    stack = torch.cat((p, t, p * p, t * t, p * t))
-    # the 11x11 window is separable (g g^T): "valid" filtering = two banded matrix products, rows then columns
-    def band(n_out):
-        m = torch.zeros(n_out, n_out + kernel_size - 1, device=p.device, dtype=p.dtype)
-        idx = torch.arange(n_out, device=p.device)
-        for j in range(kernel_size):
-            m[idx, idx + j] = g[j]
-        return m
-    H, W = preds.shape[-2:]
-    out = torch.einsum("ih,nchw,jw->ncij", band(H), stack, band(W))
-    mp, mt, pp, tt, pt = out.split(preds.shape[0])
-    sp, st, spt = pp - mp * mp, tt - mt * mt, pt - mp * mt
-    full = ((2 * mp * mt + c1) * (2 * spt + c2)) / ((mp * mp + mt * mt + c1) * (sp + st + c2))
-    full = full[..., pad:-pad, pad:-pad]
-    return float(full.reshape(full.shape[0], -1).mean(-1).mean())
+    if not (preds.is_cuda and target.is_cuda):
+        raise RuntimeError("metrics.ssim: device tensors required (bd_ssim is a HIP kernel; no CPU fallback)")
+    if min(preds.shape[-2:]) <= 10:
+        raise ValueError("ssim: images must be larger than the 11x11 window")
+    from . import ops
+    return float(ops.ssim(preds.float(), target.float(), data_range))
 
 
 class ActivationStats:
@@ -89,24 +68,31 @@ class ActivationStats:
 
 
 def frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
-    """d^2 = |mu1 - mu2|^2 + Tr(S1 + S2 - 2 (S1 S2)^(1/2)) (fid_score.py:150-204, incl. its singular-product retry)."""
+    """Squared Frechet distance between N(mu1, sigma1) and N(mu2, sigma2):
+    |mu1 - mu2|^2 + Tr(sigma1) + Tr(sigma2) - 2 Tr((sigma1 sigma2)^(1/2)).
+    Behaviour kept from fid_score.py:150-204 (pinned by G8): a non-finite square root is retried once with eps added to both
+    diagonals, and a complex root is accepted only if its diagonal is real to 1e-3."""
     from scipy import linalg
-    mu1, mu2 = np.atleast_1d(np.asarray(mu1, np.float64)), np.atleast_1d(np.asarray(mu2, np.float64))
-    sigma1, sigma2 = np.atleast_2d(np.asarray(sigma1, np.float64)), np.atleast_2d(np.asarray(sigma2, np.float64))
-    if mu1.shape != mu2.shape:
+    m = [np.atleast_1d(np.asarray(v, np.float64)) for v in (mu1, mu2)]
+    S = [np.atleast_2d(np.asarray(v, np.float64)) for v in (sigma1, sigma2)]
+    if m[0].shape != m[1].shape:
         raise ValueError("Training and test mean vectors have different lengths")
-    if sigma1.shape != sigma2.shape:
+    if S[0].shape != S[1].shape:
         raise ValueError("Training and test covariances have different dimensions")
-    diff = mu1 - mu2
-    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
-    if not np.isfinite(covmean).all():
-        offset = np.eye(sigma1.shape[0]) * eps
-        covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
-    if np.iscomplexobj(covmean):
-        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
-            raise ValueError("Imaginary component {}".format(np.max(np.abs(covmean.imag))))
-        covmean = covmean.real
-    return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean))
+
+    def root_of_product(jitter):
+        r = linalg.sqrtm((S[0] + jitter) @ (S[1] + jitter), disp=False)
+        return r[0] if isinstance(r, tuple) else r
+    root = root_of_product(0.0)
+    if not np.all(np.isfinite(root)):
+        root = root_of_product(eps * np.eye(S[0].shape[0]))
+    if np.iscomplexobj(root):
+        worst = float(np.abs(np.diagonal(root).imag).max())
+        if worst > 1e-3:
+            raise ValueError(f"Imaginary component {worst}")
+        root = root.real
+    gap = m[0] - m[1]
+    return float(gap @ gap + np.trace(S[0]) + np.trace(S[1]) - 2.0 * np.trace(root))
 
 
 def fid_from_features(features_a, features_b):

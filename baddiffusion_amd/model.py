@@ -157,9 +157,11 @@ def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], 
     # being sampled.  A pipeline that returns host arrays (float [0,1]) keeps the reference's serial save_imgs path.
     from concurrent.futures import ThreadPoolExecutor
     cnt = offset
-    pool = ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4))
     pending = []
     copy_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
+    # decided up front (not by catching exceptions around the sampling call: an error raised mid-chain must surface, and a retry
+    # would re-sample with an rng that has already advanced)
+    device_u8 = bool(getattr(pipeline, "supports_u8", False)) and copy_stream is not None
 
     def _write(host, ev, start):
         from PIL import Image
@@ -170,29 +172,28 @@ def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], 
             img = arr[k]
             Image.fromarray(img[..., 0] if img.shape[-1] == 1 else img).save(os.path.join(path, f"{start + k}.png"))
 
-    for i, bs in enumerate(batch_sizes):
-        try:
-            res = pipeline(batch_size=bs, generator=rng, init=inits[i], output_type="u8")
-        except (TypeError, ValueError):
-            res = pipeline(batch_size=bs, generator=rng, init=inits[i], output_type=None)
-        imgs = res.images
-        if torch.is_tensor(imgs) and imgs.is_cuda and imgs.dtype == torch.uint8:
-            host = torch.empty(imgs.shape, dtype=torch.uint8, pin_memory=True)
-            copy_stream.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(copy_stream):
-                host.copy_(imgs, non_blocking=True)
-                ev = torch.cuda.Event(); ev.record(copy_stream)
-            imgs.record_stream(copy_stream)
-            # split the chunk over the pool: PNG encoding is the slow part (zlib), one task per 64 images
-            for s0 in range(0, bs, 64):
-                pending.append(pool.submit(_write, host[s0: s0 + 64], ev, cnt + s0))
-        else:
-            save_imgs(imgs=imgs, file_dir=path, file_name="", start_cnt=cnt)
-        cnt += bs
-        del res
-    for f in pending:
-        f.result()
-    pool.shutdown()
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
+        for i, bs in enumerate(batch_sizes):
+            res = pipeline(batch_size=bs, generator=rng, init=inits[i], output_type="u8" if device_u8 else None)
+            imgs = res.images
+            if device_u8:
+                if not (torch.is_tensor(imgs) and imgs.is_cuda and imgs.dtype == torch.uint8):
+                    raise TypeError("pipeline.supports_u8 is set but output_type='u8' did not return device uint8 images")
+                host = torch.empty(imgs.shape, dtype=torch.uint8, pin_memory=True)
+                copy_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(copy_stream):
+                    host.copy_(imgs, non_blocking=True)
+                    ev = torch.cuda.Event(); ev.record(copy_stream)
+                imgs.record_stream(copy_stream)
+                # split the chunk over the pool: PNG encoding is the slow part (zlib), one task per 64 images
+                for s0 in range(0, bs, 64):
+                    pending.append(pool.submit(_write, host[s0: s0 + 64], ev, cnt + s0))
+            else:
+                save_imgs(imgs=imgs, file_dir=path, file_name="", start_cnt=cnt)
+            cnt += bs
+            del res
+        for f in pending:
+            f.result()
     return None
 
 

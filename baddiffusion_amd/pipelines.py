@@ -25,6 +25,8 @@ class ImagePipelineOutput:
 
 
 class _PipelineBase:
+    supports_u8 = True      # output_type="u8" returns device uint8 images (batch_sampling_save's overlapped PNG path)
+
     def __init__(self, unet, scheduler):
         self.unet = unet
         self.scheduler = scheduler

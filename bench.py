@@ -105,8 +105,21 @@ def _host_cores():
     return max(1, min(cores, int(os.environ.get("BD_CPU_THREADS", cores))))
 
 
-def _cpu_baseline_worker():
-    """Child process: time oracle train steps (config 1: batch 16, poison 0.0) and print one JSON line per step."""
+def _cpu_model():
+    """CPU model string of this host (print it next to every CPU number)."""
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.lower().startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    import platform
+    return platform.processor() or platform.machine()
+
+
+def _cpu_baseline_worker(kind="train"):
+    """Child process: time oracle train steps (config 1: batch 16, poison 0.0) -- or, kind == "sample", oracle DDPM sampling
+    steps (UNet forward + scheduler step, batch 16) -- and print one JSON line per step."""
     from oracle import sched_ref, train_ref
     from oracle import unet_ref as U
     cfg = U.CIFAR10_32
@@ -115,6 +128,17 @@ def _cpu_baseline_worker():
     P = U.gen_params(cfg, 0)
     _, a, ac = sched_ref.make_tables()
     B = 16
+    if kind == "sample":      # 10 DDPM sampling steps at batch 16, extrapolated to 1000 / 50
+        x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(0))
+        gz = torch.Generator().manual_seed(1)
+        with torch.no_grad():
+            for step in range(64):
+                t = 999 - step
+                t0 = time.time()
+                e = U.unet_forward(cfg, P, x, t)
+                x, _ = sched_ref.ddpm_step(ac, e, t, x, torch.randn(x.shape, generator=gz))
+                print(json.dumps({"step": step, "s": time.time() - t0, "cores": torch.get_num_threads(), "B": B}), flush=True)
+        return
     g = torch.Generator().manual_seed(0)
     x0 = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
     R = torch.zeros_like(x0)
@@ -128,12 +152,13 @@ def _cpu_baseline_worker():
         print(json.dumps({"step": step, "s": time.time() - t0, "cores": torch.get_num_threads(), "B": B}), flush=True)
 
 
-def cpu_baseline(seconds_budget=40.0):
+def cpu_baseline(seconds_budget=40.0, kind="train"):
     """The reference CPU path = the oracle's fp32 restatement (oracle/), BASELINE configs[0]: batch 16, poison 0.0,
-    run in a child process that is killed after `seconds_budget` so the bench always finishes in minutes."""
+    run in a child process that is killed after `seconds_budget` so the bench always finishes in minutes.
+    kind == "sample": per-step cost of the oracle's DDPM sampling loop (returns seconds per step at batch 16)."""
     import subprocess
-    p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker"], stdout=subprocess.PIPE,
-                         stderr=subprocess.DEVNULL, text=True, cwd=ROOT)
+    p = subprocess.Popen([sys.executable, os.path.abspath(__file__), "--cpu-baseline-worker", "--cpu-baseline-kind", kind],
+                         stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, text=True, cwd=ROOT)
     recs = []
     t_start = time.time()
     import selectors
@@ -153,35 +178,46 @@ def cpu_baseline(seconds_budget=40.0):
             pass
     p.kill()
     if not recs:
-        return {"value": None, "unit": "images/s", "cores": None, "kind": "port",
-                "sample": f"no oracle train step (batch 16) finished within {seconds_budget:.0f} s on this host"}
+        return {"value": None, "unit": "images/s", "cores": None, "cpu_model": _cpu_model(), "kind": "port",
+                "sample": f"no oracle {kind} step (batch 16) finished within {seconds_budget:.0f} s on this host"}
     timed = [r["s"] for r in recs[2:]] or [r["s"] for r in recs[-1:]]
     timed.sort()
     med = timed[len(timed) // 2]
     B = recs[0]["B"]
-    return {"value": B / med, "unit": "images/s", "cores": recs[0]["cores"], "kind": "port",
+    if kind == "sample":
+        return {"seconds_per_step": med, "batch": B, "cores": recs[0]["cores"], "cpu_model": _cpu_model(), "kind": "port",
+                "timed_steps": len(timed)}
+    return {"value": B / med, "unit": "images/s", "cores": recs[0]["cores"], "cpu_model": _cpu_model(), "kind": "port",
             "sample": f"{len(timed)} timed train steps ({len(recs) - len(timed)} warm-up) of the CIFAR-32 UNet, batch {B}, "
                       f"poison_rate 0.0, fp32, oracle/train_ref.py on the host CPU (median {med:.3f} s/step, "
                       f"budget {seconds_budget:.0f} s)"}
 
 
-def bench_sampling(args, world, rank, dev):
-    """SURVEY 8(d) sampling metric: the full DDIM-50 / DDPM-1000 loop (UNet forward + scheduler step per timestep) over one
-    chunk of --batch initial noises per GPU; chains are independent, ranks shard the rows, no collective (8e)."""
-    from baddiffusion_amd.model import KNOWN_TOPOLOGIES
+def _read_classes(lib):
+    cl = []
+    for c in range(lib.bd_prof_num_classes()):
+        name = ctypes.c_char_p(); n = ctypes.c_int64(); tms = ctypes.c_double(); fl = ctypes.c_double(); by = ctypes.c_double()
+        lib.bd_prof_get(c, ctypes.byref(name), ctypes.byref(n), ctypes.byref(tms), ctypes.byref(fl), ctypes.byref(by))
+        cl.append({"kernel": name.value.decode(), "launches": n.value, "ms": tms.value, "flops": fl.value, "bytes": by.value})
+    cl.sort(key=lambda c: -c["ms"])
+    return cl
+
+
+def run_sampling(model, kind, n, mode, world, rank, dev, lib, want_roofline=True):
+    """SURVEY 8(d) sampling metric: the full DDIM-50 / DDPM-1000 / PNDM-50 loop (UNet forward + scheduler step per timestep,
+    pipeline_ddpm.py:106-111, pipeline_ddim.py:114-121) over `n` initial noises per GPU; chains are independent, ranks shard
+    the rows, no collective (8e).  Returns the result dict (rank 0) -- whole-job samples/s, the dominant kernel's roofline
+    fraction from hipEvent pairs around every GEMM-class launch of three extra, untimed UNet evaluations of the same chunk size."""
     from baddiffusion_amd.pipelines import DDIMPipeline, DDPMPipeline, PNDMPipeline
     from baddiffusion_amd.schedulers import DDPMScheduler
-    from baddiffusion_amd.unet import UNet2DModel
-    model = UNet2DModel(**KNOWN_TOPOLOGIES["google/ddpm-cifar10-32"], compute_mode=args.mode).to(dev)
-    n = args.batch if args.batch > 0 else 512
-    ddim = args.workload == "ddim50"
-    pndm = args.workload == "pndm50"     # what every other --sched resolves to (SURVEY f-4): 50 steps = 59 UNet evaluations
+    ddim, pndm = kind == "ddim50", kind == "pndm50"   # pndm50: what every other --sched resolves to (SURVEY f-4): 59 UNet evaluations
     steps = 50 if (ddim or pndm) else 1000
     pipe = (PNDMPipeline if pndm else DDIMPipeline if ddim else DDPMPipeline)(model, DDPMScheduler(num_train_timesteps=1000))
-    pipe.set_progress_bar_config(disable=True) if hasattr(pipe, "set_progress_bar_config") else None
+    pipe.set_progress_bar_config(disable=True)
     init = torch.randn(n, 3, 32, 32, generator=torch.Generator().manual_seed(rank)).to(dev)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     pipe(batch_size=n, init=init[:min(n, 64)], generator=gen, num_inference_steps=min(steps, 5), output_type=None)   # warm-up
+    pipe(batch_size=n, init=init, generator=gen, num_inference_steps=2, output_type=None)                             # + the full chunk shape
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -195,24 +231,137 @@ def bench_sampling(args, world, rank, dev):
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
+    evals = len(pipe.scheduler.timesteps) if pndm else steps
+    gf = 12.444 * evals                               # GFLOP per sample
+    res = {"metric": f"{'PNDM 50' if pndm else 'DDIM 50' if ddim else 'DDPM 1000'}-step samples/sec (32x32 UNet, DDPM-CIFAR10-32 topology)",
+           "value": world * n / dt, "unit": "samples/s", "samples_per_gpu": n, "unet_evaluations": evals,
+           "seconds_per_loop": dt, "ms_per_unet_step": dt / evals * 1e3, "step_tflops": gf * n * world / dt / 1e3,
+           "frac_of_fp32_mfma_peak": gf * n / dt / 1e3 / FP32_MFMA_PEAK_TFLOPS,
+           "images_finite": bool(np.isfinite(np.asarray(out.images)).all())}
+    if want_roofline:
+        lib.bd_prof_reset(); lib.bd_prof_enable(1)
+        pipe(batch_size=n, init=init[:min(n, model.max_chunk)], generator=gen, num_inference_steps=3, output_type=None)
+        lib.bd_prof_enable(0)
+        torch.cuda.synchronize()
+        cl = _read_classes(lib)
+        if cl:
+            d = cl[0]
+            ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+            peak = FP32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 3
+            res["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
+                               "frac": ach / peak, "traffic": None, "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+                               "share_of_gemm_class_time": d["ms"] / sum(c["ms"] for c in cl),
+                               "note": "hipEvent pairs on the launch stream, 3 untimed UNet evaluations of one chunk; the two half-batch "
+                                       "forward pipelines share the chip, so this is an in-schedule figure"}
+    return res
+
+
+def sampling_cpu_baseline(seconds_budget=25.0):
+    """10 oracle DDPM sampling steps at batch 16 on the host cores, extrapolated to the 1000-step
+    (DDPM) and 50-step (DDIM: same UNet evaluation per step, a cheaper update) loops."""
+    r = cpu_baseline(seconds_budget, kind="sample")
+    if "seconds_per_step" not in r:
+        return {"ddpm1000": r, "ddim50": r}
+    sps, B = r["seconds_per_step"], r["batch"]
+    mk = lambda nsteps: {"value": B / (sps * nsteps), "unit": "samples/s", "cores": r["cores"], "cpu_model": r["cpu_model"], "kind": "port",
+                         "sample": f"{r['timed_steps']} timed oracle DDPM sampling steps (UNet forward + scheduler step, batch {B}, fp32, "
+                                   f"oracle/unet_ref.py + sched_ref.py; median {sps:.3f} s/step) extrapolated x{nsteps}"}
+    return {"ddpm1000": mk(1000), "ddim50": mk(50)}
+
+
+def bench_sampling(args, world, rank, dev):
+    """--workload ddim50 / ddpm1000 / pndm50: the sampling loop alone, one JSON line (side measurement)."""
+    from baddiffusion_amd import _lib as L
+    from baddiffusion_amd.model import KNOWN_TOPOLOGIES
+    from baddiffusion_amd.unet import UNet2DModel
+    model = UNet2DModel(**KNOWN_TOPOLOGIES["google/ddpm-cifar10-32"], compute_mode=args.mode).to(dev)
+    n = args.batch if args.batch > 0 else 512
+    res = run_sampling(model, args.workload, n, args.mode, world, rank, dev, L.load(), want_roofline=not args.no_prof)
+    if world > 1:
         dist.destroy_process_group()
     if rank == 0:
-        img = out.images
-        evals = len(pipe.scheduler.timesteps) if pndm else steps
-        gf = 12.444 * evals                               # GFLOP per sample
-        print(json.dumps({
-            "metric": f"{'PNDM 50' if pndm else 'DDIM 50' if ddim else 'DDPM 1000'}-step samples/sec (32x32 UNet, DDPM-CIFAR10-32 topology)",
-            "value": world * n / dt, "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": 5,
-            "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if args.mode == "f32" else "f32 (split-bf16 hi+lo products, fp32 accumulate)",
-            "data": "synthetic (seeded N(0,1) init, seeded default-init weights)",
-            "config": {"workload": f"BASELINE configs[4]-style sampling: {steps}-step {'PNDM (59 UNet evaluations)' if pndm else 'DDIM (eta 0)' if ddim else 'DDPM'} loop, "
-                                   f"{n} samples per GPU in one chunk, images to float NHWC at the end, no PNG I/O",
-                       "global_batch": world * n, "parallelism": f"replicas x{world} (rows sharded, no collective)"},
-            "seconds_per_loop": dt, "step_tflops": gf * n * world / dt / 1e3,
-            "frac_of_fp32_mfma_peak": gf * n / dt / 1e3 / FP32_MFMA_PEAK_TFLOPS,
-            "images_finite": bool(np.isfinite(np.asarray(img)).all())}))
+        steps = 1000 if args.workload == "ddpm1000" else 50
+        line = {"metric": res["metric"], "value": res["value"], "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": 5,
+                "ms_per_step": res["seconds_per_loop"] / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if args.mode == "f32" else "f32 (split-bf16 hi+lo products, fp32 accumulate)",
+                "data": "synthetic (seeded N(0,1) init, seeded default-init weights)",
+                "config": {"workload": f"BASELINE configs[4]-style sampling: {args.workload} loop, {n} samples per GPU, images to float NHWC "
+                                       f"at the end, no PNG I/O", "global_batch": world * n,
+                           "parallelism": f"replicas x{world} (rows sharded, no collective)"}}
+        line.update({k: v for k, v in res.items() if k not in line})
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = sampling_cpu_baseline()["ddpm1000" if args.workload == "ddpm1000" else "ddim50"]
+        print(json.dumps(line))
     return 0
+
+
+def setup_train(celeba, B, mode, dev, rank, use_graph=False):
+    """model + engine + resident synthetic data for one train workload; returns (model, engine, step(i), names)"""
+    from baddiffusion_amd.dataset import Backdoor
+    from baddiffusion_amd.model import KNOWN_TOPOLOGIES
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    from baddiffusion_amd.unet import UNet2DModel
+    topo = KNOWN_TOPOLOGIES["google/ddpm-ema-celebahq-256" if celeba else "google/ddpm-cifar10-32"]
+    S_IMG = topo["sample_size"]
+    model = UNet2DModel(**topo, compute_mode=mode).to(dev)
+    eng = TrainEngine(model, DDPMScheduler(num_train_timesteps=1000), lr=2e-4, lr_warmup_steps=500, num_training_steps=469 * 50,
+                      use_graph=use_graph)
+    # synthetic data resident in HBM: uint8 images, poison flags i % 10 == 0.  BASELINE configs[1] names BOX_14 -> HAT and
+    # configs[3] GLASSES -> CAT: static/*.png are reference assets and do not travel, but what the reference's Backdoor returns
+    # for them does, as a reference-derived golden vector (tests/golden/img_triggers.npz, made by make_trigger_fixture.py with a
+    # torchvision stand-in for the resize).  CORNER / BOX_14 only if that file is missing; the arithmetic is the same either way.
+    bd = Backdoor(root=None)
+    trigger = bd.get_trigger("BOX_14", 3, S_IMG).to(dev)
+    trigger_name, target_name, src = "BOX_14", "CORNER", "built-in constructors"
+    target = bd.get_target("CORNER", trigger.cpu())
+    hat = os.path.join(ROOT, "tests", "golden", "img_triggers.npz")
+    if os.path.exists(hat):
+        gv = np.load(hat)
+        src = "reference-derived golden vector tests/golden/img_triggers.npz (torchvision stand-in for the resize)"
+        if not celeba:
+            target, target_name = torch.from_numpy(gv["target_HAT_c3_s32"]), "HAT"
+        else:
+            trigger, trigger_name = torch.from_numpy(gv["trigger_GLASSES_c3_s256"]).to(dev), "GLASSES"
+            target, target_name = torch.from_numpy(gv["target_CAT_c3_s256"]), "CAT"
+    target = target.to(dev)
+    NIMG = 256 if celeba else 8192
+    g = torch.Generator().manual_seed(1000 + rank)
+    images = torch.randint(0, 256, (NIMG, S_IMG, S_IMG, 3), generator=g, dtype=torch.uint8).to(dev)
+    flags = (torch.arange(NIMG) % 10 == 0).to(dev)
+    NPOOL = 2 if celeba else 8
+    noise = torch.randn(NPOOL, B, 3, S_IMG, S_IMG, generator=g).to(dev)
+    ts = torch.randint(0, 1000, (NPOOL, B), generator=g).to(dev)
+
+    def step(i):
+        s0 = (i * B) % (NIMG - B + 1)
+        return eng.train_step(images[s0:s0 + B], flags[s0:s0 + B], trigger, target, noise[i % NPOOL], ts[i % NPOOL])
+    return model, eng, step, {"trigger": trigger_name, "target": target_name, "target_source": src, "S": S_IMG}
+
+
+def timed_steps(step, first, n, barrier, dev, world, prof=None):
+    """EXACTLY n steps bracketed by barrier + synchronize on both sides; returns (wall seconds max over ranks, last loss,
+    per-step milliseconds from events on the launch stream)."""
+    ev = [torch.cuda.Event(enable_timing=True) for _ in range(n + 1)]
+    barrier()
+    t0 = time.perf_counter()
+    loss = None
+    for i in range(n):
+        ev[i].record()
+        if prof:
+            prof(i, True)
+        loss = step(first + i)
+        if prof:
+            prof(i, False)
+    ev[n].record()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt)
+    per = [ev[i].elapsed_time(ev[i + 1]) for i in range(n)]
+    return dt, loss, per
 
 
 def main():
@@ -222,22 +371,31 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 128 for cifar, 4 for celeba)")
     ap.add_argument("--workload", default="cifar", choices=["cifar", "celeba", "ddim50", "ddpm1000", "pndm50"],
-                    help="cifar = BASELINE configs[1] (the metric); celeba = the 256x256 DDPM-CELEBA-HQ-256 topology; "
-                         "ddim50 / ddpm1000 = CIFAR sampling loops (samples/s, --batch samples per GPU, --steps ignored) -- side measurements")
+                    help="cifar = BASELINE configs[1] (the metric; its line also carries the sampling loops and the 256x256 step as "
+                         "`sampling` / `celeba` objects); celeba = the 256x256 DDPM-CELEBA-HQ-256 topology alone; "
+                         "ddim50 / ddpm1000 / pndm50 = one CIFAR sampling loop alone (samples/s, --batch samples per GPU, --steps ignored)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
+    ap.add_argument("--no-sampling", action="store_true", help="skip the DDIM-50 x 2048 and DDPM-1000 x 256 loops of the default line")
+    ap.add_argument("--sampling-n", default="2048,256", help="samples per GPU of the DDIM-50 and DDPM-1000 loops (BASELINE configs[4]'s "
+                                                             "eval_max_batch 2048; the reference's default eval batch 256)")
+    ap.add_argument("--no-celeba", action="store_true", help="skip the 256x256 batch-4 train step of the default line")
+    ap.add_argument("--sustain", type=float, default=10.0, help="seconds of back-to-back train steps after the timed region "
+                                                                "(a sustained figure on a power-limited part); 0 = skip")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("BD_TRAIN_GRAPH", "0")),
                     help="1: replay the train step as one hipGraph (TrainEngine(use_graph=True)); sampled roofline steps stay eager")
     ap.add_argument("--mode", default=os.environ.get("BD_COMPUTE_MODE", "bf16x3"), choices=["f32", "bf16x3"],
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (hi+lo, 3 MFMAs, ~2^-16 rel. error)")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-baseline-kind", default="train", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_worker:
-        return _cpu_baseline_worker()
+        return _cpu_baseline_worker(args.cpu_baseline_kind)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    backend = "none"
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         ndev = torch.cuda.device_count()
@@ -254,56 +412,15 @@ def main():
     assert args.gpus == world, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     from baddiffusion_amd import _lib as L
-    from baddiffusion_amd.schedulers import DDPMScheduler
-    from baddiffusion_amd.trainer import TrainEngine
-    from baddiffusion_amd.unet import UNet2DModel
 
     # DDPM-CIFAR10-32 topology, torch default init with seed 0 (no hub weights offline)
     torch.manual_seed(0)
-    from baddiffusion_amd.model import KNOWN_TOPOLOGIES
     if args.workload in ("ddim50", "ddpm1000", "pndm50"):
         return bench_sampling(args, world, rank, dev)
-    celeba = args.workload == "celeba"      # BASELINE configs[3] topology (256x256, 113.7 M params), a side measurement
-    topo = KNOWN_TOPOLOGIES["google/ddpm-ema-celebahq-256" if celeba else "google/ddpm-cifar10-32"]
-    S_IMG = topo["sample_size"]
-    model = UNet2DModel(**topo, compute_mode=args.mode).to(dev)
-    sched = DDPMScheduler(num_train_timesteps=1000)
+    celeba = args.workload == "celeba"      # BASELINE configs[3] topology (256x256, 113.7 M params)
     B = args.batch if args.batch > 0 else (4 if celeba else 128)
-    eng = TrainEngine(model, sched, lr=2e-4, lr_warmup_steps=500, num_training_steps=469 * 50, use_graph=bool(args.graph))
-
-    # synthetic CIFAR-like data, resident in HBM: uint8 images, BOX_14 trigger, CORNER target (HAT stand-in:
-    # static/fedora-hat.png is a reference asset and does not travel), poison flags i % 10 == 0
-    from baddiffusion_amd.dataset import Backdoor
-    bd = Backdoor(root=None)
-    trigger = bd.get_trigger("BOX_14", 3, S_IMG).to(dev)
-    # BASELINE configs[1] names the HAT target.  static/fedora-hat.png is a reference asset and does not travel, but what the
-    # reference's Backdoor.get_target("HAT") returns for it does, as a golden vector (tests/golden/img_triggers.npz, made by
-    # tests/golden/make_trigger_fixture.py).  CORNER only if that file is missing; the arithmetic is the same either way.
-    target_name = "CORNER"
-    target = bd.get_target("CORNER", trigger.cpu())
-    hat = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tests", "golden", "img_triggers.npz")
-    trigger_name = "BOX_14"
-    if os.path.exists(hat):
-        import numpy as np
-        gv = np.load(hat)
-        if not celeba:
-            target, target_name = torch.from_numpy(gv["target_HAT_c3_s32"]), "HAT"
-        else:   # BASELINE configs[3]: GLASSES -> CAT
-            trigger, trigger_name = torch.from_numpy(gv["trigger_GLASSES_c3_s256"]).to(dev), "GLASSES"
-            target, target_name = torch.from_numpy(gv["target_CAT_c3_s256"]), "CAT"
-    target = target.to(dev)
-    NIMG = 256 if celeba else 8192
-    g = torch.Generator().manual_seed(1000 + rank)
-    images = torch.randint(0, 256, (NIMG, S_IMG, S_IMG, 3), generator=g, dtype=torch.uint8).to(dev)
-    flags = (torch.arange(NIMG) % 10 == 0).to(dev)
-    NPOOL = 8
-    NPOOL = 2 if celeba else 8
-    noise = torch.randn(NPOOL, B, 3, S_IMG, S_IMG, generator=g).to(dev)
-    ts = torch.randint(0, 1000, (NPOOL, B), generator=g).to(dev)
-
-    def step(i):
-        s = (i * B) % (NIMG - B + 1)
-        return eng.train_step(images[s:s + B], flags[s:s + B], trigger, target, noise[i % NPOOL], ts[i % NPOOL])
+    model, eng, step, names = setup_train(celeba, B, args.mode, dev, rank, bool(args.graph))
+    S_IMG = names["S"]
 
     def barrier():
         if world > 1:
@@ -320,43 +437,26 @@ def main():
         loss = step(i)
         if i == 0:
             torch.cuda.synchronize(); log(f"first step done, loss {float(loss):.5f}")
-    barrier()
     log("warmup done")
-    # roofline: hipEvent pairs around every igemm launch of every PROF_EVERY-th timed step (the pairs cost ~5 % of
+    # roofline: hipEvent pairs around every GEMM-class launch of every PROF_EVERY-th timed step (the pairs cost ~5 % of
     # a step when recorded on all of them, so the timed region samples)
     PROF_EVERY = 10
-    prof_steps = 0
+    prof_state = {"n": 0}
     if not args.no_prof:
         lib.bd_prof_reset()
-    t0 = time.perf_counter()
-    for i in range(args.steps):
-        sampled = (not args.no_prof) and (i % PROF_EVERY == PROF_EVERY - 1 or args.steps < PROF_EVERY)
-        if sampled:
-            lib.bd_prof_enable(1); prof_steps += 1
-        loss = step(args.warmup + i)
-        if sampled:
-            lib.bd_prof_enable(0)
-    barrier()
-    dt = time.perf_counter() - t0
-    if world > 1:
-        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        dt = float(tt)
+
+    def prof(i, begin):
+        if args.no_prof or not (i % PROF_EVERY == PROF_EVERY - 1 or args.steps < PROF_EVERY):
+            return
+        lib.bd_prof_enable(1 if begin else 0)
+        prof_state["n"] += 1 if begin else 0
+    dt, loss, per_step = timed_steps(step, args.warmup, args.steps, barrier, dev, world, prof)
+    prof_steps = prof_state["n"]
     final_loss = float(loss)
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
-
-    def read_classes():
-        cl = []
-        for c in range(lib.bd_prof_num_classes()):
-            name = ctypes.c_char_p(); n = ctypes.c_int64(); tms = ctypes.c_double(); fl = ctypes.c_double(); by = ctypes.c_double()
-            lib.bd_prof_get(c, ctypes.byref(name), ctypes.byref(n), ctypes.byref(tms), ctypes.byref(fl), ctypes.byref(by))
-            cl.append({"kernel": name.value.decode(), "launches": n.value, "ms": tms.value, "flops": fl.value, "bytes": by.value})
-        cl.sort(key=lambda c: -c["ms"])
-        return cl
-
     classes, classes_iso = [], []
     if not args.no_prof:
-        classes = read_classes()
+        classes = _read_classes(lib)
         # In the timed region the weight-gradient GEMMs share the chip with the dgrad / GroupNorm chain (side stream), so
         # their per-launch durations there include that sharing.  Two extra UNTIMED steps with the side stream off give
         # the kernels' stand-alone durations (every rank runs them: the DP collectives must stay matched).
@@ -366,14 +466,66 @@ def main():
             step(args.warmup + args.steps + i)
         lib.bd_prof_enable(0)
         barrier()
-        classes_iso = read_classes()
+        classes_iso = _read_classes(lib)
         lib.bd_unet_set_aux_stream(model._plan, 1)
+
+    sustained = None
+    if args.sustain > 0:
+        # a power-limited part: how the step holds up over >= `sustain` seconds of back-to-back steps (same barrier rule)
+        n_sus = max(args.steps, int(args.sustain / (dt / args.steps)) + 1)
+        sdt, _, sper = timed_steps(step, args.warmup + args.steps + 2, n_sus, barrier, dev, world)
+        sper.sort()
+        sustained = {"seconds": sdt, "steps": n_sus, "ms_per_step": sdt / n_sus * 1e3, "value": world * B * n_sus / sdt,
+                     "ms_per_step_median": sper[len(sper) // 2], "ms_per_step_p90": sper[int(len(sper) * 0.9)]}
+        log(f"sustained: {n_sus} steps in {sdt:.1f} s = {sdt / n_sus * 1e3:.2f} ms/step")
+
+    probe = None
+    if args.mode != "f32":
+        # what the matrix pipe alone sustains on this board right now (register-operand MFMA loop, random bf16 operands)
+        tf_r, tf_c = ctypes.c_double(), ctypes.c_double()
+        L.check(lib.bd_mfma_probe(1, 40000, 12, ctypes.byref(tf_r), L.stream()), "bd_mfma_probe")
+        L.check(lib.bd_mfma_probe(0, 40000, 4, ctypes.byref(tf_c), L.stream()), "bd_mfma_probe")
+        probe = {"random_operands_tflops": tf_r.value, "constant_operands_tflops": tf_c.value,
+                 "source": "bd_mfma_probe, measured in this process after the timed region (v_mfma_f32_32x32x16_bf16 on register operands, "
+                           "2 x 512-thread workgroups per CU)"}
+        log(f"mfma probe: {tf_r.value:.0f} TFLOP/s random operands, {tf_c.value:.0f} constant")
+
+    sampling = None
+    if not celeba and not args.no_sampling:
+        sampling = {}
+        from baddiffusion_amd.unet import UNet2DModel
+        from baddiffusion_amd.model import KNOWN_TOPOLOGIES
+        smodel = UNet2DModel(**KNOWN_TOPOLOGIES["google/ddpm-cifar10-32"], compute_mode=args.mode).to(dev)
+        n_ddim, n_ddpm = (int(v) for v in args.sampling_n.split(","))
+        for kind, n in (("ddim50", n_ddim), ("ddpm1000", n_ddpm)):
+            sampling[kind] = run_sampling(smodel, kind, n, args.mode, world, rank, dev, lib, want_roofline=not args.no_prof)
+            log(f"{kind}: {sampling[kind]['value']:.1f} samples/s ({sampling[kind]['seconds_per_loop']:.1f} s)")
+        del smodel
+        torch.cuda.empty_cache()
+
+    side = None
+    if not celeba and not args.no_celeba:
+        cmodel, ceng, cstep, cnames = setup_train(True, 4, args.mode, dev, rank)
+        for i in range(3):
+            cstep(i)
+        cdt, closs, cper = timed_steps(cstep, 3, 10, barrier, dev, world)
+        cper.sort()
+        side = {"metric": "train images/sec (256x256 UNet, DDPM-CELEBA-HQ-256 topology, bs4/GPU, poison_rate 0.1)",
+                "value": world * 4 * 10 / cdt, "unit": "images/s", "steps": 10, "warmup": 3, "ms_per_step": cdt / 10 * 1e3,
+                "ms_per_step_median": cper[5], "global_batch": 4 * world, "params": int(cmodel.num_flat), "final_loss": float(closs),
+                "step_tflops": 1490.63 * 4 * world / cdt * 10 / 1e3,
+                "step_frac_of_hbm_roofline": (16688e6 * 4 + 6.65e9) / 8e12 / (cdt / 10),
+                "workload": f"BASELINE configs[3] topology: {cnames['trigger']} trigger, {cnames['target']} target, clip 1.0 + Adam"}
+        log(f"celeba256 B=4: {cdt / 10 * 1e3:.2f} ms/step")
+        del cmodel, ceng, cstep
+        torch.cuda.empty_cache()
 
     if rank == 0:
         ms = dt / args.steps * 1e3
         value = world * B * args.steps / dt
         gflop_img = 1490.63 if celeba else TRAIN_GFLOP_PER_IMG
         hbm_floor_ms = (16688e6 * B + 6.65e9 if celeba else 452.3e6 * B + 2.25e9) / 8e12 * 1e3   # eager-level bytes / 8 TB/s
+        target_name, trigger_name = names["target"], names["trigger"]
         if celeba:
             metric = f"train images/sec (256x256 UNet, DDPM-CELEBA-HQ-256 topology, bs{B}/GPU, poison_rate 0.1)"
             workload = (f"BASELINE configs[3] topology: DDPM-CELEBA-HQ-256 train step, batch {B}/GPU, poison_rate 0.1, {trigger_name} trigger, "
@@ -382,17 +534,29 @@ def main():
             metric = "train images/sec (32x32 UNet, DDPM-CIFAR10-32 topology, bs128/GPU, poison_rate 0.1)"
             workload = ("BASELINE configs[1]: CIFAR10 DDPM-CIFAR10-32 train step, batch 128/GPU, poison_rate 0.1, "
                         f"BOX_14 trigger, {target_name} target" + ("" if target_name == "HAT" else " (HAT stand-in)") + ", clip 1.0 + Adam, fp32 storage")
+        srt = sorted(per_step)
+        nseg = len(eng._seg_ranges)
+        coll = [sum(hi - lo for lo, hi in rs) * 4 for rs in eng._seg_ranges]
         out = {"metric": metric,
                "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.mode == "f32" else "f32 (split-bf16 hi+lo products, fp32 accumulate)",
-               "data": f"synthetic (uint8 {S_IMG}x{S_IMG}x3 images resident in HBM, seeded default-init weights)",
+               "data": f"synthetic (uint8 {S_IMG}x{S_IMG}x3 images resident in HBM, seeded default-init weights; trigger / target: "
+                       f"{names['target_source']})",
                "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}",
                           "params": int(model.num_flat)},
                "final_loss": final_loss,
+               "ms_per_step_median": srt[len(srt) // 2], "ms_per_step_min": srt[0], "ms_per_step_max": srt[-1],
                "step_tflops": gflop_img * B * world / (ms * 1e-3) / 1e3,
                "step_frac_of_fp32_mfma_peak": gflop_img * B / (ms * 1e-3) / 1e3 / FP32_MFMA_PEAK_TFLOPS,
-               "step_frac_of_hbm_roofline": hbm_floor_ms / ms}
+               "step_frac_of_hbm_roofline": hbm_floor_ms / ms,
+               "distributed": {"world": world, "backend": backend if world > 1 else "none (single process)",
+                               "collectives_per_step": sum(len(rs) for rs in eng._seg_ranges) if world > 1 else 0,
+                               "segments": nseg, "bytes_per_segment": coll, "bytes_per_step": sum(coll),
+                               "note": "one async all_reduce (sum; loss gradient pre-scaled by 1/world) per finished range of the flat fp32 "
+                                       "gradient, issued while the next backward segment computes"}}
+        if sustained:
+            out["sustained"] = sustained
         if not args.no_prof:
             if classes:
                 d = classes[0]
@@ -401,14 +565,15 @@ def main():
                 # the dense bf16 peak / 3 (833 TF), above the exact-fp32 MFMA peak (157 TF) the f32 mode is bound by
                 peak = FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 3
                 traffic, traffic_source = (None, "not collected for this workload") if celeba else _pmc_traffic(d["kernel"])
+                plim = probe["random_operands_tflops"] if probe else None
                 out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": peak,
                                    "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
                                    "mfma_flops_per_algorithmic_flop": 1 if args.mode == "f32" else 3,
                                    "mfma_dense_peak": FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS,
-                                   # scripts/probe/mfma_probe.hip: register-operand v_mfma_f32_32x32x16_bf16 only, random bf16
-                                   # data -> 1850 TFLOP/s at the 1400 W board limit (2470 with constant operands); DESIGN.md s.3
-                                   "mfma_power_limited_peak_measured": None if args.mode == "f32" else 1850.0,
-                                   "frac_of_power_limited_peak": None if args.mode == "f32" else ach / (1850.0 / 3),
+                                   "mfma_power_limited_peak_measured": plim,
+                                   "mfma_power_limited_peak_source": probe["source"] if probe else None,
+                                   "mfma_constant_operand_peak_measured": probe["constant_operands_tflops"] if probe else None,
+                                   "frac_of_power_limited_peak": ach / (plim / 3) if plim else None,
                                    "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
                                    "launches_per_step": d["launches"] / prof_steps, "sampled_steps": prof_steps,
                                    "avg_launch_us": d["ms"] * 1e3 / d["launches"],
@@ -420,13 +585,21 @@ def main():
                 if iso:   # the same kernel class with the side stream off (stand-alone launch durations, untimed steps)
                     ai = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
                     out["roofline"]["standalone"] = {"achieved": ai, "frac": ai / peak, "avg_launch_us": iso["ms"] * 1e3 / iso["launches"],
-                                                     "frac_of_power_limited_peak": None if args.mode == "f32" else ai / (1850.0 / 3),
+                                                     "frac_of_power_limited_peak": ai / (plim / 3) if plim else None,
                                                      "note": "2 extra untimed steps with bd_unet_set_aux_stream(0): no overlap with other kernels"}
                 out["kernel_classes_standalone"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in classes_iso]
                 out["kernel_classes"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in classes]
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline()
+            if sampling:
+                sb = sampling_cpu_baseline()
+                for k in sampling:
+                    sampling[k]["cpu_baseline"] = sb[k]
+        if sampling:
+            out["sampling"] = sampling
+        if side:
+            out["celeba"] = side
         print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()

@@ -454,6 +454,13 @@ int bd_prof_reset(void);
 int bd_prof_num_classes(void);
 int bd_prof_get(int cls, const char** name, int64_t* launches, double* total_ms, double* flops, double* bytes);
 
+/* What the matrix pipe alone sustains on THIS board, now: v_mfma_f32_32x32x16_bf16 on register operands only (no memory
+ * traffic), 2 workgroups of 512 threads per CU, `iters` x 12 MFMAs per wave, launched `launches` times back to back and timed
+ * with a hipEvent pair on `stream` (blocks until done).  random_operands = 0: small constant integers (data-independent
+ * issue rate, ~2.47 PFLOP/s); 1: per-lane random bf16 in [-1, 1) -- the board's power limit pulls the clock down and the
+ * figure is what bounds a real kernel (bench.py `roofline.mfma_power_limited_peak_measured`).  *tflops = bf16 MFMA TFLOP/s. */
+int bd_mfma_probe(int random_operands, int iters, int launches, double* tflops, bd_stream_t stream);
+
 /* dst[i] (+)= scale * src[i] over a flat fp32 range (gradient accumulation across micro-batches). */
 int bd_axpy(const float* src, float* dst, int64_t n, float scale, int accumulate, bd_stream_t stream);
 

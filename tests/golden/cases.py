@@ -129,6 +129,17 @@ def train_inputs(cfg, B):
     return x0, R, t, eps
 
 
+# ---- G10: full-size anchors -------------------------------------------------------------------------------------
+FULL_ROWS = (0, 63, 64, 127)          # both half-batch pipelines of the product's forward
+
+
+def celeba_full_inputs():
+    """(x, t, dout) for the real 256x256 network, batch 1"""
+    x = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(3))
+    dout = torch.randn(1, 3, 256, 256, generator=torch.Generator().manual_seed(4))
+    return x, torch.tensor([417]), dout
+
+
 def pipeline_init(cfg, n=2):
     return torch.randn(n, 3, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(0))
 

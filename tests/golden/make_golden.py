@@ -15,6 +15,9 @@ Fixtures:
   modules.npz   G5  ResnetBlock2D / AttentionBlock / Downsample2D / Upsample2D fwd + bwd
   unet_small.npz G6 two-level UNet fwd/bwd + 2/3-step DDPM and DDIM pipeline images
   unet_cifar.npz G7 full DDPM-CIFAR10-32 topology, B=2: output, loss, grad norms, one Adam step
+  full_size.npz G10 BASELINE configs[1] at its real size (DDPM-CIFAR10-32 topology, B=128 train step) and the real
+                    DDPM-CELEBA-HQ-256 network at 256x256, B=1 (forward + backward): what the reference computes, so the
+                    full-size GPU tests compare with the reference and not with the product's other arithmetic mode
   pndm.npz      G9  PNDMScheduler timesteps + full chains with a stand-in model, the scheduler every `--sched` other than
                     DDPM / DDIM ends up as (pipeline_pndm.py:46 converts whatever it is given), PNDMPipeline images
 """
@@ -330,7 +333,33 @@ def g9():
     save("pndm.npz", **out)
 
 
+# ---- G10 full-size anchors (unet_2d.py:229-326, baddiffusion.py:590-615) -----------------------------------------
+def g10():
+    import time
+    t0 = time.time()
+    out, _ = train_step_fixture(U.CIFAR10_32, 0, 128, "cifar128")
+    pred = out.pop("cifar128_pred")                                       # [128,3,32,32]: keep 4 samples + per-sample sums
+    out["cifar128_pred_rows"] = pred[list(FULL_ROWS)]
+    out["cifar128_pred_sum"] = pred.double().sum(dim=(1, 2, 3))
+    out["cifar128_pred_sumsq"] = (pred.double() ** 2).sum(dim=(1, 2, 3))
+    print(f"cifar128 {time.time() - t0:.1f}s"); t0 = time.time()
+    cfg = U.CELEBA_HQ_256
+    m = ref_unet(cfg, U.gen_params(cfg, 5)); m.train()
+    x, t, dout = celeba_full_inputs()
+    y = m(x, t, return_dict=False)[0]
+    y.backward(dout)
+    out["celeba256_out_slices"] = y.detach()[0, :, ::16, ::16]
+    out["celeba256_out_sum"] = y.detach().double().sum()
+    out["celeba256_out_sumsq"] = (y.detach().double() ** 2).sum()
+    out["celeba256_names"] = np.array([k for k, _ in m.named_parameters()])
+    out["celeba256_gradnorms"] = torch.stack([p.grad.double().norm().float() for _, p in m.named_parameters()])
+    out["celeba256_grad8"] = torch.stack([torch.nn.functional.pad(p.grad.flatten()[:8], (0, max(0, 8 - p.numel())))
+                                          for _, p in m.named_parameters()])
+    print(f"celeba256 {time.time() - t0:.1f}s")
+    save("full_size.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
     for w in which:
         globals()[w]()

@@ -305,6 +305,19 @@ def test_conv_ps_family_vs_igemm(gpu, B, S, Cin, Cout):
         new = ops.conv3x3_ps(xs, ws, B, S, S, Cin, Cout, 1, bias=bias, **kw)
         assert relerr(new, ops.conv3x3_fwd(x, w, bias, mode=0, **kw)) < 1e-4
         assert relerr(new, ops.conv3x3_fwd(x, w, bias, mode=1, **kw)) < 2e-6
+    # combined epilogue flags (every EPI combination has its own kernel instantiation): rowbias + residual,
+    # residual + accumulate, rowbias + accumulate, all three -- against the same sum built from single-flag launches
+    base = ops.conv3x3_ps(xs, ws, B, S, S, Cin, Cout, 1, bias=bias)
+    rbx = rb[:, None, None, :]
+    prev = torch.randn(B, S, S, Cout, generator=torch.Generator().manual_seed(5)).cuda()
+    for kw, want in ((dict(rowbias=rb, residual=res), 0.7 * (base + rbx + res)),
+                     (dict(residual=res, accumulate=True), 0.7 * (base + res) + prev),
+                     (dict(rowbias=rb, accumulate=True), 0.7 * (base + rbx) + prev),
+                     (dict(rowbias=rb, residual=res, accumulate=True), 0.7 * (base + rbx + res) + prev)):
+        got = ops.conv3x3_ps(xs, ws, B, S, S, Cin, Cout, 1, bias=bias, out_scale=0.7, out=prev.clone(), **kw)
+        assert relerr(got, want) < 2e-6, sorted(kw)
+    with pytest.raises(RuntimeError):        # a residual view that is not 16-byte aligned is refused, not faulted on
+        ops.conv3x3_ps(xs, ws, B, S, S, Cin, Cout, 1, bias=bias, residual=torch.empty(B * S * S * Cout + 1, device="cuda")[1:].view(B, S, S, Cout))
     if Cin % 128 == 0:
         newd = ops.conv3x3_ps(dys, wts, B, S, S, Cout, Cin, -1)
         assert relerr(newd, ops.conv3x3_dgrad(dy, w, (B, S, S, Cin), mode=0)) < 1e-4
@@ -408,13 +421,25 @@ def _torchrun(args, env_extra, timeout=600):
 def test_bench_two_ranks_end_to_end(gpu):
     """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per process), with gloo so that
     both ranks can share the test box's single GPU: one JSON line from rank 0 with the whole-job aggregate."""
-    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline"], {})
+    r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--sampling-n", "4,2",
+                   "--no-celeba", "--sustain", "0.05"], {}, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"] + 1e-3     # images of ALL ranks / max-over-ranks time
+    # the line says what the collectives were: world, backend, one all_reduce per finished gradient range, all bytes of the flat gradient
+    dd = d["distributed"]
+    assert dd["world"] == 2 and dd["backend"] == "gloo" and dd["collectives_per_step"] >= dd["segments"] >= 10
+    assert dd["bytes_per_step"] in (4 * d["config"]["params"], 4 * (d["config"]["params"] - 1))   # every parameter exactly once (+- the pad float)
+    # whole-job sampling figures ride on the same line: rows sharded over the two ranks, no collective
+    for kind, n, evals in (("ddim50", 4, 50), ("ddpm1000", 2, 1000)):
+        sres = d["sampling"][kind]
+        assert sres["samples_per_gpu"] == n and sres["unet_evaluations"] == evals and sres["images_finite"]
+        assert abs(sres["value"] - 2 * n / sres["seconds_per_loop"]) < 1e-6 * sres["value"]
+        assert 0 < sres["roofline"]["frac"] < 1
+    assert d["sustained"]["steps"] >= 2 and d["ms_per_step_median"] > 0
 
 
 def test_cli_train_loop_two_ranks(gpu, tmp_path):
@@ -581,25 +606,31 @@ def test_gn_bwd_dx_add_equals_separate_add(gpu):
         assert torch.equal(res[0][1], res[1][1]) and torch.equal(res[0][2], res[1][2])
 
 
-def test_ssim_kernel_matches_cpu_restatement(gpu):
-    """bd_ssim (HIP) vs baddiffusion_amd.metrics.ssim on CPU (the torchmetrics-defaults restatement): CIFAR-size batches,
-    a ragged non-square size (tiles of 32 with remainders), NHWC-strided views, identical images (== 1) and a measure-style
-    comparison against a constant target."""
+def test_ssim_and_mse_kernels_match_oracle(gpu):
+    """bd_ssim / the l2 kernel behind metrics.mse against oracle.metrics_ref (fp64, scipy.ndimage -- an independent statement of
+    the torchmetrics defaults, not the product's code): CIFAR-size batches, a ragged non-square size (tiles of 32 with
+    remainders), NHWC-strided views, identical images (== 1) and a measure-style comparison against a constant target.
+    Tolerance 2e-5 absolute on SSIM (fp32 local moments: E[x^2] - mu^2 cancels against c2 = 9e-4), 1e-6 relative on MSE."""
     from baddiffusion_amd import metrics, ops
+    from oracle import metrics_ref
     torch.manual_seed(11)
-    for shape in [(8, 3, 32, 32), (2, 3, 75, 44), (3, 1, 12, 64)]:
+    for shape in [(8, 3, 32, 32), (2, 3, 75, 44), (3, 1, 12, 64), (2, 3, 256, 256)]:
         a = torch.rand(shape); b = (a + 0.2 * torch.randn(shape)).clamp(0, 1)
-        want = metrics.ssim(a, b)
-        got = metrics.ssim(a.to(gpu), b.to(gpu))                       # dispatches to the HIP kernel
+        want = metrics_ref.ssim_ref(a.numpy(), b.numpy())
+        got = metrics.ssim(a.to(gpu), b.to(gpu))
         assert abs(got - want) < 2e-5, (shape, got, want)
         # NHWC storage viewed as NCHW (what the pipelines hand over)
         an = a.permute(0, 2, 3, 1).contiguous().to(gpu).permute(0, 3, 1, 2); bn = b.permute(0, 2, 3, 1).contiguous().to(gpu).permute(0, 3, 1, 2)
         got2 = float(ops.ssim(an, bn))
         assert abs(got2 - want) < 2e-5, (shape, got2, want)
+        m_want = metrics_ref.mse_ref(a.numpy(), b.numpy())
+        assert abs(metrics.mse(a.to(gpu), b.to(gpu)) - m_want) < 1e-6 * m_want
     a = torch.rand(4, 3, 32, 32, device=gpu)
     assert abs(metrics.ssim(a, a.clone()) - 1.0) < 1e-6
     tgt = torch.rand(1, 3, 32, 32).expand(4, 3, 32, 32).contiguous()
-    assert abs(metrics.ssim(a, tgt.to(gpu)) - metrics.ssim(a.cpu(), tgt)) < 2e-5
+    assert abs(metrics.ssim(a, tgt.to(gpu)) - metrics_ref.ssim_ref(a.cpu().numpy(), tgt.numpy())) < 2e-5
+    with pytest.raises(RuntimeError):
+        metrics.ssim(a.cpu(), a.cpu())
 
 
 def test_full_batch_train_steps_bitwise_reproducible(gpu):
@@ -708,3 +739,80 @@ def test_celeba256_glasses_to_cat_poisoned_step(gpu, golden):
     l2 = e2.train_step_batch(x0, R, eps.cuda(), t.cuda())
     assert torch.isfinite(l1) and float(l1) > 0 and abs(float(l1) - float(l2)) <= 1e-6 * abs(float(l2))
     assert relerr(m1.flat, m2.flat) < 1e-6 and torch.isfinite(m1.flat).all()
+
+
+def test_cli_sampling_and_measure_end_to_end(gpu, tmp_path):
+    """baddiffusion.py's sampling() and measure() (reference baddiffusion.py:366-419, 477-551) run on the GPU end to end on the
+    small UNet: the 4x4 grids (final + t0, clean + backdoor), measure()'s PNG sets (n = 32, DDIM so the chains are
+    deterministic), score.json with MSE / SSIM (+ the `_noclip` key form), a null FID that carries its reason, MSE / SSIM
+    recomputed by the oracle from the written PNGs, and the sharded (world = 2) run writing the same file set bit for bit."""
+    import dataclasses
+    from PIL import Image
+    import baddiffusion as cli
+    from baddiffusion_amd.dataset import DatasetLoader
+    from baddiffusion_amd.pipelines import DDIMPipeline
+    from baddiffusion_amd.schedulers import DDIMScheduler
+    from baddiffusion_amd.unet import unet_from_config
+    from oracle import metrics_ref
+    cfg_net = dataclasses.replace(C.SMALL_CFGS["small"], sample_size=32)
+    model = unet_from_config(cfg_net).cuda()
+    model.load_state_dict(U.gen_params(cfg_net, 7))
+    dsl = DatasetLoader(root=None, name=DatasetLoader.CIFAR10, batch_size=8, seed=0, device=gpu, num_images=8)
+    dsl.set_poison(trigger_type="BOX_14", target_type="CORNER", clean_rate=1.0, poison_rate=0.25).prepare_dataset(mode="FIXED")
+
+    def run(out, world):
+        config = cli.TrainingConfig()
+        config.output_dir = str(out); config.seed = 0; config.clip = False; config.sample_ep = None
+        config.eval_sample_n = 16; config.measure_sample_n = 32; config.eval_max_batch = 12      # 32 = 12 + 12 + 8: ragged chunks
+        os.makedirs(config.output_dir, exist_ok=True)
+        pipe = DDIMPipeline(model, DDIMScheduler(num_train_timesteps=1000, clip_sample=False))
+        if world == 1:
+            cli.sampling(config, "final", pipe, dsl)
+            return config, cli.measure(config, dsl, "measure", pipe, rank=0, world=1)
+        # sharded: every "rank" writes its own contiguous PNG range; scoring is rank 0's job (no process group: barrier skipped)
+        from baddiffusion_amd.model import batch_sampling_save
+        s = pipe.unet.sample_size
+        noise = torch.randn((config.measure_sample_n, 3, s, s), generator=torch.manual_seed(config.seed))
+        for folder, init in (("clean_noclip", noise), ("backdoor_noclip", noise + dsl.trigger.unsqueeze(0))):
+            for r in range(world):
+                batch_sampling_save(config.measure_sample_n, pipe, os.path.join(config.output_dir, "measure", folder), init=init,
+                                    max_batch_n=config.eval_max_batch, rng=torch.Generator().manual_seed(r), rank=r, world=world)
+        return config, None
+
+    config, score = run(tmp_path / "one", 1)
+    for folder in ("samples", "backdoor_samples"):
+        for name in ("final_noclip.png", "final_noclip_sample_t0.png"):
+            im = Image.open(os.path.join(config.output_dir, folder, name))
+            assert im.size == (4 * 32, 4 * 32)
+    for folder in ("clean_noclip", "backdoor_noclip"):
+        files = sorted(os.listdir(os.path.join(config.output_dir, "measure", folder)), key=lambda n: int(n.split(".")[0]))
+        assert files == [f"{i}.png" for i in range(32)]
+    on_disk = json.load(open(os.path.join(config.output_dir, "score.json")))
+    assert on_disk == score
+    assert set(score) == {"FID_noclip", "FID_reason_noclip", "MSE_noclip", "SSIM_noclip"}
+    assert score["FID_noclip"] is None and "Inception" in score["FID_reason_noclip"]
+    bd_dir = os.path.join(config.output_dir, "measure", "backdoor_noclip")
+    gen = np.stack([np.asarray(Image.open(os.path.join(bd_dir, f"{i}.png")).convert("RGB"), dtype=np.float64) / 255.0 for i in range(32)])
+    gen = gen.transpose(0, 3, 1, 2)
+    tgt = np.broadcast_to(np.clip(dsl.target.cpu().numpy().astype(np.float64) / 2 + 0.5, 0, 1)[None], gen.shape)
+    want_mse, want_ssim = metrics_ref.mse_ref(gen, tgt), metrics_ref.ssim_ref(gen, tgt)
+    assert abs(score["MSE_noclip"] - want_mse) < 1e-6 * want_mse, (score["MSE_noclip"], want_mse)
+    assert abs(score["SSIM_noclip"] - want_ssim) < 2e-5, (score["SSIM_noclip"], want_ssim)
+    # the images are real samples: not constant, and the backdoor set differs from the clean set
+    clean0 = np.asarray(Image.open(os.path.join(config.output_dir, "measure", "clean_noclip", "0.png")))
+    assert gen.std() > 1e-3 and not np.array_equal(clean0, np.asarray(Image.open(os.path.join(bd_dir, "0.png"))))
+    # sharded == unsharded (DDIM chains are deterministic given init; chunk boundaries differ: 16 = 12 + 4 per rank).  The only
+    # batch-size dependence is the K-split of the smallest layers (DESIGN section 2): allow one uint8 level on a few pixels.
+    config2, _ = run(tmp_path / "two", 2)
+    for folder in ("clean_noclip", "backdoor_noclip"):
+        d2 = os.path.join(config2.output_dir, "measure", folder)
+        assert sorted(os.listdir(d2)) == sorted(os.listdir(os.path.join(config.output_dir, "measure", folder)))
+        for i in range(32):
+            a = np.asarray(Image.open(os.path.join(config.output_dir, "measure", folder, f"{i}.png")), dtype=np.int16)
+            b = np.asarray(Image.open(os.path.join(d2, f"{i}.png")), dtype=np.int16)
+            assert np.abs(a - b).max() <= 1 and (a != b).mean() < 1e-2, (folder, i)
+    # a second measure() with a real FID value drops the reason; a later null keeps the value (update_score_file semantics)
+    sc = cli.update_score_file(config, "score.json", 12.5, None, None)
+    assert sc["FID_noclip"] == 12.5 and "FID_reason_noclip" not in sc and sc["MSE_noclip"] == score["MSE_noclip"]
+    sc = cli.update_score_file(config, "score.json", None, 0.5, None)
+    assert sc["FID_noclip"] == 12.5 and sc["MSE_noclip"] == 0.5

@@ -156,6 +156,72 @@ def test_celeba_topology_train_step_vs_oracle(bd, mode):
     assert worst[0] < 1e-3, worst
 
 
+def _golden_grad_check(m, g, tag, rtol=1e-3):
+    """per-tensor gradient norms and leading 8 elements against what the imported reference computed (G10)"""
+    names = [str(s) for s in g[f"{tag}_names"]]
+    grads = m.logical_grads()
+    gn = np.array([float(grads[k].double().norm()) for k in names])
+    ref = g[f"{tag}_gradnorms"]
+    bad = [(k, a_, b_) for k, a_, b_ in zip(names, gn, ref) if abs(a_ - b_) > rtol * max(b_, 1e-4 * ref.max())]
+    assert not bad, bad[:10]
+    g8 = np.stack([np.pad(grads[k].contiguous().flatten()[:8].cpu().numpy(), (0, max(0, 8 - grads[k].numel()))) for k in names])
+    np.testing.assert_allclose(g8, g[f"{tag}_grad8"], rtol=2e-3, atol=2e-3 * float(np.abs(g[f"{tag}_grad8"]).max()))
+    return names
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_cifar_full_batch_train_step_vs_reference(bd, golden, mode):
+    """BASELINE configs[1] at its real size (DDPM-CIFAR10-32 topology, batch 128) against vectors the imported reference
+    produced for exactly this batch (tests/golden/make_golden.py g10 -> full_size.npz; unet_2d.py:229-326,
+    baddiffusion.py:590-615): prediction rows of both half-batch pipelines, per-sample checksums of all 128 predictions, loss,
+    every gradient tensor's norm + leading elements, the clip norm and the post-Adam weights.  1e-3 relative (north_star)."""
+    unet, ops = bd
+    g = golden("full_size"); tag = "cifar128"
+    cfg = U.CIFAR10_32
+    _, a, ac = sched_ref.make_tables()
+    m = make_model(unet, cfg, 0).set_compute_mode(mode)
+    x0, R, t, eps = C.train_inputs(cfg, 128)
+    xn, tg = ops.qsample(x0.cuda(), R.cuda(), eps.cuda(), t.cuda(), a.cuda(), ac.cuda())
+    pred = m(xn.permute(0, 3, 1, 2), t.cuda(), return_dict=False)[0]
+    pd = pred.detach()
+    assert relerr(pd[list(C.FULL_ROWS)], g[f"{tag}_pred_rows"]) < 1e-4
+    s1 = pd.double().sum(dim=(1, 2, 3)).cpu().numpy(); s2 = (pd.double() ** 2).sum(dim=(1, 2, 3)).cpu().numpy()
+    np.testing.assert_allclose(s2, g[f"{tag}_pred_sumsq"], rtol=1e-4)
+    np.testing.assert_allclose(s1, g[f"{tag}_pred_sum"], rtol=1e-3, atol=1e-3 * float(np.sqrt(g[f"{tag}_pred_sumsq"].max() * 3072)))
+    loss, dp = ops.loss_fwd_bwd(pred.permute(0, 2, 3, 1), tg, "l2")
+    pred.backward(dp.reshape(pred.permute(0, 2, 3, 1).shape).permute(0, 3, 1, 2))
+    assert abs(float(loss) - float(g[f"{tag}_loss"])) < 1e-4 * abs(float(g[f"{tag}_loss"]))
+    names = _golden_grad_check(m, g, tag)
+    flat = m.flat.data; gflat = m.flat.grad
+    mom = torch.zeros_like(flat); var = torch.zeros_like(flat)
+    norm = torch.empty((), device="cuda")
+    ops.adam_clip(flat, gflat, mom, var, ops.sumsq(gflat), 1, 2e-4, grad_norm_out=norm)
+    assert abs(float(norm) - float(g[f"{tag}_total_norm"])) < 1e-3 * float(g[f"{tag}_total_norm"])
+    sd = m.state_dict()
+    p8 = np.stack([np.pad(sd[k].flatten()[:8].cpu().numpy(), (0, max(0, 8 - sd[k].numel()))) for k in names])
+    # first Adam update is +-lr wherever |g| is above rounding noise: elements whose gradient is noise may flip sign
+    d = np.abs(p8 - g[f"{tag}_p8_after"])
+    assert d.max() <= 2.2 * 2e-4 and (d > 5e-5).mean() < 5e-3, (d.max(), (d > 5e-5).mean())
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_celeba_full_resolution_vs_reference(bd, golden, mode):
+    """the real 256x256 DDPM-CELEBA-HQ-256 network (113.7 M parameters), batch 1, forward + backward against the imported
+    reference's output (strided slices + checksums) and every gradient tensor's norm + leading elements (G10)."""
+    unet, ops = bd
+    g = golden("full_size"); tag = "celeba256"
+    cfg = U.CELEBA_HQ_256
+    m = make_model(unet, cfg, 5).set_compute_mode(mode)
+    x, t, dout = C.celeba_full_inputs()
+    out = m(x.cuda(), t.cuda(), return_dict=False)[0]
+    od = out.detach()
+    assert relerr(od[0, :, ::16, ::16], g[f"{tag}_out_slices"]) < 1e-4
+    assert abs(float((od.double() ** 2).sum()) - float(g[f"{tag}_out_sumsq"])) < 1e-4 * float(g[f"{tag}_out_sumsq"])
+    assert abs(float(od.double().sum()) - float(g[f"{tag}_out_sum"])) < 1e-3 * float(np.sqrt(float(g[f"{tag}_out_sumsq"]) * od.numel()))
+    out.backward(dout.cuda())
+    _golden_grad_check(m, g, tag)
+
+
 def test_cifar_full_batch_modes_and_schedules_agree(bd):
     """BASELINE configs[1] at its full size (DDPM-CIFAR10-32, batch 128): the oracle would need a minute, so the check
     is self-consistency across the independent code paths -- split-bf16 vs exact-fp32 contraction, two-stream vs

@@ -254,3 +254,27 @@ def test_image_file_triggers_match_reference_fixture():
         assert torch.equal(got, want), (key, float((got - want).abs().max()))
         n += 1
     assert n == 9
+
+
+def test_resume_rng_state_is_per_rank(tmp_path):
+    """rank 0's RNG state must not be installed on every rank.  checkpoint() (rank 0) + save_rank_rng (others)
+    write one state per rank; restore_training_state(rank) gives each rank its own stream back, and a rank that has no state of
+    its own is re-seeded with seed + rank instead of silently sharing rank 0's."""
+    import baddiffusion as cli
+    config = cli.TrainingConfig()
+    config.seed = 3
+    config.ckpt_path = str(tmp_path / "ckpt"); config.data_ckpt_path = str(tmp_path / "data.ckpt")
+    torch.manual_seed(100)                                        # "rank 0"
+    torch.save({"epoch": 1, "step": 7, "cpu_rng": torch.get_rng_state(), "cuda_rng": None}, config.data_ckpt_path)
+    next0 = torch.randn(4)
+    torch.manual_seed(101)                                        # "rank 1"
+    cli.save_rank_rng(config, 1)
+    next1 = torch.randn(4)
+    assert os.path.exists(config.data_ckpt_path + ".rank1") and not torch.equal(next0, next1)
+    torch.manual_seed(999)
+    assert cli.restore_training_state(config, None, rank=0) == (1, 7) and torch.equal(torch.randn(4), next0)
+    torch.manual_seed(999)
+    assert cli.restore_training_state(config, None, rank=1) == (1, 7) and torch.equal(torch.randn(4), next1)
+    assert cli.restore_training_state(config, None, rank=2) == (1, 7)     # no file: seed + rank
+    want = torch.randn(4, generator=torch.Generator().manual_seed(config.seed + 2))
+    assert torch.equal(torch.randn(4), want)
