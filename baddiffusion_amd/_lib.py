@@ -181,6 +181,8 @@ SIGNATURES = {
     "bd_unet_create": (i32, [C.POINTER(UnetConfig), C.POINTER(vp)]),
     "bd_unet_destroy": (None, [vp]),
     "bd_unet_set_compute_mode": (i32, [vp, i32]),
+    "bd_unet_set_deferred_join": (i32, [vp, i32]),
+    "bd_unet_stream_wait_aux": (i32, [vp, vp]),
     "bd_unet_num_params": (i64, [vp]),
     "bd_unet_num_tensors": (i32, [vp]),
     "bd_unet_param_info": (i32, [vp, i32, C.POINTER(C.c_char_p), C.POINTER(i64), C.POINTER(i32), i64 * 4, C.POINTER(i32)]),

@@ -24,7 +24,7 @@ SOURCES = [  # (file, extra flags)
     ("attn.hip", []),
     ("metrics.hip", ["-ffp-contract=off"]),
     ("conv.cpp", ["-x", "hip"]),
-    ("conv_thin.hip", []),
+    ("conv_thin.hip", ["-fno-slp-vectorize"]),   # SLP pairs the fp32 FMAs into v_pk_fma_f32 with splatted coefficients: 2x the registers, spills
     ("unet_plan.cpp", ["-x", "hip"]),
     ("prof.cpp", ["-x", "hip"]),
 ]

@@ -19,9 +19,16 @@ static int conv_geom_check(const char* who, int B, int Hs, int Ws, int Cin, int 
     return BD_OK;
 }
 
+int conv3x3_fwd_thin(const bd_conv3x3_fwd_desc& d, hipStream_t st);       // conv_thin.hip
+int conv3x3_dgrad_thin(const bd_conv3x3_dgrad_desc& d, hipStream_t st);
+
 int conv3x3_fwd(const bd_conv3x3_fwd_desc& d, hipStream_t st) {
     BD_TRY(conv_geom_check("conv3x3_fwd", d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.stride, d.ups, d.Ho, d.Wo));
     BD_CHECK(d.x && d.w && d.y, BD_ERR_INVALID, "conv3x3_fwd: null pointer");
+    {   // 3-channel conv_in / conv_out: direct fp32 streaming kernels (unet_2d.py:124,217)
+        const int thin = conv3x3_fwd_thin(d, st);
+        if (thin != 0) return thin < 0 ? thin : (int)BD_OK;
+    }
     bd_igemm_desc g = {};
     g.A.kind = BD_OPK_CONV; g.A.kc = 1; g.A.p = d.x; g.A.ld = d.ldx;
     g.A.C = d.Cin; g.A.Hs = d.Hs; g.A.Ws = d.Ws; g.A.Ho = d.Ho; g.A.Wo = d.Wo;
@@ -41,6 +48,10 @@ int conv3x3_fwd(const bd_conv3x3_fwd_desc& d, hipStream_t st) {
 int conv3x3_dgrad(const bd_conv3x3_dgrad_desc& d, hipStream_t st) {
     BD_TRY(conv_geom_check("conv3x3_dgrad", d.B, d.Hs, d.Ws, d.Cin, d.Cout, d.stride, d.ups, d.Ho, d.Wo));
     BD_CHECK(d.dy && d.w && d.dx, BD_ERR_INVALID, "conv3x3_dgrad: null pointer");
+    {
+        const int thin = conv3x3_dgrad_thin(d, st);
+        if (thin != 0) return thin < 0 ? thin : (int)BD_OK;
+    }
     const int Hi = d.Hs << d.ups, Wi = d.Ws << d.ups;  // the conv's own (virtual) input grid
     bd_igemm_desc g = {};
     g.A.kind = BD_OPK_TCONV; g.A.kc = 1; g.A.p = d.dy; g.A.ld = d.lddy;

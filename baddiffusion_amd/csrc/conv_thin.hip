@@ -179,6 +179,320 @@ __global__ __launch_bounds__(1024) void thin_reduce_kernel(const float* __restri
     }
 }
 
+// =====================================================================================================================
+// Round 3: the same two layers' FORWARD and DATA-GRADIENT passes as direct fp32 streaming kernels (they used to run
+// on the generic igemm loaders at 10-17 TFLOP/s: 53-89 us per launch for a 13 us stream of bytes), and wave-per-row
+// versions of the two weight gradients above.
+//   expand   (few -> many channels): conv_in forward (Cin = 3 -> C) and conv_out data gradient (dy[.,3] -> dx[.,C]):
+//            out[p][n] = sum_{tap, j<J} in[nbr(p, tap)][j] * coef[tap][j][n].  Thread = 4 adjacent output channels (its 9*J
+//            float4 coefficients stay in registers) x a run of 4 pixels of one image row (the 3 x 6 x J inputs of the run
+//            are loaded once); the 32 threads of a run write 512 contiguous bytes per pixel.
+//   contract (many -> few): conv_out forward (C = 128 -> 3): wave = 32 adjacent pixels of one image row, lane = 2 channels;
+//            a 3 x 3 window of float2 slides along the row (3 coalesced 512-byte loads per pixel), the per-lane partial sums
+//            of the 32 pixels are folded across the wave by a halving butterfly (one shuffle per value, not six).
+// Both compute modes take these kernels: plain fp32 FMAs are exact products, i.e. at least as accurate as either MFMA path.
+__device__ __attribute__((aligned(16))) const float kThinZero4[4] = {0.f, 0.f, 0.f, 0.f};
+
+struct ThinCoef { long long base, sn, st, sj; };   // coefficient of (out channel n, tap t, in channel j) = w[base + n*sn + t*st + j*sj]
+
+template <int J>
+__global__ __launch_bounds__(256) void thin_expand_kernel(const float* __restrict__ in, long long ldi, const float* __restrict__ w, ThinCoef cm,
+                                                        const float* __restrict__ bias, float* __restrict__ out, long long ldo, int H,
+                                                        int W, long long pixels, int iters, float out_scale) {
+    const int q = threadIdx.x & 31, slot = threadIdx.x >> 5;
+    const int n0 = blockIdx.y * 128 + q * 4;
+    float4 cf[9 * J];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            const float* c0 = w + cm.base + (long long)n0 * cm.sn + t * cm.st + j * cm.sj;
+            cf[t * J + j] = make_float4(c0[0], c0[cm.sn], c0[2 * cm.sn], c0[3 * cm.sn]);
+        }
+    const float4 b4 = bias ? *reinterpret_cast<const float4*>(bias + n0) : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int HW = H * W;
+    for (int it = 0; it < iters; ++it) {
+        const long long p0 = ((long long)blockIdx.x * iters + it) * 32 + slot * 4;   // W % 4 == 0: a run never leaves its row
+        if (p0 >= pixels) break;
+        const int b = (int)(p0 / HW), r = (int)(p0 - (long long)b * HW);
+        const int y = r / W, x0 = r - y * W;
+        // the 3 x 6 x J inputs of the run: out-of-image taps read a clamped (valid) pixel and are multiplied by 0 -- no pointer
+        // select (it turns the loads into FLAT loads with 64-bit address arithmetic each), one 32-bit offset per position
+        float v[3][6][J];
+        unsigned roff[3], coff[6]; float rm[3], cmk[6];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int ys = y - 1 + dy;
+            rm[dy] = (unsigned)ys < (unsigned)H ? 1.f : 0.f;
+            roff[dy] = (unsigned)(b * HW + min(max(ys, 0), H - 1) * W);
+        }
+#pragma unroll
+        for (int dx = 0; dx < 6; ++dx) {
+            const int xs = x0 - 1 + dx;
+            cmk[dx] = (unsigned)xs < (unsigned)W ? 1.f : 0.f;
+            coff[dx] = (unsigned)min(max(xs, 0), W - 1);
+        }
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 6; ++dx) {
+                const float* src = in + (size_t)(roff[dy] + coff[dx]) * (size_t)ldi;
+                const float m = rm[dy] * cmk[dx];
+#pragma unroll
+                for (int j = 0; j < J; ++j) v[dy][dx][j] = src[j] * m;
+            }
+#pragma unroll
+        for (int px = 0; px < 4; ++px) {
+            float4 a = b4;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const float s = v[t / 3][px + t % 3][j];
+                    const float4 c = cf[t * J + j];
+                    a.x = fmaf(s, c.x, a.x); a.y = fmaf(s, c.y, a.y); a.z = fmaf(s, c.z, a.z); a.w = fmaf(s, c.w, a.w);
+                }
+            a.x *= out_scale; a.y *= out_scale; a.z *= out_scale; a.w *= out_scale;
+            *reinterpret_cast<float4*>(out + (p0 + px) * ldo + n0) = a;
+        }
+    }
+}
+
+// halving butterfly: on entry every lane holds NV partial values ("slots", NV a power of two <= 32); on exit lane l holds the
+// sum over all 64 lanes of slot l / (64 / NV).  NV - 1 + log2(64 / NV) shuffles for NV values instead of 6 per value.
+template <int NV>
+__device__ __forceinline__ float thin_fold(float (&v)[NV], int lane) {
+#pragma unroll
+    for (int half = NV / 2, bit = 32; half >= 1; half >>= 1, bit >>= 1) {
+        // lanes with (lane & bit) == 0 keep the lower `half` slots and hand over the upper ones, and vice versa
+        const bool up = (lane & bit) != 0;
+#pragma unroll
+        for (int k = 0; k < half; ++k) {
+            const float keep = up ? v[k + half] : v[k];
+            const float give = up ? v[k] : v[k + half];
+            v[k] = keep + __shfl_xor(give, bit, 64);
+        }
+    }
+    float s = v[0];
+#pragma unroll
+    for (int m = 64 / NV / 2; m >= 1; m >>= 1) s += __shfl_xor(s, m, 64);   // the 64 / NV lanes that share a slot
+    return s;
+}
+
+template <int O>
+__global__ __launch_bounds__(256, 3) void thin_contract_kernel(const float* __restrict__ a, long long lda, const float* __restrict__ w,
+                                                          const float* __restrict__ bias, float* __restrict__ out, long long ldo, int H,
+                                                          int W, long long nseg, float out_scale) {
+    const int lane = threadIdx.x & 63;
+    const long long seg = (long long)blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);   // wave-uniform
+    if (seg >= nseg) return;
+    float2 cf[O][9];
+#pragma unroll
+    for (int o = 0; o < O; ++o)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) cf[o][t] = *reinterpret_cast<const float2*>(w + ((long long)o * 9 + t) * 128 + lane * 2);
+    const int HW = H * W;
+    const long long p0 = seg * 32;
+    const int b = (int)(p0 / HW), r = (int)(p0 - (long long)b * HW);
+    const int y = r / W, x0 = r - y * W;
+    const float* base = a + (long long)b * HW * lda + lane * 2;
+    // out-of-image taps: the load goes to a clamped (valid) pixel -- one that is inside the same 3 x 3 neighbourhood -- and is
+    // multiplied by a 0 / 1 mask.  (A select would be turned back into a branch around the load with s_waitcnt vmcnt(0)
+    // behind it: 30 serialised round trips per group; DESIGN.md "a compiler trap".)
+    auto ld = [&](int ys, int xs) -> float2 {
+        const float m = ((unsigned)ys < (unsigned)H && (unsigned)xs < (unsigned)W) ? 1.f : 0.f;
+        const int yc = min(max(ys, 0), H - 1), xc = min(max(xs, 0), W - 1);
+        const float2 v = *reinterpret_cast<const float2*>(base + (long long)(yc * W + xc) * lda);
+        return make_float2(v.x * m, v.y * m);
+    };
+    // four groups of GP = 8 pixels: their 3 x 10 neighbourhood is loaded up front (30 coalesced 512-byte loads in flight), then
+    // per output channel 8 partial sums per lane are folded across the wave; lane l ends with pixel (l >> 3) of the group
+    constexpr int GP = 8;
+#pragma unroll 1
+    for (int g = 0; g < 32 / GP; ++g) {
+        float2 win[3][GP + 2];
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < GP + 2; ++dx) win[dy][dx] = ld(y - 1 + dy, x0 + g * GP + dx - 1);
+#pragma unroll
+        for (int o = 0; o < O; ++o) {
+            float part[GP];
+#pragma unroll
+            for (int px = 0; px < GP; ++px) {
+                float s = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    s = fmaf(win[t / 3][px + t % 3].x, cf[o][t].x, s);
+                    s = fmaf(win[t / 3][px + t % 3].y, cf[o][t].y, s);
+                }
+                part[px] = s;
+            }
+            const float s = thin_fold<GP>(part, lane);
+            if ((lane & (64 / GP - 1)) == 0) out[(p0 + g * GP + lane / (64 / GP)) * ldo + o] = (s + (bias ? bias[o] : 0.f)) * out_scale;
+        }
+    }
+}
+
+// Weight gradients of the two layers, wave-per-row form (W % 32 == 0): a wave walks 32-pixel row segments, lane = 2 channels of
+// the wide tensor (one coalesced 512-byte load per pixel), the narrow tensor's 3 x 3 x J neighbourhood is wave-uniform (scalar
+// loads, sliding window), 9*J float2 accumulators per lane.  Four waves fold through LDS in a fixed order, every workgroup
+// leaves one partial row, thin_reduce_kernel sums the rows (deterministic).
+//   WIDE_IS_DY (conv_in):  dW[co][t][j] = sum_p dy[p][co] * x[p + d(t)][j]          wide = dy, narrow = x
+//   otherwise  (conv_out): dW[j][t][c]  = sum_q a[q][c]  * dy[q - d(t)][j]          wide = a,  narrow = dy
+template <int J, bool WIDE_IS_DY>
+__global__ __launch_bounds__(256) void wgrad_thin_row_kernel(const float* __restrict__ wide, long long ldw, const float* __restrict__ nar,
+                                                           long long ldn, int Cw, int H, int W, long long nseg, int segs_per_wave,
+                                                           float* __restrict__ partial) {
+    __shared__ float2 red[3][9 * J + 1][64];
+    __shared__ float redn[4][J];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int cb = blockIdx.y * 128;
+    float2 acc[9][J];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < J; ++j) acc[t][j] = make_float2(0.f, 0.f);
+    float2 accw = make_float2(0.f, 0.f);
+    float accn[J];
+#pragma unroll
+    for (int j = 0; j < J; ++j) accn[j] = 0.f;
+    const int HW = H * W;
+    for (int s = 0; s < segs_per_wave; ++s) {
+        const long long seg = ((long long)blockIdx.x * 4 + wave) * segs_per_wave + s;
+        if (seg >= nseg) break;
+        const long long p0 = seg * 32;
+        const int b = (int)(p0 / HW), r = (int)(p0 - (long long)b * HW);
+        const int y = r / W, x0 = r - y * W;
+        const float* nb = nar + (long long)b * HW * ldn;
+        float win[3][3][J];
+        auto ldcol = [&](int xs, int slot) {      // wave-uniform; out-of-image -> clamped pixel x 0 (no pointer select, no FLAT loads)
+            const float mx = (unsigned)xs < (unsigned)W ? 1.f : 0.f;
+            const int xc = min(max(xs, 0), W - 1);
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy) {
+                const int ys = y - 1 + dy;
+                const float m = (unsigned)ys < (unsigned)H ? mx : 0.f;
+                const float* src = nb + ((long long)min(max(ys, 0), H - 1) * W + xc) * ldn;
+#pragma unroll
+                for (int j = 0; j < J; ++j) win[dy][slot][j] = src[j] * m;
+            }
+        };
+        ldcol(x0 - 1, 1); ldcol(x0, 2);
+        const float* wb = wide + ((long long)b * HW + (long long)y * W + x0) * ldw + cb + lane * 2;
+#pragma unroll 4
+        for (int px = 0; px < 32; ++px) {
+#pragma unroll
+            for (int dy = 0; dy < 3; ++dy)
+#pragma unroll
+                for (int j = 0; j < J; ++j) { win[dy][0][j] = win[dy][1][j]; win[dy][1][j] = win[dy][2][j]; }
+            ldcol(x0 + px + 1, 2);
+            const float2 v = *reinterpret_cast<const float2*>(wb + (long long)px * ldw);
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+#pragma unroll
+                for (int j = 0; j < J; ++j) {
+                    const float nv = WIDE_IS_DY ? win[t / 3][t % 3][j] : win[2 - t / 3][2 - t % 3][j];
+                    acc[t][j].x = fmaf(v.x, nv, acc[t][j].x); acc[t][j].y = fmaf(v.y, nv, acc[t][j].y);
+                }
+            if (WIDE_IS_DY) { accw.x += v.x; accw.y += v.y; }
+            else {
+#pragma unroll
+                for (int j = 0; j < J; ++j) accn[j] += win[1][1][j];
+            }
+        }
+    }
+    if (wave > 0) {
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+            for (int j = 0; j < J; ++j) red[wave - 1][t * J + j][lane] = acc[t][j];
+        red[wave - 1][9 * J][lane] = accw;
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int j = 0; j < J; ++j) redn[wave][j] = accn[j];
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    const long long n_w = (long long)Cw * 9 * J, n = n_w + (WIDE_IS_DY ? Cw : J);
+    float* o = partial + (long long)blockIdx.x * n;
+    const int c0 = cb + lane * 2;
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int j = 0; j < J; ++j) {
+            float2 v = acc[t][j];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) { v.x += red[k][t * J + j][lane].x; v.y += red[k][t * J + j][lane].y; }
+            if (WIDE_IS_DY) { o[(long long)c0 * 9 * J + t * J + j] = v.x; o[(long long)(c0 + 1) * 9 * J + t * J + j] = v.y; }
+            else *reinterpret_cast<float2*>(o + ((long long)j * 9 + t) * Cw + c0) = v;
+        }
+    if (WIDE_IS_DY) {
+        float2 v = accw;
+#pragma unroll
+        for (int k = 0; k < 3; ++k) { v.x += red[k][9 * J][lane].x; v.y += red[k][9 * J][lane].y; }
+        *reinterpret_cast<float2*>(o + n_w + c0) = v;
+    } else if (blockIdx.y == 0 && lane < J) {
+        o[n_w + lane] = ((redn[0][lane] + redn[1][lane]) + redn[2][lane]) + redn[3][lane];
+    }
+}
+
+static bool thin_same_grid(int stride, int ups, int pad_t, int pad_l, int Hs, int Ws, int Ho, int Wo) {
+    return stride == 1 && ups == 0 && pad_t == 1 && pad_l == 1 && Ho == Hs && Wo == Ws;
+}
+
+static int thin_expand_launch(int J, const float* in, long long ldi, const float* w, ThinCoef cm, const float* bias, float* out, long long ldo,
+                              int N, int B, int H, int W, float out_scale, hipStream_t st) {
+    const long long pixels = (long long)B * H * W;
+    const long long runs = cdiv(pixels, 32);
+    const int iters = (int)(runs >= 4096 ? 4 : 1);      // >= 1024 workgroups per 128-channel block at the UNet's sizes
+    const dim3 grid((unsigned)cdiv(runs, iters), (unsigned)(N / 128)), block(256);
+    if (J == 3) hipLaunchKernelGGL(thin_expand_kernel<3>, grid, block, 0, st, in, ldi, w, cm, bias, out, ldo, H, W, pixels, iters, out_scale);
+    else hipLaunchKernelGGL(thin_expand_kernel<1>, grid, block, 0, st, in, ldi, w, cm, bias, out, ldo, H, W, pixels, iters, out_scale);
+    BD_LAUNCH_CHECK("conv3x3 thin expand");
+    return 1;
+}
+
+// returns 1 when it handled the call, 0 when the shape belongs to the igemm path, < 0 on error
+int conv3x3_fwd_thin(const bd_conv3x3_fwd_desc& d, hipStream_t st) {
+    static const bool off = getenv("BD_THIN_DIRECT") && atoi(getenv("BD_THIN_DIRECT")) == 0;
+    if (off || d.rowbias || d.residual || !thin_same_grid(d.stride, d.ups, d.pad_t, d.pad_l, d.Hs, d.Ws, d.Ho, d.Wo)) return 0;
+    const float os = d.out_scale == 0.f ? 1.f : d.out_scale;
+    const double flops = 2.0 * d.B * d.Hs * d.Ws * 9.0 * d.Cin * d.Cout, bytes = 4.0 * d.B * d.Hs * d.Ws * (d.Cin + d.Cout);
+    if ((d.Cin == 3 || d.Cin == 1) && d.Cout % 128 == 0 && d.Ws % 4 == 0 && d.ldy % 4 == 0 && aligned16(d.y) && (!d.bias || aligned16(d.bias))) {
+        const int rec = prof_on() ? prof_begin("conv_thin_fwd", flops, bytes, st) : -1;
+        const ThinCoef cm = {0, 9ll * d.Cin, d.Cin, 1};
+        const int r = thin_expand_launch(d.Cin, d.x, d.ldx, d.w, cm, d.bias, d.y, d.ldy, d.Cout, d.B, d.Hs, d.Ws, os, st);
+        prof_end(rec, st);
+        return r;
+    }
+    if ((d.Cout == 3 || d.Cout == 1) && d.Cin == 128 && d.Ws % 32 == 0 && d.ldx % 2 == 0 && ((uintptr_t)d.x & 7) == 0) {
+        const int rec = prof_on() ? prof_begin("conv_thin_fwd", flops, bytes, st) : -1;
+        const long long nseg = (long long)d.B * d.Hs * d.Ws / 32;
+        const dim3 grid((unsigned)cdiv(nseg, 4)), block(256);
+        if (d.Cout == 3) hipLaunchKernelGGL(thin_contract_kernel<3>, grid, block, 0, st, d.x, (long long)d.ldx, d.w, d.bias, d.y, (long long)d.ldy, d.Hs, d.Ws, nseg, os);
+        else hipLaunchKernelGGL(thin_contract_kernel<1>, grid, block, 0, st, d.x, (long long)d.ldx, d.w, d.bias, d.y, (long long)d.ldy, d.Hs, d.Ws, nseg, os);
+        BD_LAUNCH_CHECK("conv3x3 thin contract");
+        prof_end(rec, st);
+        return 1;
+    }
+    return 0;
+}
+
+int conv3x3_dgrad_thin(const bd_conv3x3_dgrad_desc& d, hipStream_t st) {
+    static const bool off = getenv("BD_THIN_DIRECT") && atoi(getenv("BD_THIN_DIRECT")) == 0;
+    if (off || d.accumulate || !thin_same_grid(d.stride, d.ups, d.pad_t, d.pad_l, d.Hs, d.Ws, d.Ho, d.Wo)) return 0;
+    if (!((d.Cout == 3 || d.Cout == 1) && d.Cin % 128 == 0 && d.Ws % 4 == 0 && d.lddx % 4 == 0 && aligned16(d.dx))) return 0;
+    const int rec = prof_on() ? prof_begin("conv_thin_dgrad", 2.0 * d.B * d.Hs * d.Ws * 9.0 * d.Cin * d.Cout, 4.0 * d.B * d.Hs * d.Ws * (d.Cin + d.Cout), st) : -1;
+    // dx[p][c] = sum_{t', o} dy[p + d(t')][o] * w[o][8 - t'][c]   (w = [Cout][3][3][Cin])
+    const ThinCoef cm = {8ll * d.Cin, 1, -(long long)d.Cin, 9ll * d.Cin};
+    const int r = thin_expand_launch(d.Cout, d.dy, d.lddy, d.w, cm, nullptr, d.dx, d.lddx, d.Cin, d.B, d.Hs, d.Ws, 1.f, st);
+    prof_end(rec, st);
+    return r;
+}
+
 static bool thin_in_shape(const bd_conv3x3_wgrad_desc& d) { return (d.Cin == 3 || d.Cin == 1) && d.Cout % 128 == 0; }
 static bool thin_out_shape(const bd_conv3x3_wgrad_desc& d) { return (d.Cout == 3 || d.Cout == 1) && d.Cin % 128 == 0; }
 // shapes these kernels take (they also produce the bias gradient d.db for ANY Cout, unlike the igemm fusion)
@@ -203,6 +517,22 @@ int conv3x3_wgrad_thin(const bd_conv3x3_wgrad_desc& d, hipStream_t st) {
     BD_CHECK(d.workspace && d.workspace_bytes >= need, BD_ERR_WORKSPACE, "conv3x3_wgrad (thin): workspace %zu < %zu", d.workspace_bytes,
              need);
     float* part = reinterpret_cast<float*>(d.workspace);
+    static const bool row_off = getenv("BD_THIN_DIRECT") && atoi(getenv("BD_THIN_DIRECT")) == 0;
+    if (!row_off && d.Ws % 32 == 0 && d.pad_t == 1 && d.pad_l == 1 && (d.Cin == 3 || d.Cout == 3) &&
+        (thin_in ? d.lddy : d.ldx) % 2 == 0 && ((uintptr_t)(thin_in ? d.dy : d.x) & 7) == 0) {   // float2 loads of the wide tensor
+        const long long nseg = g.pixels / 32;
+        const int spw = (int)cdiv(nseg, 1024);
+        const int Pr = (int)cdiv(nseg, 4ll * spw);
+        const int Cw = thin_in ? d.Cout : d.Cin;
+        BD_CHECK(d.workspace_bytes >= (size_t)Pr * n * sizeof(float), BD_ERR_WORKSPACE, "conv3x3_wgrad (thin rows): workspace too small");
+        const dim3 grid((unsigned)Pr, (unsigned)(Cw / 128));
+        if (thin_in) hipLaunchKernelGGL((wgrad_thin_row_kernel<3, true>), grid, dim3(256), 0, st, d.dy, (long long)d.lddy, d.x, (long long)d.ldx, Cw, d.Hs, d.Ws, nseg, spw, part);
+        else hipLaunchKernelGGL((wgrad_thin_row_kernel<3, false>), grid, dim3(256), 0, st, d.x, (long long)d.ldx, d.dy, (long long)d.lddy, Cw, d.Hs, d.Ws, nseg, spw, part);
+        BD_LAUNCH_CHECK("conv3x3_wgrad_thin_row");
+        hipLaunchKernelGGL(thin_reduce_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, part, Pr, n, n_w, d.dw, d.db);
+        BD_LAUNCH_CHECK("conv3x3_wgrad_thin_reduce");
+        return 1;
+    }
     if (thin_in) {
         const dim3 grid((unsigned)P, (unsigned)(d.Cout / 128));
         if (d.Cin == 3) hipLaunchKernelGGL(wgrad_thin_cin_kernel<3>, grid, dim3(256), 0, st, d.x, (long long)d.ldx, d.dy, (long long)d.lddy, g, d.Cout, part);
@@ -217,5 +547,7 @@ int conv3x3_wgrad_thin(const bd_conv3x3_wgrad_desc& d, hipStream_t st) {
     BD_LAUNCH_CHECK("conv3x3_wgrad_thin_reduce");
     return 1;
 }
+
+
 
 }  // namespace bd

@@ -108,7 +108,9 @@ struct bd_unet {
     bd_unet_config cfg;
     hipStream_t aux_stream = nullptr;              // created on the first backward (plan creation stays host-only)
     hipEvent_t aux_ev_fork = nullptr, aux_ev_join[2] = {nullptr, nullptr};
-    int aux_enabled = 1;
+    hipEvent_t aux_ev_seg = nullptr;               // side-stream position after the last segment call's weight gradients
+    bool aux_pend[2] = {false, false};             // carried from one bd_unet_backward_segment call to the next (same backward pass)
+    int aux_enabled = 1, aux_defer = 0;
     std::vector<Buf> bufs;
     std::vector<Param> params;
     int64_t nparams = 0;
@@ -333,6 +335,10 @@ struct bd_unet {
     int conv_pw(Ctx& c, bd_conv3x3_ps_wgrad_desc& d) const {
         d.workspace_bytes = c.opws_bytes;
         if (c.dry) { note_conv(c); return BD_OK; }
+        // BD_AUX_MAXPIX (A/B knob): weight gradients over more pixels than this stay on the main stream -- they fill the chip
+        // on their own, and beside the dgrad chain they mostly trade clock for overlap
+        static const long long maxpix = getenv("BD_AUX_MAXPIX") ? atoll(getenv("BD_AUX_MAXPIX")) : (1ll << 62);
+        if ((long long)d.B * d.H * d.W > maxpix) { d.workspace = c.opws; return conv3x3_ps_wgrad(d, c.st); }
         return on_aux(c, [&](hipStream_t st, char* ws) { d.workspace = ws; return conv3x3_ps_wgrad(d, st); });
     }
     static uint16_t* U16(float* p) { return reinterpret_cast<uint16_t*>(p); }
@@ -575,9 +581,9 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             d.param_partials = c.gn_slot(d.B, d.HW, d.C, d.G, d.dgamma, d.dbeta);
             if (!c.dry) BD_TRY(bd_gn_bwd(&d, (bd_stream_t)c.st));
         }
-        // this resnet's rows of the batched time_emb_proj weight / bias gradient: dW = dtproj[:, rows]^T embs (resnet.py:571)
-        BD_TRY(linear_wgrad(c, BP(c, b_dtproj) + toff, sumC_, BP(c, b_embs_), T_, c.grads + p_tw_ + (int64_t)toff * T_, c.B, Cout, T_,
-                            c.grads + p_tb_ + toff));
+        // (this resnet's rows of the batched time_emb_proj weight / bias gradient, dW = dtproj[:, rows]^T embs (resnet.py:571),
+        //  are produced by ONE launch per backward segment over all of the segment's resnets: temb_wgrad below)
+        if (c.dry) BD_TRY(linear_wgrad(c, BP(c, b_dtproj), sumC_, BP(c, b_embs_), T_, c.grads, c.B, sumC_, T_, c.grads));   // workspace bound
         if (ps1) {
             bd_conv3x3_ps_wgrad_desc w1 = {};
             w1.B = c.B; w1.H = H; w1.W = W; w1.Cin = Cin; w1.Cout = Cout;
@@ -1052,6 +1058,7 @@ extern "C" void bd_unet_destroy(bd_unet* u) {
         (void)hipEventDestroy(u->aux_ev_fork);
         (void)hipEventDestroy(u->aux_ev_join[0]);
         (void)hipEventDestroy(u->aux_ev_join[1]);
+        (void)hipEventDestroy(u->aux_ev_seg);
         (void)hipStreamDestroy(u->aux_stream);
     }
     delete u;
@@ -1059,6 +1066,17 @@ extern "C" void bd_unet_destroy(bd_unet* u) {
 extern "C" int bd_unet_set_aux_stream(bd_unet* u, int enabled) {
     BD_CHECK(u, BD_ERR_INVALID, "bd_unet_set_aux_stream: null plan");
     u->aux_enabled = enabled ? 1 : 0;
+    return BD_OK;
+}
+extern "C" int bd_unet_set_deferred_join(bd_unet* u, int enabled) {
+    BD_CHECK(u, BD_ERR_INVALID, "bd_unet_set_deferred_join: null plan");
+    u->aux_defer = enabled ? 1 : 0;
+    return BD_OK;
+}
+extern "C" int bd_unet_stream_wait_aux(bd_unet* u, bd_stream_t stream) {
+    BD_CHECK(u, BD_ERR_INVALID, "bd_unet_stream_wait_aux: null plan");
+    if (!u->aux_stream || !u->aux_ev_seg) return BD_OK;      // no side stream yet: nothing to wait for
+    BD_HIP_TRY(hipStreamWaitEvent(S(stream), u->aux_ev_seg, 0));
     return BD_OK;
 }
 extern "C" int bd_unet_set_compute_mode(bd_unet* u, int mode) {
@@ -1122,6 +1140,7 @@ static int unet_aux_init(bd_unet* u) {
     BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_fork, hipEventDisableTiming));
     BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join[0], hipEventDisableTiming));
     BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join[1], hipEventDisableTiming));
+    BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_seg, hipEventDisableTiming));
     return BD_OK;
 }
 
@@ -1203,9 +1222,16 @@ extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float*
     BD_CHECK(seg >= -1 && seg < (int)u->segs.size(), BD_ERR_INVALID, "bd_unet_backward: segment %d out of range", seg);
     c.params = params; c.grads = grads; c.dout = dout; c.lddo = lddo; c.st = S(stream);
     c.x = x; c.ldx = ldx;   // conv_in wgrad re-reads the forward input
+    // Deferred join (bd_unet_set_deferred_join, used by the data-parallel trainer): the weight gradients a segment puts on the side
+    // stream may still be running when the call returns and while the NEXT segment's data-gradient chain runs; the caller orders
+    // whatever consumes this segment's gradient ranges behind them with bd_unet_stream_wait_aux(plan, consumer_stream).  The
+    // scratch-arena hazard is covered across calls by carrying the per-parity "pending" marks in the plan.  The last segment (and
+    // a whole backward, seg == -1) always joins, so the caller's stream ends ordered after everything.
+    const bool defer = u->aux_enabled && u->aux_defer && seg >= 0 && seg + 1 < (int)u->segs.size();
     if (u->aux_enabled) {
         BD_TRY(unet_aux_init(u));
         c.st2 = u->aux_stream; c.ev_fork = u->aux_ev_fork; c.ev_join[0] = u->aux_ev_join[0]; c.ev_join[1] = u->aux_ev_join[1];
+        if (seg > 0 && u->aux_defer) { c.pend[0] = u->aux_pend[0]; c.pend[1] = u->aux_pend[1]; }
     }
     // grad-init flags must reflect everything executed before this segment: replay them (host-only)
     for (auto it = u->bwd.rbegin(); it != u->bwd.rend(); ++it) {
@@ -1221,8 +1247,31 @@ extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float*
         if (run) BD_TRY(bd_unet::aux_mark(c, par));
     }
     if (!c.gn_items.empty()) BD_TRY(bd_gn_bwd_params(c.gn_items.data(), (int)c.gn_items.size(), c.B, (bd_stream_t)c.st));
-    BD_TRY(bd_unet::aux_wait(c, 0));   // every weight gradient of this call is ordered before what the caller enqueues next
-    BD_TRY(bd_unet::aux_wait(c, 1));
+    {   // time_emb_proj weight / bias gradient rows of the resnets that just ran: the rows of a segment are adjacent in the batched
+        // [sumC, T] projection, so one GEMM per segment (one for a whole backward) replaces one tiny launch per resnet
+        int64_t lo = -1, hi = -1;
+        for (int sg = 0; sg < (int)u->segs.size(); ++sg) {
+            if (seg >= 0 && sg != seg) continue;
+            const bd_unet::Seg& q = u->segs[sg];
+            if (q.tb_lo < 0) continue;
+            if (lo < 0 || q.tb_lo - u->p_tb < lo) lo = q.tb_lo - u->p_tb;
+            if (q.tb_hi - u->p_tb > hi) hi = q.tb_hi - u->p_tb;
+        }
+        if (lo >= 0) {
+            BD_TRY(u->linear_wgrad(c, u->BP(c, u->b_dtproj) + lo, u->sumC, u->BP(c, u->b_embs), u->T, c.grads + u->p_tw + lo * u->T, c.B,
+                                   (int)(hi - lo), u->T, c.grads + u->p_tb + lo));
+            BD_TRY(bd_unet::aux_mark(c, 0));
+        }
+    }
+    if (defer) {
+        u->aux_pend[0] = c.pend[0]; u->aux_pend[1] = c.pend[1];
+        BD_HIP_TRY(hipEventRecord(u->aux_ev_seg, c.st2));   // everything this (and every earlier) call put on the side stream
+    } else {
+        BD_TRY(bd_unet::aux_wait(c, 0));   // every weight gradient of this call is ordered before what the caller enqueues next
+        BD_TRY(bd_unet::aux_wait(c, 1));
+        u->aux_pend[0] = u->aux_pend[1] = false;
+        if (c.st2) BD_HIP_TRY(hipEventRecord(u->aux_ev_seg, c.st2));
+    }
     if (seg >= 0) {
         if (ready_lo) *ready_lo = u->segs[seg].lo;
         if (ready_hi) *ready_hi = u->segs[seg].hi;

@@ -37,10 +37,12 @@ class DPReducer:
         self.flat, self.pg = flat, process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.works = []
+        self.bytes = 0
 
     def reduce_range(self, lo, hi):
         if self.world > 1 and hi > lo:
             self.works.append(dist.all_reduce(self.flat[lo:hi], group=self.pg, async_op=True))
+            self.bytes += 4 * (hi - lo)
 
     def finish(self):
         for w in self.works:
@@ -100,6 +102,11 @@ class TrainEngine:
             use_graph = os.environ.get("BD_TRAIN_GRAPH", "0") == "1"
         self.use_graph = bool(use_graph) and self.world == 1 and self.accum == 1
         self._graphs = {}
+        # deferred join of the weight-gradient side stream (include/bd_hip.h: bd_unet_set_deferred_join); BD_DEFER_JOIN=0 = A/B
+        self._defer = os.environ.get("BD_DEFER_JOIN", "1") != "0"
+        L.check(self._lib.bd_unet_set_deferred_join(model._plan, 1 if self._defer else 0), "bd_unet_set_deferred_join")
+        self._comm = torch.cuda.Stream(device=dev) if (self.world > 1 and self._defer) else None
+        self.collective_bytes = 0
         self.alphas, self.alphas_cumprod = noise_sched.device_tables(dev)
         self.sync_state()
 
@@ -127,16 +134,30 @@ class TrainEngine:
         B = xn.shape[0]
         red = DPReducer(self.grads, self.pg)
         lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        main = torch.cuda.current_stream()
         for s in range(self._nseg):
             L.check(self._lib.bd_unet_backward_segment(
                 model._plan, s, B, flat.data_ptr(), xn.data_ptr(), xn.shape[-1], dpred.data_ptr(), dpred.shape[-1],
                 self.grads.data_ptr(), ws.data_ptr(), ws.numel(), L.stream(), ctypes.byref(lo), ctypes.byref(hi)),
                 "bd_unet_backward_segment")
-            # the collective waits (on RCCL's stream) for the kernels enqueued so far, then overlaps with the
-            # next segments' kernels; 143 MB in total per step for the CIFAR UNet
-            for (rlo, rhi) in self._seg_ranges[s]:
-                red.reduce_range(rlo, rhi)
-        red.finish()
+            if self.world == 1:
+                continue
+            # The segment's weight gradients may still be running on the plan's side stream (deferred join): the collective
+            # is issued from a third stream that waits for (a) the main stream's position -- GroupNorm parameter fold, bias
+            # rows -- and (b) the side stream's position, so the NEXT segment's kernels on the main stream are not held back.
+            # RCCL orders itself after the issuing stream, then overlaps with the next segments; 143 MB per step for the
+            # CIFAR UNet.
+            if self._defer:
+                self._comm.wait_stream(main)
+                L.check(self._lib.bd_unet_stream_wait_aux(model._plan, self._comm.cuda_stream), "bd_unet_stream_wait_aux")
+                with torch.cuda.stream(self._comm):
+                    for (rlo, rhi) in self._seg_ranges[s]:
+                        red.reduce_range(rlo, rhi)
+            else:
+                for (rlo, rhi) in self._seg_ranges[s]:
+                    red.reduce_range(rlo, rhi)
+        red.finish()          # the main stream waits for every collective (work.wait() orders the CURRENT stream)
+        self.collective_bytes = red.bytes
         model._release_ws(ws)
         return loss
 

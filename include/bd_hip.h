@@ -439,6 +439,14 @@ int bd_unet_segment_range(const bd_unet* u, int seg, int64_t* lo, int64_t* hi); 
  * batched time_emb_proj weight / bias (stored with the time embedding, computed in the resnets' backward) */
 int bd_unet_segment_num_ranges(const bd_unet* u, int seg);
 int bd_unet_segment_range_k(const bd_unet* u, int seg, int k, int64_t* lo, int64_t* hi);
+/* Deferred join (data-parallel training).  By default every bd_unet_backward_segment call ends with the caller's stream ordered
+ * after the weight gradients it put on the plan's side stream.  With bd_unet_set_deferred_join(u, 1) only the LAST segment joins:
+ * a segment's weight gradients keep running beside the next segment's data-gradient chain, and whoever consumes the segment's
+ * gradient ranges (the all-reduce) is ordered behind them explicitly: bd_unet_stream_wait_aux(u, s) makes stream `s` wait for
+ * everything the segment calls made so far have put on the side stream (no host synchronisation; a no-op before the first
+ * backward or with the side stream disabled). */
+int bd_unet_set_deferred_join(bd_unet* u, int enabled);
+int bd_unet_stream_wait_aux(bd_unet* u, bd_stream_t stream);
 int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float* params, const float* x, int64_t ldx,
                              const float* dout, int64_t lddo, float* grads, void* workspace, size_t workspace_bytes,
                              bd_stream_t stream, int64_t* ready_lo, int64_t* ready_hi);
