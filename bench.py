@@ -39,7 +39,7 @@ _PMC_OPERANDS = {"conv_fwd": ("ConvKC", ("WgtKC", "WgtKCs")), "conv_dgrad": ("TC
 _PMC_PS = {"conv_ps_wgrad": (r"conv_ps_wgrad_kernel<", r"conv_ps_wgrad_reduce"), "conv_ps_fwd": (r"conv_ps_kernel<[12]>",),
            "conv_ps_dgrad": (r"conv_ps_kernel<0>",), "conv_ps128_fwd": (r"conv_ps128_kernel<", r"conv_ps128_reduce"),
            "conv_ps128_dgrad": (r"conv_ps128_kernel<", r"conv_ps128_reduce")}
-PMC_FILE = "profiles/r02_pmc_bench_{mode}.json"
+PMC_FILE = "profiles/r03_pmc_bench_{mode}.json"       # falls back to the round-2 file when this round's is absent
 
 
 def _pmc_traffic(cls, launches_per_step=None):
@@ -52,6 +52,9 @@ def _pmc_traffic(cls, launches_per_step=None):
     mode = "bf16x3" if ("bf16x3" in cls or cls.startswith("conv_ps")) else "f32"
     rel = PMC_FILE.format(mode=mode)
     path = os.path.join(ROOT, rel)
+    if not os.path.exists(path):
+        rel = rel.replace("r03_", "r02_")
+        path = os.path.join(ROOT, rel)
     if not os.path.exists(path):
         return None, f"{rel} not found"
     kernels = json.load(open(path))["kernels"]

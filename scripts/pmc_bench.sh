@@ -5,7 +5,7 @@ mode=${1:-bf16x3}
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pb_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pb_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --mode $mode > /tmp/pb_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pb_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-sampling --no-celeba --sustain 0 --mode $mode > /tmp/pb_$c.log 2>&1
 done
 python3 - $mode <<'PY'
 import csv, sys, glob, json, collections, os

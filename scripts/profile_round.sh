@@ -1,22 +1,28 @@
 #!/bin/bash
-# Round profile artifacts (run on the GPU box through gpurun): rocprofv3 kernel-trace summary + bench JSON of the
-# same command, then the PMC traffic passes.  usage: scripts/profile_round.sh <tag>   -> gpurun_out/<tag>_*
-tag=${1:-r02}
+# Round profile artifacts (run on the GPU box through gpurun): rocprofv3 kernel-trace summaries + bench JSON lines, then the
+# PMC traffic passes.  usage: scripts/profile_round.sh <tag>   -> gpurun_out/<tag>_*   (copy what is to be judged into profiles/)
+tag=${1:-r03}
 out=$GRAFT_REPO_ROOT/gpurun_out
+TRAIN="--no-cpu-baseline --no-sampling --no-celeba --sustain 0"     # the headline train step alone (what the kernel tables describe)
 cd /tmp && export TMPDIR=/tmp
+# 1. the train step of the default command under rocprofv3 (two-stream schedule = the timed region of the bench line)
 rm -rf /tmp/rp
-rocprofv3 --kernel-trace --stats -d /tmp/rp -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline > /tmp/rp.log 2>&1
+rocprofv3 --kernel-trace --stats -d /tmp/rp -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 $TRAIN > /tmp/rp.log 2>&1
 grep "^{\"metric\"" /tmp/rp.log | tail -1 > $out/${tag}_bench_under_rocprof.json
 python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/rp -name "*.db" | head -1) 12 > $out/${tag}_train_step_b128_kernel_stats.txt
+# 2. the driver's command, unprofiled: the whole default line (train + sustained + sampling + celeba + CPU baselines)
 cd $GRAFT_REPO_ROOT && python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $out/${tag}_bench.json
-cd $GRAFT_REPO_ROOT && python bench.py --steps 20 --warmup 5 --mode f32 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${tag}_bench_f32.json
-cd $GRAFT_REPO_ROOT && python bench.py --workload celeba --steps 5 --warmup 2 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${tag}_bench_celeba256.json
+cd $GRAFT_REPO_ROOT && python bench.py --steps 20 --warmup 5 --mode f32 $TRAIN 2>/dev/null | tail -1 > $out/${tag}_bench_f32.json
+cd $GRAFT_REPO_ROOT && python bench.py --workload celeba --steps 5 --warmup 2 --no-cpu-baseline --sustain 0 2>/dev/null | tail -1 > $out/${tag}_bench_celeba256.json
+cd $GRAFT_REPO_ROOT && python bench.py --workload pndm50 --batch 2048 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${tag}_bench_pndm50.json
+# 3. HBM traffic per kernel (FETCH_SIZE / WRITE_SIZE in separate --pmc passes)
 $GRAFT_REPO_ROOT/scripts/pmc_bench.sh bf16x3 > /dev/null 2>&1
+cp $out/pmc_bench_bf16x3.json $out/${tag}_pmc_bench_bf16x3.json
+# 4. stand-alone kernel durations (side stream off) for the kernel table in DESIGN.md
+cd /tmp && rm -rf /tmp/rp2 && BD_AUX_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/rp2 -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-prof $TRAIN > /tmp/rp2.log 2>&1
+python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/rp2 -name "*.db" | head -1) 10 > $out/${tag}_train_step_b128_single_stream_kernel_stats.txt
+# 5. the sampling loops of the default line under rocprofv3 (DDIM-50 x 512: same chunk size as the x 2048 loop)
+cd /tmp && rm -rf /tmp/rp3 && rocprofv3 --kernel-trace --stats -d /tmp/rp3 -o r -- python $GRAFT_REPO_ROOT/bench.py --workload ddim50 --batch 512 --no-cpu-baseline --no-prof > /tmp/rp3.log 2>&1
+python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/rp3 -name "*.db" | head -1) 57 > $out/${tag}_ddim50_b512_kernel_stats.txt
 head -12 $out/${tag}_train_step_b128_kernel_stats.txt | cut -c1-140
 cut -c1-400 $out/${tag}_bench.json
-cd $GRAFT_REPO_ROOT && python bench.py --workload ddim50 --batch 2048 2>/dev/null | tail -1 > $out/${tag}_bench_ddim50.json
-cd $GRAFT_REPO_ROOT && python bench.py --workload ddpm1000 --batch 256 2>/dev/null | tail -1 > $out/${tag}_bench_ddpm1000.json
-cd $GRAFT_REPO_ROOT && python bench.py --workload pndm50 --batch 2048 2>/dev/null | tail -1 > $out/${tag}_bench_pndm50.json
-# stand-alone kernel durations (side stream off) for the kernel table in DESIGN.md
-cd /tmp && rm -rf /tmp/rp2 && BD_AUX_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/rp2 -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-cpu-baseline --no-prof > /tmp/rp2.log 2>&1
-python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/rp2 -name "*.db" | head -1) 10 > $out/${tag}_train_step_b128_single_stream_kernel_stats.txt
