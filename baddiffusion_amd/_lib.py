@@ -111,6 +111,17 @@ class ConvPsWgradDesc(C.Structure):
                 ("dy_split", vp), ("lddy", i64), ("dw", vp), ("db", vp), ("workspace", vp), ("workspace_bytes", sz)]
 
 
+class UpsampleConvDesc(C.Structure):
+    _fields_ = [("B", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("x_split", vp), ("ldx", i64), ("dy_split", vp),
+                ("lddy", i64), ("e_split", vp), ("et_split", vp), ("bias", vp), ("y", vp), ("ldy", i64), ("dx", vp), ("lddx", i64),
+                ("accumulate", i32), ("dw", vp), ("db", vp), ("workspace", vp), ("workspace_bytes", sz)]
+
+
+class ConvS2DgradDesc(C.Structure):
+    _fields_ = [("B", i32), ("Ho", i32), ("Wo", i32), ("Cin", i32), ("Cout", i32), ("pad", i32), ("dy_split", vp), ("lddy", i64),
+                ("wT_split", vp), ("dx", vp), ("lddx", i64), ("accumulate", i32)]
+
+
 class AttnFwdDesc(C.Structure):
     _fields_ = [("B", i32), ("heads", i32), ("N", i32), ("dh", i32), ("q", vp), ("k", vp), ("v", vp), ("ld", i64), ("scale", f32),
                 ("o", vp), ("ldo", i64), ("p_out", vp), ("lse", vp)]
@@ -153,6 +164,12 @@ SIGNATURES = {
     "bd_split_rows_ups2": (i32, [vp, i64, i32, i32, i32, i32, vp, i64, vp]),
     "bd_conv3x3_ps": (i32, [C.POINTER(ConvPsDesc), vp]),
     "bd_conv3x3_ps_workspace_bytes": (sz, [C.POINTER(ConvPsDesc)]),
+    "bd_upsample_weights": (i32, [vp, i32, i32, vp, vp, vp]),
+    "bd_upsample_conv_fwd": (i32, [C.POINTER(UpsampleConvDesc), vp]),
+    "bd_upsample_conv_dgrad": (i32, [C.POINTER(UpsampleConvDesc), vp]),
+    "bd_upsample_conv_wgrad": (i32, [C.POINTER(UpsampleConvDesc), vp]),
+    "bd_upsample_conv_wgrad_workspace_bytes": (sz, [C.POINTER(UpsampleConvDesc)]),
+    "bd_conv3x3_s2_dgrad_ps": (i32, [C.POINTER(ConvS2DgradDesc), vp]),
     "bd_conv3x3_ps_wgrad": (i32, [C.POINTER(ConvPsWgradDesc), vp]),
     "bd_conv3x3_ps_wgrad_workspace_bytes": (sz, [C.POINTER(ConvPsWgradDesc)]),
     "bd_conv3x3_fwd": (i32, [C.POINTER(ConvFwdDesc), vp]),

@@ -21,6 +21,7 @@ SOURCES = [  # (file, extra flags)
     ("groupnorm.hip", []),
     ("igemm.hip", []),
     ("conv_ps.hip", []),
+    ("conv_ph.hip", []),
     ("attn.hip", []),
     ("metrics.hip", ["-ffp-contract=off"]),
     ("conv.cpp", ["-x", "hip"]),

@@ -485,6 +485,7 @@ struct PsWgParams {
     int tiles_m, tiles_n, ksplit, cps; // chunks (of 32 pixels) per split
     int want_db;
     int ablate;                        // -DBD_PS_ABLATION builds only, as in PsParams
+    int ntaps;                         // taps per output row: 9, or 16 in the PHASE form (conv_ph.hip: upsample convolution)
 };
 
 typedef short ps_short4 __attribute__((ext_vector_type(4)));
@@ -515,7 +516,12 @@ __device__ __forceinline__ bf16x8 ps_tr_join(ps_short4 v0, ps_short4 v1) {
 
 // NW = 8: waves 4 x 2, 32 x 64 each.  NW = 4: waves 2 x 2, 64 x 64 each (a third fewer LDS fragment reads per MFMA, twice
 // the MFMAs between barriers, half the waves per SIMD).
-template <int STAGES, int NW>
+// PH = true: the PHASE form for the upsample convolution (conv_ph.hip).  H x W is the SOURCE grid, X lives on it, dY on the 2H x 2W
+// grid; the 16 "taps" e = (oy+1)*4 + (ox+1) are the entries of E: entry (oy, ox) belongs to pixel class (p, q) of the fine grid and
+// to the source-grid shift (dy, dx) with oy -> (p, dy): -1 -> (1, +1), 0 -> (0, 0), 1 -> (1, 0), 2 -> (0, -1):
+//     dE[e][co][ci] = sum_{source pixels (a, b)} dY[2a+p, 2b+q][co] * X[a+dy, b+dx][ci].
+// The bias gradient (sum of ALL dY) rides in the four (dy, dx) = (0, 0) entries, one bias row per class and K split.
+template <int STAGES, int NW, bool PH = false>
 __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel(PsWgParams p) {
     constexpr int TMW = 8 / NW;        // 32-row co tiles per wave
     constexpr int NDMA = 16 / NW;      // pixel pairs per wave, operand and chunk
@@ -538,7 +544,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
     }
     const int co0 = tm * WG_BM, n0 = tn * WG_BN;
     const int tap = n0 / p.Cin, ci0 = n0 - tap * p.Cin;
-    const int dyt = tap / 3 - 1, dxt = tap - (tap / 3) * 3 - 1;
+    int dyt, dxt, cp = 0, cq = 0;
+    if constexpr (PH) {
+        const int oy = tap / 4 - 1, ox = (tap & 3) - 1;
+        cp = oy & 1; cq = ox & 1;                                   // oy in {-1, 1} -> class row 1, {0, 2} -> 0
+        dyt = oy == 2 ? -1 : (oy == -1 ? 1 : 0); dxt = ox == 2 ? -1 : (ox == -1 ? 1 : 0);
+    } else {
+        dyt = tap / 3 - 1; dxt = tap - (tap / 3) * 3 - 1;
+    }
+    const long long fine_off = (long long)cp * 2 * p.W + cq;        // PH: dY row of source pixel i = 4i - 2(i & (W-1)) + fine_off
     const int nchunks = (p.P + 31) >> 5;   // a ragged last chunk reads zeros past the last pixel
     const int c_begin = zz * p.cps;
     int c_end = c_begin + p.cps;
@@ -554,7 +568,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
         kpix[j] = k;
         const int ls = ps ^ ((k & 3) << 2);
         const long long pa = (long long)c_begin * 32 + k;
-        asrc[j] = p.dy + pa * p.lddy * 4 + co0 * 4 + ls * 16;
+        asrc[j] = PH ? p.dy + co0 * 4 + ls * 16 : p.dy + pa * p.lddy * 4 + co0 * 4 + ls * 16;
         bsrc[j] = p.x + (pa + dyt * p.W + dxt) * p.ldx * 4 + ci0 * 4 + ls * 16;
     }
     const long long a_adv = 32 * p.lddy * 4, b_adv = 32 * p.ldx * 4;
@@ -567,9 +581,15 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
         const int x = pp & (p.W - 1), y = (pp >> p.lw) & (p.H - 1);
         const bool in = pp < p.P;
         const bool ok = in && (unsigned)(y + dyt) < (unsigned)p.H && (unsigned)(x + dxt) < (unsigned)p.W;
-        ps_dma16(in ? asrc[j] : reinterpret_cast<const char*>(kPsZero), stage + (wave + NW * j) * 1024);
+        if constexpr (PH) {
+            const long long fr = 4ll * pp - 2 * x + fine_off;       // pixel (2a+p, 2b+q) of the fine grid, x = pp & (W-1)
+            ps_dma16(in ? asrc[j] + fr * p.lddy * 4 : reinterpret_cast<const char*>(kPsZero), stage + (wave + NW * j) * 1024);
+        } else {
+            ps_dma16(in ? asrc[j] : reinterpret_cast<const char*>(kPsZero), stage + (wave + NW * j) * 1024);
+            asrc[j] += a_adv;
+        }
         ps_dma16(ok ? bsrc[j] : reinterpret_cast<const char*>(kPsZero), stage + WG_OP_BYTES + (wave + NW * j) * 1024);
-        asrc[j] += a_adv; bsrc[j] += b_adv;
+        bsrc[j] += b_adv;
     };
     auto issue = [&](char* stage) {
 #ifdef BD_PS_ABLATION
@@ -595,7 +615,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
     for (int i = 0; i < TMW; ++i)
 #pragma unroll
         for (int r = 0; r < 16; ++r) { acc[i][0][r] = 0.f; acc[i][1][r] = 0.f; accb[i][r] = 0.f; }
-    const bool do_db = p.want_db && tn == 0 && wn == 0;   // wave-uniform
+    // wave-uniform.  PH: the (dy, dx) = (0, 0) entry of each pixel class (taps 5, 6, 9, 10), first channel block
+    const bool do_db = p.want_db && wn == 0 && (PH ? (dyt == 0 && dxt == 0 && ci0 == 0) : tn == 0);
     bf16x8 ones;
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
@@ -741,8 +762,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
 
     // ---- epilogue: lane holds column n = li of rows (r&3) + 8*(r>>2) + 4*h
     const int li = lane & 31;
-    const int M = p.Cout, N = 9 * p.Cin;
-    float* out = p.out + (p.ksplit > 1 ? (long long)zz * M * N : 0);
+    const int M = p.Cout, N = p.ntaps * p.Cin;
+    float* out = p.out + ((p.ksplit > 1 || PH) ? (long long)zz * M * N : 0);
 #pragma unroll
     for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -755,7 +776,8 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
             }
         }
     if (do_db && li == 0) {
-        float* o = p.ksplit > 1 ? p.out + (long long)p.ksplit * M * N + (long long)zz * M : p.db;
+        float* o = PH ? p.out + (long long)p.ksplit * M * N + ((long long)(cp * 2 + cq) * p.ksplit + zz) * M
+                      : (p.ksplit > 1 ? p.out + (long long)p.ksplit * M * N + (long long)zz * M : p.db);
 #pragma unroll
         for (int i = 0; i < TMW; ++i)
 #pragma unroll
@@ -765,7 +787,7 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
 
 // fixed-order sum of the K-split slabs (float4 per thread); the tail threads fold the bias rows
 __global__ __launch_bounds__(256) void conv_ps_wgrad_reduce(const float* __restrict__ part, int ksplit, long long mn, int M,
-                                                            float* __restrict__ dw, float* __restrict__ db) {
+                                                            float* __restrict__ dw, float* __restrict__ db, int brows) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
     const long long n4 = mn >> 2;
     if (i < n4) {
@@ -779,7 +801,7 @@ __global__ __launch_bounds__(256) void conv_ps_wgrad_reduce(const float* __restr
     } else if (db && i - n4 < M) {
         const long long m = i - n4;
         float v = 0.f;
-        for (int s = 0; s < ksplit; ++s) v += part[(long long)ksplit * mn + (long long)s * M + m];
+        for (int s = 0; s < brows; ++s) v += part[(long long)ksplit * mn + (long long)s * M + m];   // brows = ksplit (x 4 classes in the PHASE form)
         db[m] = v;
     }
 }
@@ -1064,7 +1086,7 @@ int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
     p.dy = reinterpret_cast<const char*>(d.dy_split); p.x = reinterpret_cast<const char*>(d.x_split);
     p.lddy = d.lddy; p.ldx = d.ldx; p.Cin = d.Cin; p.Cout = d.Cout; p.H = d.H; p.W = d.W; p.lw = ilog2x(d.W);
     p.P = d.B * d.H * d.W;
-    p.tiles_m = d.Cout / WG_BM; p.tiles_n = 9 * d.Cin / WG_BN;
+    p.tiles_m = d.Cout / WG_BM; p.tiles_n = 9 * d.Cin / WG_BN; p.ntaps = 9;
     ps_wgrad_split(d, p.ksplit, p.cps);
     p.want_db = d.db != nullptr;
     const long long mn = (long long)d.Cout * 9 * d.Cin;
@@ -1096,15 +1118,79 @@ int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
     BD_LAUNCH_CHECK("conv_ps_wgrad");
     if (p.ksplit > 1) {
         const long long total = mn / 4 + (d.db ? d.Cout : 0);
-        hipLaunchKernelGGL(conv_ps_wgrad_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, p.out, p.ksplit, mn, d.Cout, d.dw, d.db);
+        hipLaunchKernelGGL(conv_ps_wgrad_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, p.out, p.ksplit, mn, d.Cout, d.dw, d.db, p.ksplit);
         BD_LAUNCH_CHECK("conv_ps_wgrad_reduce");
     }
     prof_end(rec, st);
     return BD_OK;
 }
 
+// ---- PHASE form of the weight gradient: the upsample convolution (conv_ph.hip) ---------------------------------------------------
+int ups_dweff_combine(const float* de, int Cin, int Cout, float* dw, hipStream_t st);   // conv_ph.hip
+
+static void ups_wgrad_split(const bd_upsample_conv_desc& d, int& ksplit, int& cps) {
+    bd_conv3x3_ps_wgrad_desc q = {};
+    q.B = d.B; q.H = d.H; q.W = d.W; q.Cin = d.Cin; q.Cout = d.Cout;
+    const long long tiles = (long long)(d.Cout / WG_BM) * (16 * d.Cin / WG_BN);
+    const int nchunks = (int)cdiv((long long)d.B * d.H * d.W, 32);
+    int dev = 0, cus = 256;
+    if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
+    int ks = (int)(2 * cus / tiles);
+    if (ks < 1) ks = 1;
+    if (ks > nchunks / 8) ks = nchunks / 8 > 0 ? nchunks / 8 : 1;
+    cps = (int)cdiv(nchunks, ks);
+    ksplit = (int)cdiv(nchunks, cps);
+}
+size_t upsample_conv_wgrad_workspace_bytes(const bd_upsample_conv_desc& d) {
+    int ks, cps;
+    ups_wgrad_split(d, ks, cps);
+    const size_t mn = (size_t)d.Cout * 16 * d.Cin;
+    return ((size_t)ks * (mn + 4 * (size_t)d.Cout) + mn) * sizeof(float);       // K-split slabs (+ 4 bias rows each) + dE
+}
+// dw [Cout,3,3,Cin] (+ db) of y = conv3x3(nearest_up2(x)) from x (split planes, SOURCE grid) and dY (split planes, fine grid)
+int upsample_conv_wgrad(const bd_upsample_conv_desc& d, hipStream_t st) {
+    BD_CHECK(d.x_split && d.dy_split && d.dw, BD_ERR_INVALID, "bd_upsample_conv_wgrad: null pointer");
+    BD_CHECK(d.B > 0 && conv3x3_ps_wgrad_supported(d.B, d.H, d.W, d.Cin, d.Cout), BD_ERR_UNSUPPORTED,
+             "bd_upsample_conv_wgrad: needs power-of-two H, W, Cin and Cout multiples of 128");
+    BD_CHECK(d.ldx % 32 == 0 && d.lddy % 32 == 0 && ((uintptr_t)d.x_split & 127) == 0 && ((uintptr_t)d.dy_split & 127) == 0,
+             BD_ERR_UNSUPPORTED, "bd_upsample_conv_wgrad: split planes need ld %% 32 == 0 and 128-byte aligned bases");
+    BD_CHECK((long long)d.B * d.H * d.W * 4 < (1ll << 31), BD_ERR_UNSUPPORTED, "bd_upsample_conv_wgrad: pixel count overflows int32");
+    const size_t need = upsample_conv_wgrad_workspace_bytes(d);
+    BD_CHECK(d.workspace && d.workspace_bytes >= need, BD_ERR_WORKSPACE, "bd_upsample_conv_wgrad: workspace %zu < %zu", d.workspace_bytes, need);
+    PsWgParams p = {};
+    p.dy = reinterpret_cast<const char*>(d.dy_split); p.x = reinterpret_cast<const char*>(d.x_split);
+    p.lddy = d.lddy; p.ldx = d.ldx; p.Cin = d.Cin; p.Cout = d.Cout; p.H = d.H; p.W = d.W; p.lw = ilog2x(d.W);
+    p.P = d.B * d.H * d.W;
+    p.tiles_m = d.Cout / WG_BM; p.tiles_n = 16 * d.Cin / WG_BN; p.ntaps = 16;
+    ups_wgrad_split(d, p.ksplit, p.cps);
+    p.want_db = d.db != nullptr;
+    const long long mn = (long long)d.Cout * 16 * d.Cin;
+    p.out = reinterpret_cast<float*>(d.workspace);
+    float* de = p.out + (size_t)p.ksplit * ((size_t)mn + 4 * (size_t)d.Cout);
+    int rec = -1;
+    if (prof_on())
+        rec = prof_begin("conv_ph_ups_wgrad", 2.0 * (double)p.P * 4.0 * d.Cout * 9.0 * d.Cin,
+                         ((double)p.P * (d.Cin + 4.0 * d.Cout) + 9.0 * d.Cin * d.Cout) * 4.0, st);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * p.ksplit));
+    hipLaunchKernelGGL((conv_ps_wgrad_kernel<2, 8, true>), grid, dim3(512), 0, st, p);
+    BD_LAUNCH_CHECK("conv_ps_wgrad (phase)");
+    const long long total = mn / 4 + (d.db ? d.Cout : 0);
+    hipLaunchKernelGGL(conv_ps_wgrad_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, p.out, p.ksplit, mn, d.Cout, de, d.db, 4 * p.ksplit);
+    BD_LAUNCH_CHECK("conv_ps_wgrad_reduce (phase)");
+    BD_TRY(ups_dweff_combine(de, d.Cin, d.Cout, d.dw, st));
+    prof_end(rec, st);
+    return BD_OK;
+}
+
 }  // namespace bd
 
+extern "C" size_t bd_upsample_conv_wgrad_workspace_bytes(const bd_upsample_conv_desc* d) {
+    return d ? bd::upsample_conv_wgrad_workspace_bytes(*d) : 0;
+}
+extern "C" int bd_upsample_conv_wgrad(const bd_upsample_conv_desc* d, bd_stream_t s) {
+    BD_CHECK(d, BD_ERR_INVALID, "bd_upsample_conv_wgrad: null descriptor");
+    return bd::upsample_conv_wgrad(*d, bd::S(s));
+}
 extern "C" size_t bd_conv3x3_ps_workspace_bytes(const bd_conv3x3_ps_desc* d) { return d ? bd::conv3x3_ps_workspace_bytes(*d) : 0; }
 extern "C" int bd_conv3x3_ps(const bd_conv3x3_ps_desc* d, bd_stream_t s) {
     BD_CHECK(d, BD_ERR_INVALID, "bd_conv3x3_ps: null descriptor");

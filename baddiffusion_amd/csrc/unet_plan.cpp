@@ -30,6 +30,13 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st);                    
 bool conv3x3_ps_supported(int B, int H, int W, int K_channels, int N_channels);
 int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st);
 bool conv3x3_ps_wgrad_supported(int B, int H, int W, int Cin, int Cout);
+int upsample_weights(const float* w, int Cin, int Cout, uint16_t* e_split, uint16_t* et_split, hipStream_t st);   // conv_ph.hip
+int upsample_conv_fwd(const bd_upsample_conv_desc& d, hipStream_t st);
+int upsample_conv_dgrad(const bd_upsample_conv_desc& d, hipStream_t st);
+int upsample_conv_wgrad(const bd_upsample_conv_desc& d, hipStream_t st);             // conv_ps.hip (PHASE form of the weight gradient)
+size_t upsample_conv_wgrad_workspace_bytes(const bd_upsample_conv_desc& d);
+bool upsample_conv_ps_supported(int B, int H, int W, int Cin, int Cout);
+int conv3x3_s2_dgrad_ps(const bd_conv3x3_s2_dgrad_desc& d, hipStream_t st);
 int attn_fwd(const bd_attn_fwd_desc& d, hipStream_t st);                             // attn.hip
 bool attn_fwd_supported(int N, int dh);
 int split_wt_batched(const float* params, uint16_t* out, const long long* off, const int* cin, const int* cout, int n, hipStream_t st);
@@ -131,6 +138,8 @@ struct bd_unet {
     int64_t p_tw = 0, p_tb = 0;  // offsets of the batched time_emb_proj weight / bias
     int b_tproj = -1, b_dtproj = -1, b_embs = -1;
     std::vector<long long> wt_off; std::vector<int> wt_cin, wt_cout;   // 3x3 conv weights with a transposed split copy
+    struct UpsW { int64_t pw; int C; int b_e, b_et; };                 // upsample convolutions: E / E^T planes rebuilt every forward
+    std::vector<UpsW> upsw;
 
     // ---------------------------------------------------------------- construction helpers
     int new_buf(int64_t per_sample, int64_t fixed, int region) {
@@ -331,6 +340,11 @@ struct bd_unet {
         const int B = c.LB > 0 ? c.LB : c.B;
         return !off && cfg.compute_mode == BD_MODE_BF16X3 && (c.dry || c.w_split) && conv3x3_ps_supported(B, H, W, Cin, Cout) &&
                conv3x3_ps_supported(B, H, W, Cout, Cin) && conv3x3_ps_wgrad_supported(B, H, W, Cin, Cout);
+    }
+    // phase-decomposed forms (conv_ph.hip): the upsample convolution on its SOURCE grid, the stride-2 data gradient by parity class
+    bool phase_ok(const Ctx& c, int H, int W, int Cin, int Cout) const {
+        const int B = c.LB > 0 ? c.LB : c.B;
+        return cfg.compute_mode == BD_MODE_BF16X3 && (c.dry || c.w_split) && upsample_conv_ps_supported(B, H, W, Cin, Cout);
     }
     int conv_pw(Ctx& c, bd_conv3x3_ps_wgrad_desc& d) const {
         d.workspace_bytes = c.opws_bytes;
@@ -737,7 +751,8 @@ void bd_unet::node_downsample(const std::string& pre, const View& x, const View&
     const int C = x.C, H = x.H, W = x.W, Ho = y.H, Wo = y.W;
     const int pad = cfg.downsample_padding ? 1 : 0;
     const int64_t pw = add_param(pre + "conv.weight", {C, C, 3, 3}, 1), pb = add_param(pre + "conv.bias", {C});
-    const int b_bs = scratch(C);
+    if (C % 32 == 0) { wt_off.push_back(pw); wt_cin.push_back(C); wt_cout.push_back(C); }   // transposed planes for the phase data gradient
+    const int b_bs = scratch(C), b_dyS = scratch((int64_t)Ho * Wo * C);
     F([=](Ctx& c) {
         bd_conv3x3_fwd_desc d = {};
         d.B = c.B; d.Hs = H; d.Ws = W; d.Cin = C; d.Cout = C; d.stride = 2; d.pad_t = pad; d.pad_l = pad; d.Ho = Ho; d.Wo = Wo;
@@ -751,10 +766,21 @@ void bd_unet::node_downsample(const std::string& pre, const View& x, const View&
         w.B = c.B; w.Hs = H; w.Ws = W; w.Cin = C; w.Cout = C; w.stride = 2; w.pad_t = pad; w.pad_l = pad; w.Ho = Ho; w.Wo = Wo;
         w.x = VP(c, x); w.ldx = x.ld; w.dy = dy; w.lddy = y.ld; w.dw = c.grads + pw; w.db = c.grads + pb;
         BD_TRY(conv_w(c, w));
+        const int acc = c.ginit[x.buf];
+        c.ginit[x.buf] = 1;
+        if (H == 2 * Ho && W == 2 * Wo && phase_ok(c, Ho, Wo, C, C)) {
+            // by the parity of the input pixel only 4 / 2 / 2 / 1 of the nine taps contribute: four classes on the output grid
+            BD_TRY(split_rows(c, dy, y.ld, (int64_t)c.B * Ho * Wo, C, BP(c, b_dyS)));
+            if (c.dry) return (int)BD_OK;
+            bd_conv3x3_s2_dgrad_desc g = {};
+            g.B = c.B; g.Ho = Ho; g.Wo = Wo; g.Cin = C; g.Cout = C; g.pad = pad;
+            g.dy_split = U16(BP(c, b_dyS)); g.lddy = C; g.wT_split = c.wT_split + 2 * pw;
+            g.dx = GP(c, x); g.lddx = x.ld; g.accumulate = acc;
+            return conv3x3_s2_dgrad_ps(g, c.st);
+        }
         bd_conv3x3_dgrad_desc g = {};
         g.B = c.B; g.Hs = H; g.Ws = W; g.Cin = C; g.Cout = C; g.stride = 2; g.pad_t = pad; g.pad_l = pad; g.Ho = Ho; g.Wo = Wo;
-        g.dy = dy; g.lddy = y.ld; g.w = c.params + pw; g.dx = GP(c, x); g.lddx = x.ld; g.accumulate = c.ginit[x.buf];
-        c.ginit[x.buf] = 1;
+        g.dy = dy; g.lddy = y.ld; g.w = c.params + pw; g.dx = GP(c, x); g.lddx = x.ld; g.accumulate = acc;
         return conv_d(c, g);
     });
 }
@@ -768,7 +794,20 @@ void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y
     // grid) and feeds the stride-1 "same" kernels of conv_ps.hip: forward, weight gradient and (through b_du + 2x2 sums)
     // the data gradient.  Otherwise the upsampling stays folded into the igemm gather.
     const int b_xuS = new_buf((int64_t)4 * H * W * C, 0, R_VALUE), b_dyS = scratch((int64_t)4 * H * W * C);
+    // phase-decomposed path (round 3): x as split planes on the SOURCE grid + the pre-summed tap planes E / E^T of this layer
+    const int b_xS = new_buf((int64_t)H * W * C, 0, R_VALUE);
+    const int b_e = new_buf(0, (int64_t)16 * C * C, R_VALUE), b_et = new_buf(0, (int64_t)16 * C * C, R_VALUE);
+    if (C % 128 == 0) upsw.push_back({pw, C, b_e, b_et});
     F([=](Ctx& c) {
+        if (phase_ok(c, H, W, C, C)) {
+            BD_TRY(split_rows(c, VP(c, x), x.ld, (int64_t)c.B * H * W, C, BP(c, b_xS)));
+            if (c.dry) return (int)BD_OK;
+            bd_upsample_conv_desc d = {};
+            d.B = c.B; d.H = H; d.W = W; d.Cin = C; d.Cout = C;
+            d.x_split = U16(BP(c, b_xS)); d.ldx = C; d.e_split = U16(BP(c, b_e)); d.bias = c.params + pb;
+            d.y = VP(c, y); d.ldy = y.ld;
+            return upsample_conv_fwd(d, c.st);
+        }
         if (ps_ok(c, 2 * H, 2 * W, C, C)) {
             if (!c.dry) BD_TRY(bd_split_rows_ups2(VP(c, x), x.ld, c.B, H, W, C, U16(BP(c, b_xuS)), C, (bd_stream_t)c.st));
             bd_conv3x3_ps_desc d = {};
@@ -787,6 +826,22 @@ void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y
         const float* dy = GP(c, y);
         const int acc = c.ginit[x.buf];
         c.ginit[x.buf] = 1;
+        if (phase_ok(c, H, W, C, C)) {
+            BD_TRY(split_rows(c, dy, y.ld, (int64_t)c.B * 4 * H * W, C, BP(c, b_dyS)));
+            bd_upsample_conv_desc d = {};
+            d.B = c.B; d.H = H; d.W = W; d.Cin = C; d.Cout = C;
+            d.x_split = U16(BP(c, b_xS)); d.ldx = C; d.dy_split = U16(BP(c, b_dyS)); d.lddy = C;
+            d.et_split = U16(BP(c, b_et)); d.dx = GP(c, x); d.lddx = x.ld; d.accumulate = acc;
+            d.dw = c.grads + pw; d.db = c.grads + pb;
+            if (c.dry) {
+                const size_t n = upsample_conv_wgrad_workspace_bytes(d);
+                if (n > c.opws_need) c.opws_need = n;
+                return (int)BD_OK;
+            }
+            d.workspace_bytes = c.opws_bytes;
+            BD_TRY(on_aux(c, [&](hipStream_t st, char* ws) { d.workspace = ws; return upsample_conv_wgrad(d, st); }));
+            return upsample_conv_dgrad(d, c.st);      // 16 taps on dY sampled at stride 2: replaces the fine-grid dgrad + 2x2 sum
+        }
         if (ps_ok(c, 2 * H, 2 * W, C, C)) {
             BD_TRY(split_rows(c, dy, y.ld, (int64_t)c.B * 4 * H * W, C, BP(c, b_dyS)));
             bd_conv3x3_ps_wgrad_desc w = {};
@@ -1154,8 +1209,13 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
     BD_CHECK(aligned16(params), BD_ERR_INVALID, "bd_unet_forward: params must be 16-byte aligned");
     c.params = params; c.x = x; c.ldx = ldx; c.t = t; c.t_stride = t_stride; c.out = out; c.ldo = ldo; c.st = S(stream);
     c.training = training != 0;
-    if (c.w_split)   // split the weights once; forward convs and (same workspace) the backward dgrads read the copy
+    if (c.w_split) {   // split the weights once; forward convs and (same workspace) the backward dgrads read the copy
         BD_TRY(bd_split_bf16(params, (int64_t)wsplit_elems(u), const_cast<uint16_t*>(c.w_split), stream));
+        // pre-summed tap planes of the upsample convolutions (both forward pipelines read them: before the fork)
+        for (const auto& uw : u->upsw)
+            if (upsample_conv_ps_supported(B, 1, 1, uw.C, uw.C))
+                BD_TRY(upsample_weights(params + uw.pw, uw.C, uw.C, bd_unet::U16(u->BP(c, uw.b_e)), bd_unet::U16(u->BP(c, uw.b_et)), c.st));
+    }
     // transposed split planes of the 3x3 conv weights for the backward's data gradients: one launch, needed only in training
     auto transpose_weights = [&](hipStream_t st) -> int {
         if (!training || !c.wT_split || u->wt_off.empty()) return BD_OK;

@@ -302,6 +302,61 @@ def conv3x3_ps_wgrad(x_split, dy_split, B, H, W, Cin, Cout, with_db=False):
     return (dw, db) if with_db else dw
 
 
+def upsample_weights(w):
+    """conv weight [Cout,3,3,Cin] of an Upsample2D layer -> (E planes [Cout,16,Cin], E^T planes [Cin,16,Cout]) as split planes:
+    E[oy][ox] = sum of the taps that read the same source pixel (include/bd_hip.h, phase-decomposed convolutions)."""
+    lib = L.load(); _need_cuda(w)
+    Cout, _, _, Cin = w.shape
+    e = torch.empty(Cout, 16 * Cin // 32, 2, 32, dtype=torch.int16, device=w.device)
+    et = torch.empty(Cin, 16 * Cout // 32, 2, 32, dtype=torch.int16, device=w.device)
+    L.check(lib.bd_upsample_weights(L.ptr(w.contiguous()), Cin, Cout, L.ptr(e), L.ptr(et), L.stream()), "bd_upsample_weights")
+    return e, et
+
+
+def upsample_conv_fwd(x_split, e_split, B, H, W, Cin, Cout, bias=None):
+    """y [B,2H,2W,Cout] = conv3x3(nearest_up2(x)) + bias from the SOURCE-grid split planes of x and the E planes."""
+    lib = L.load(); _need_cuda(x_split, e_split, bias)
+    y = torch.empty(B, 2 * H, 2 * W, Cout, device=x_split.device)
+    d = L.UpsampleConvDesc(B=B, H=H, W=W, Cin=Cin, Cout=Cout, x_split=L.ptr(x_split), ldx=Cin, e_split=L.ptr(e_split), bias=L.ptr(bias),
+                           y=L.ptr(y), ldy=Cout)
+    L.check(lib.bd_upsample_conv_fwd(C.byref(d), L.stream()), "bd_upsample_conv_fwd")
+    return y
+
+
+def upsample_conv_dgrad(dy_split, et_split, B, H, W, Cin, Cout, out=None, accumulate=False):
+    """dx [B,H,W,Cin] of the same layer from the fine-grid split planes of dY [B,2H,2W,Cout] and the E^T planes."""
+    lib = L.load(); _need_cuda(dy_split, et_split)
+    dx = torch.empty(B, H, W, Cin, device=dy_split.device) if out is None else out
+    d = L.UpsampleConvDesc(B=B, H=H, W=W, Cin=Cin, Cout=Cout, dy_split=L.ptr(dy_split), lddy=Cout, et_split=L.ptr(et_split),
+                           dx=L.ptr(dx), lddx=_ld(dx), accumulate=int(accumulate))
+    L.check(lib.bd_upsample_conv_dgrad(C.byref(d), L.stream()), "bd_upsample_conv_dgrad")
+    return dx
+
+
+def upsample_conv_wgrad(x_split, dy_split, B, H, W, Cin, Cout, with_db=False):
+    """dw [Cout,3,3,Cin] (and db) of the same layer from x (source grid) and dY (fine grid), both split planes."""
+    lib = L.load(); _need_cuda(x_split, dy_split)
+    dw = torch.empty(Cout, 3, 3, Cin, device=x_split.device)
+    db = torch.empty(Cout, device=x_split.device) if with_db else None
+    d = L.UpsampleConvDesc(B=B, H=H, W=W, Cin=Cin, Cout=Cout, x_split=L.ptr(x_split), ldx=Cin, dy_split=L.ptr(dy_split), lddy=Cout,
+                           dw=L.ptr(dw), db=L.ptr(db))
+    ws = workspace(lib.bd_upsample_conv_wgrad_workspace_bytes(C.byref(d)), x_split.device, "ups_wgrad")
+    d.workspace = L.ptr(ws); d.workspace_bytes = ws.numel()
+    L.check(lib.bd_upsample_conv_wgrad(C.byref(d), L.stream()), "bd_upsample_conv_wgrad")
+    return (dw, db) if with_db else dw
+
+
+def conv3x3_s2_dgrad_ps(dy_split, wT_split, B, Ho, Wo, Cin, Cout, pad=0, out=None, accumulate=False):
+    """dx [B,2Ho,2Wo,Cin] of a stride-2 3x3 convolution (pad 0 = F.pad(0,1,0,1) + padding 0; 1 = padding 1) from the split planes
+    of dy [B,Ho,Wo,Cout] and the transposed weight planes (split_wT)."""
+    lib = L.load(); _need_cuda(dy_split, wT_split)
+    dx = torch.empty(B, 2 * Ho, 2 * Wo, Cin, device=dy_split.device) if out is None else out
+    d = L.ConvS2DgradDesc(B=B, Ho=Ho, Wo=Wo, Cin=Cin, Cout=Cout, pad=pad, dy_split=L.ptr(dy_split), lddy=Cout, wT_split=L.ptr(wT_split),
+                          dx=L.ptr(dx), lddx=_ld(dx), accumulate=int(accumulate))
+    L.check(lib.bd_conv3x3_s2_dgrad_ps(C.byref(d), L.stream()), "bd_conv3x3_s2_dgrad_ps")
+    return dx
+
+
 def conv3x3_dgrad(dy, w, x_shape, stride=1, pad=1, ups=0, asym=False, mode=0, w_split=None):
     """Returns dx over the conv's own input grid [B, Hs<<ups, Ws<<ups, Cin]."""
     lib = L.load(); _need_cuda(dy, w)

@@ -462,6 +462,42 @@ int bd_prof_reset(void);
 int bd_prof_num_classes(void);
 int bd_prof_get(int cls, const char** name, int64_t* launches, double* total_ms, double* flops, double* bytes);
 
+/* ------------------------------------------------------------------------------------------------
+ * Phase-decomposed convolutions on split planes (round 3, csrc/conv_ph.hip).
+ * Upsample2D (resnet.py:126-161) is y = conv3x3(nearest_up2(x)): every output pixel's 3x3 window covers only 2x2 distinct
+ * source pixels, so with the tap sums E[oy][ox] (bd_upsample_weights) the forward is four 2x2-tap convolutions on the SOURCE
+ * grid (one per output pixel class), the data gradient ONE 16-tap convolution sampling dY at stride 2, and the weight gradient
+ * 16 tap products folded back to the nine taps: 16 instead of 36 tap products per source pixel, same result up to the fp32
+ * rounding of the weight sums.  The data gradient of a stride-2 convolution (Downsample2D, resnet.py:199-208) is the same
+ * construction with 4 / 2 / 2 / 1 taps per input-pixel parity class (bd_conv3x3_s2_dgrad_ps).
+ * All operands are split planes (see above): H, W powers of two, Cin, Cout multiples of 128.
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    int B, H, W, Cin, Cout;                     /* H x W = SOURCE grid; the convolution runs on 2H x 2W            */
+    const uint16_t* x_split; int64_t ldx;       /* source activations [B*H*W, Cin]                 (fwd, wgrad)    */
+    const uint16_t* dy_split; int64_t lddy;     /* output gradient on the fine grid [B*4HW, Cout]  (dgrad, wgrad)  */
+    const uint16_t* e_split;                    /* bd_upsample_weights: E   [Cout][16][Cin]        (fwd)           */
+    const uint16_t* et_split;                   /* bd_upsample_weights: E^T [Cin][16][Cout]        (dgrad)         */
+    const float* bias;                          /* fwd, optional [Cout]                                            */
+    float* y; int64_t ldy;                      /* fwd out [B*4HW, Cout]                                           */
+    float* dx; int64_t lddx; int accumulate;    /* dgrad out [B*HW, Cin], += when accumulate                       */
+    float* dw; float* db;                       /* wgrad out [Cout,3,3,Cin] and (optional) [Cout]                  */
+    void* workspace; size_t workspace_bytes;    /* wgrad: bd_upsample_conv_wgrad_workspace_bytes                   */
+} bd_upsample_conv_desc;
+int bd_upsample_weights(const float* w /* [Cout,3,3,Cin] */, int Cin, int Cout, uint16_t* e_split, uint16_t* et_split, bd_stream_t stream);
+int bd_upsample_conv_fwd(const bd_upsample_conv_desc* d, bd_stream_t stream);
+int bd_upsample_conv_dgrad(const bd_upsample_conv_desc* d, bd_stream_t stream);
+int bd_upsample_conv_wgrad(const bd_upsample_conv_desc* d, bd_stream_t stream);
+size_t bd_upsample_conv_wgrad_workspace_bytes(const bd_upsample_conv_desc* d);
+
+typedef struct {
+    int B, Ho, Wo, Cin, Cout, pad;              /* stride-2 conv: input grid 2Ho x 2Wo; pad 0 = F.pad(0,1,0,1) + padding 0, 1 = padding 1 */
+    const uint16_t* dy_split; int64_t lddy;     /* [B*Ho*Wo, Cout] */
+    const uint16_t* wT_split;                   /* transposed weight planes Wt[ci][9][co] (bd_split_wt) */
+    float* dx; int64_t lddx; int accumulate;    /* [B*4HoWo, Cin] */
+} bd_conv3x3_s2_dgrad_desc;
+int bd_conv3x3_s2_dgrad_ps(const bd_conv3x3_s2_dgrad_desc* d, bd_stream_t stream);
+
 /* What the matrix pipe alone sustains on THIS board, now: v_mfma_f32_32x32x16_bf16 on register operands only (no memory
  * traffic), 2 workgroups of 512 threads per CU, `iters` x 12 MFMAs per wave, launched `launches` times back to back and timed
  * with a hipEvent pair on `stream` (blocks until done).  random_operands = 0: small constant integers (data-independent

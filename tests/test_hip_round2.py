@@ -869,3 +869,67 @@ def test_thin_convs_direct_kernels(gpu, B, H, W, C):
         assert relerr(gw, dw) < 1e-5 and relerr(gb, db) < 1e-5
         gw2, _ = ops.conv3x3_wgrad(xc.cuda(), dy_3.cuda(), mode=mode, with_db=True)
         assert torch.equal(gw, gw2)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 8, 8, 128, 128), (2, 16, 16, 256, 128), (5, 4, 4, 128, 256), (64, 16, 16, 256, 256), (1, 32, 64, 128, 128)])
+def test_upsample_conv_phase_decomposition(gpu, B, H, W, Cin, Cout):
+    """Upsample2D = conv3x3(nearest_up2(x)) (resnet.py:126-161) in its phase-decomposed form (conv_ph.hip: four 2x2-tap convolutions on
+    the source grid / one 16-tap stride-2 sampled data gradient / 16 tap products folded to 9 for the weight gradient) against
+    fp64 F.interpolate + F.conv2d + autograd on the CPU and against the literal split-plane path of round 2 on the upsampled grid.
+    3e-5 relative: the split-bf16 product drops lo*lo (~2^-16 per product), and the phase form multiplies pre-summed taps, i.e. rounds
+    differently from the literal form (both sit ~1e-5 from the fp64 result)."""
+    import torch.nn.functional as F
+    from baddiffusion_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + H * 10 + Cin // 128)
+    x = torch.randn(B, H, W, Cin, generator=g); dy = torch.randn(B, 2 * H, 2 * W, Cout, generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05; bias = torch.randn(Cout, generator=g)
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True); wr = w.double().permute(0, 3, 1, 2).requires_grad_(True)
+    br = bias.double().requires_grad_(True)
+    y = F.conv2d(F.interpolate(xr, scale_factor=2.0, mode="nearest"), wr, br, padding=1)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    y_ref, dx_ref, dw_ref, db_ref = y.permute(0, 2, 3, 1), xr.grad.permute(0, 2, 3, 1), wr.grad.permute(0, 2, 3, 1), br.grad
+    xs, dys = ops.split_rows(x.cuda()), ops.split_rows(dy.cuda())
+    e, et = ops.upsample_weights(w.cuda())
+    got = ops.upsample_conv_fwd(xs, e, B, H, W, Cin, Cout, bias=bias.cuda())
+    assert relerr(got, y_ref) < 3e-5
+    gx = ops.upsample_conv_dgrad(dys, et, B, H, W, Cin, Cout)
+    assert relerr(gx, dx_ref) < 3e-5
+    prev = torch.randn(B, H, W, Cin, generator=g).cuda()
+    acc = ops.upsample_conv_dgrad(dys, et, B, H, W, Cin, Cout, out=prev.clone(), accumulate=True)
+    assert relerr(acc, prev + gx) < 1e-6
+    gw, gb = ops.upsample_conv_wgrad(xs, dys, B, H, W, Cin, Cout, with_db=True)
+    assert relerr(gw, dw_ref) < 3e-5 and relerr(gb, db_ref) < 3e-5
+    gw2, gb2 = ops.upsample_conv_wgrad(xs, dys, B, H, W, Cin, Cout, with_db=True)
+    assert torch.equal(gw, gw2) and torch.equal(gb, gb2)                                  # fixed-order K split
+    # the literal form on the upsampled grid (round 2)
+    xu = ops.split_rows_ups2(x.cuda())
+    lit = ops.conv3x3_ps(xu, ops.split_bf16(w.cuda()), B, 2 * H, 2 * W, Cin, Cout, 1, bias=bias.cuda())
+    assert relerr(got, lit) < 3e-5
+    lit_w = ops.conv3x3_ps_wgrad(xu, dys, B, 2 * H, 2 * W, Cin, Cout)
+    assert relerr(gw, lit_w) < 3e-5
+
+
+@pytest.mark.parametrize("B,Ho,Wo,Cin,Cout,pad", [(3, 8, 8, 128, 128, 0), (2, 4, 16, 256, 128, 1), (64, 16, 16, 128, 128, 0), (4, 8, 8, 128, 256, 1)])
+def test_stride2_conv_dgrad_phase_decomposition(gpu, B, Ho, Wo, Cin, Cout, pad):
+    """data gradient of Downsample2D's stride-2 convolution (resnet.py:199-208; pad 0 = F.pad(0,1,0,1) + padding 0, pad 1 = padding 1)
+    as four parity classes with 4 / 2 / 2 / 1 taps on the output grid, against fp64 autograd and the implicit-GEMM path"""
+    import torch.nn.functional as F
+    from baddiffusion_amd import ops
+    g = torch.Generator().manual_seed(B * 100 + Ho + pad)
+    H, W = 2 * Ho, 2 * Wo
+    x = torch.randn(B, H, W, Cin, generator=g); dy = torch.randn(B, Ho, Wo, Cout, generator=g)
+    w = torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05
+    xr = x.double().permute(0, 3, 1, 2).requires_grad_(True); wr = w.double().permute(0, 3, 1, 2)
+    xin = F.pad(xr, (0, 1, 0, 1)) if pad == 0 else xr
+    y = F.conv2d(xin, wr, None, stride=2, padding=pad)
+    assert tuple(y.shape[-2:]) == (Ho, Wo)
+    y.backward(dy.double().permute(0, 3, 1, 2))
+    dx_ref = xr.grad.permute(0, 2, 3, 1)
+    dys, wt = ops.split_rows(dy.cuda()), ops.split_wT(w.cuda())
+    gx = ops.conv3x3_s2_dgrad_ps(dys, wt, B, Ho, Wo, Cin, Cout, pad=pad)
+    assert relerr(gx, dx_ref) < 3e-5
+    prev = torch.randn(B, H, W, Cin, generator=g).cuda()
+    acc = ops.conv3x3_s2_dgrad_ps(dys, wt, B, Ho, Wo, Cin, Cout, pad=pad, out=prev.clone(), accumulate=True)
+    assert relerr(acc, prev + gx) < 1e-6
+    old = ops.conv3x3_dgrad(dy.cuda(), w.cuda(), (B, H, W, Cin), stride=2, pad=pad, asym=(pad == 0), mode=1)
+    assert relerr(gx, old) < 3e-5
