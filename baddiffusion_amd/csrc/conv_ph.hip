@@ -65,6 +65,48 @@ __device__ __forceinline__ void ph_sync() {
     __builtin_amdgcn_s_barrier();
 }
 
+// y = out_scale * (acc + bias) (+ y) for a wave's 2 x 2 grid of 32x32 tiles; rows optionally scattered to one pixel class of the fine
+// grid.  FULL removes the per-element predicate (behind an exec-masked branch hipcc serialises the stores with s_waitcnt vmcnt(0),
+// DESIGN.md "a compiler trap"); the old values of an accumulating store are loaded first, all in flight.
+template <bool FULL>
+__device__ __forceinline__ void ph_epilogue(const PhParams& p, const ph_floatx16 (&acc)[2][2], int mw, int nw, int li, int h, int yoff) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        long long rowoff[16];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (!FULL && m >= p.M) m = -1;
+            // class pixel (2a+p, 2b+q) of the fine grid: img*4HW + (2a+p)*2W + 2b+q = 4m - 2(m & (W-1)) + p*2W + q
+            const long long row = p.y_fine ? 4ll * m - 2 * (m & (p.W - 1)) + yoff : (long long)m;
+            rowoff[r] = m < 0 ? -1 : row * p.ldy;
+        }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int n = nw + q * 32 + li;
+            const float bv = p.bias ? p.bias[n] : 0.f;
+            float v[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) v[r] = (acc[i][q][r] + bv) * p.out_scale;
+            if (p.accumulate) {
+                float old[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) old[r] = *((FULL || rowoff[r] >= 0) ? p.y + rowoff[r] + n : kPhZero);   // branch-free
+#pragma unroll
+                for (int r = 0; r < 16; ++r) v[r] += old[r];
+            }
+            if (FULL) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) p.y[rowoff[r] + n] = v[r];
+            } else {
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    if (rowoff[r] >= 0) p.y[rowoff[r] + n] = v[r];
+            }
+        }
+    }
+}
+
 // 256 x 128 tile, 8 waves of 64 x 64, three LDS stages, one barrier per K chunk (one tap x 32 channels): conv_ps_kernel's
 // main loop with (i) a tap TABLE per class instead of the 3 x 3 cursor, (ii) the A rows optionally taken from the fine grid at
 // stride 2, (iii) the output rows optionally scattered to one pixel class of the fine grid, (iv) any chunk count.
@@ -119,11 +161,19 @@ __global__ __launch_bounds__(PH_NT, 2) void conv_ph_kernel(PhParams p) {
     const int pix_bytes = (int)p.lda * 4;
     const int nchunks = ntaps * (p.C >> 5);
 
+    // the tap table lives in the lanes of two VGPRs (lane t = tap t) and is fetched with v_readlane: table reads from the kernel
+    // arguments inside the loop are s_load + s_waitcnt lgkmcnt(0), which also drains the LDS fragment reads (184 -> TFLOP/s)
+    int v_aoff, v_woff;
+    {
+        const int t = lane & (PH_MAXT - 1);
+        v_aoff = (pc.oy[t] * Wf + pc.ox[t]) * pix_bytes;
+        v_woff = pc.wt[t] * p.C * 4;
+    }
     // cursor of the next chunk to issue (wave-uniform): tap inner, 32-channel block outer
     int q_t = 0, q_cb = 0;
     auto issue = [&](char* stage) {
-        const int aoff = (pc.oy[q_t] * Wf + pc.ox[q_t]) * pix_bytes + q_cb * 128;
-        const int woff = (pc.wt[q_t] * p.C + q_cb * 32) * 4;
+        const int aoff = __builtin_amdgcn_readlane(v_aoff, q_t) + q_cb * 128;
+        const int woff = __builtin_amdgcn_readlane(v_woff, q_t) + q_cb * 128;
         const int bit = 1 << q_t;
 #pragma unroll
         for (int j = 0; j < 4; ++j) ph_dma16((vm[j] & bit) ? ap[j] + aoff : reinterpret_cast<const char*>(kPhZero), stage + (wave + 8 * j) * 1024);
@@ -187,35 +237,8 @@ __global__ __launch_bounds__(PH_NT, 2) void conv_ph_kernel(PhParams p) {
     // ---- epilogue: lane holds column n = li of rows (r&3) + 8*(r>>2) + 4*h of every 32x32 tile
     const int mw = m0 + wm * 64, nw = n0 + wn * 64;
     const int yoff = pc.p * 2 * p.W + pc.q;
-#pragma unroll
-    for (int i = 0; i < 2; ++i) {
-        long long rowoff[16];
-        bool rok[16];
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-            rok[r] = m < p.M;
-            // class pixel (2a+p, 2b+q) of the fine grid: img*4HW + (2a+p)*2W + 2b+q = 4m - 2(m & (W-1)) + p*2W + q
-            const long long row = p.y_fine ? 4ll * m - 2 * (m & (p.W - 1)) + yoff : (long long)m;
-            rowoff[r] = row * p.ldy;
-        }
-#pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int n = nw + q * 32 + li;
-            const float bv = p.bias ? p.bias[n] : 0.f;
-            float old[16];
-            if (p.accumulate) {
-#pragma unroll
-                for (int r = 0; r < 16; ++r) old[r] = rok[r] ? p.y[rowoff[r] + n] : 0.f;
-            }
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                float v = (acc[i][q][r] + bv) * p.out_scale;
-                if (p.accumulate) v += old[r];
-                if (rok[r]) p.y[rowoff[r] + n] = v;
-            }
-        }
-    }
+    if (mw + 64 <= p.M) ph_epilogue<true>(p, acc, mw, nw, li, h, yoff);     // wave-uniform: whole sub-tile inside M, no predicates
+    else ph_epilogue<false>(p, acc, mw, nw, li, h, yoff);
 }
 
 // ---- weights of the upsample convolution ----------------------------------------------------------------------------------

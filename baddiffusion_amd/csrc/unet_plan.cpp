@@ -342,9 +342,12 @@ struct bd_unet {
                conv3x3_ps_supported(B, H, W, Cout, Cin) && conv3x3_ps_wgrad_supported(B, H, W, Cin, Cout);
     }
     // phase-decomposed forms (conv_ph.hip): the upsample convolution on its SOURCE grid, the stride-2 data gradient by parity class
-    bool phase_ok(const Ctx& c, int H, int W, int Cin, int Cout) const {
+    // `min_wgs`: the launch must offer at least that many 256 x 128 workgroups (classes x tiles on the batch the workspace is laid
+    // out for) -- a one-class 16-tap data gradient of an 8 x 8 source grid is 64 long workgroups on 256 CUs and loses to the literal form
+    bool phase_ok(const Ctx& c, int H, int W, int Cin, int Cout, int classes = 4, int min_wgs = 128) const {
         const int B = c.LB > 0 ? c.LB : c.B;
-        return cfg.compute_mode == BD_MODE_BF16X3 && (c.dry || c.w_split) && upsample_conv_ps_supported(B, H, W, Cin, Cout);
+        const long long wgs = (long long)classes * (((long long)B * H * W + 255) / 256) * (Cout / 128);
+        return cfg.compute_mode == BD_MODE_BF16X3 && (c.dry || c.w_split) && upsample_conv_ps_supported(B, H, W, Cin, Cout) && wgs >= min_wgs;
     }
     int conv_pw(Ctx& c, bd_conv3x3_ps_wgrad_desc& d) const {
         d.workspace_bytes = c.opws_bytes;
@@ -833,14 +836,22 @@ void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y
             d.x_split = U16(BP(c, b_xS)); d.ldx = C; d.dy_split = U16(BP(c, b_dyS)); d.lddy = C;
             d.et_split = U16(BP(c, b_et)); d.dx = GP(c, x); d.lddx = x.ld; d.accumulate = acc;
             d.dw = c.grads + pw; d.db = c.grads + pb;
+            const bool ph_d = phase_ok(c, H, W, C, C, 1);     // ONE class of 16 taps: needs >= 128 tiles of its own
             if (c.dry) {
                 const size_t n = upsample_conv_wgrad_workspace_bytes(d);
                 if (n > c.opws_need) c.opws_need = n;
+                if (!ph_d) note_conv(c);
                 return (int)BD_OK;
             }
             d.workspace_bytes = c.opws_bytes;
             BD_TRY(on_aux(c, [&](hipStream_t st, char* ws) { d.workspace = ws; return upsample_conv_wgrad(d, st); }));
-            return upsample_conv_dgrad(d, c.st);      // 16 taps on dY sampled at stride 2: replaces the fine-grid dgrad + 2x2 sum
+            if (ph_d) return upsample_conv_dgrad(d, c.st);      // 16 taps on dY sampled at stride 2: replaces the fine-grid dgrad + 2x2 sum
+            bd_conv3x3_ps_desc g = {};                           // literal data gradient on the fine grid + 2x2 sums
+            g.B = c.B; g.H = 2 * H; g.W = 2 * W; g.K = C; g.N = C; g.direction = -1;
+            g.x_split = U16(BP(c, b_dyS)); g.ldx = C; g.w_split = c.wT_split + 2 * pw; g.out_scale = 1.f;
+            g.y = BP(c, b_du); g.ldy = C;
+            BD_TRY(conv_p(c, g));
+            return bd_sum2x2(BP(c, b_du), C, GP(c, x), x.ld, c.B, H, W, C, acc, (bd_stream_t)c.st);
         }
         if (ps_ok(c, 2 * H, 2 * W, C, C)) {
             BD_TRY(split_rows(c, dy, y.ld, (int64_t)c.B * 4 * H * W, C, BP(c, b_dyS)));
