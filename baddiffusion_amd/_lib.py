@@ -169,6 +169,7 @@ SIGNATURES = {
     "bd_upsample_conv_dgrad": (i32, [C.POINTER(UpsampleConvDesc), vp]),
     "bd_upsample_conv_wgrad": (i32, [C.POINTER(UpsampleConvDesc), vp]),
     "bd_upsample_conv_wgrad_workspace_bytes": (sz, [C.POINTER(UpsampleConvDesc)]),
+    "bd_upsample_conv_dgrad_workspace_bytes": (sz, [C.POINTER(UpsampleConvDesc)]),
     "bd_conv3x3_s2_dgrad_ps": (i32, [C.POINTER(ConvS2DgradDesc), vp]),
     "bd_conv3x3_ps_wgrad": (i32, [C.POINTER(ConvPsWgradDesc), vp]),
     "bd_conv3x3_ps_wgrad_workspace_bytes": (sz, [C.POINTER(ConvPsWgradDesc)]),

@@ -50,6 +50,8 @@ struct PhParams {
     int a_fine, y_fine, accumulate;
     float out_scale;
     int ncls;
+    int tsplit;          // > 1: ONE class whose taps are dealt to `tsplit` workgroups per tile (blockIdx.y = tap group); every group
+    float* partial;      //      leaves a partial tile in partial[group][M][N], ph_tsplit_reduce folds them in fixed order
     PhClass cls[4];
 };
 
@@ -117,9 +119,11 @@ __global__ __launch_bounds__(PH_NT, 2) void conv_ph_kernel(PhParams p) {
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
     const int li = lane & 31, h = lane >> 5;
-    const int cls = blockIdx.y;
+    const int grp = p.tsplit > 1 ? blockIdx.y : 0;            // tap group of a tap-split launch (single class)
+    const int cls = p.tsplit > 1 ? 0 : blockIdx.y;
     const PhClass& pc = p.cls[cls];
-    const int ntaps = pc.ntaps;
+    const int ntaps = p.tsplit > 1 ? pc.ntaps / p.tsplit : pc.ntaps;
+    const int tbase = grp * ntaps;
 
     int tm, tn;
     {
@@ -143,7 +147,7 @@ __global__ __launch_bounds__(PH_NT, 2) void conv_ph_kernel(PhParams p) {
         const int gy = p.a_fine ? 2 * by : by, gx = p.a_fine ? 2 * bx : bx;      // position of the row's origin on A's grid
         int mask = 0;
         for (int t = 0; t < ntaps; ++t) {
-            const int yy = gy + pc.oy[t], xx = gx + pc.ox[t];
+            const int yy = gy + pc.oy[tbase + t], xx = gx + pc.ox[tbase + t];
             if ((unsigned)yy < (unsigned)Hv && (unsigned)xx < (unsigned)Wv) mask |= 1 << t;
         }
         vm[j] = m < p.M ? mask : 0;
@@ -172,8 +176,8 @@ __global__ __launch_bounds__(PH_NT, 2) void conv_ph_kernel(PhParams p) {
     // cursor of the next chunk to issue (wave-uniform): tap inner, 32-channel block outer
     int q_t = 0, q_cb = 0;
     auto issue = [&](char* stage) {
-        const int aoff = __builtin_amdgcn_readlane(v_aoff, q_t) + q_cb * 128;
-        const int woff = __builtin_amdgcn_readlane(v_woff, q_t) + q_cb * 128;
+        const int aoff = __builtin_amdgcn_readlane(v_aoff, tbase + q_t) + q_cb * 128;
+        const int woff = __builtin_amdgcn_readlane(v_woff, tbase + q_t) + q_cb * 128;
         const int bit = 1 << q_t;
 #pragma unroll
         for (int j = 0; j < 4; ++j) ph_dma16((vm[j] & bit) ? ap[j] + aoff : reinterpret_cast<const char*>(kPhZero), stage + (wave + 8 * j) * 1024);
@@ -224,21 +228,58 @@ __global__ __launch_bounds__(PH_NT, 2) void conv_ph_kernel(PhParams p) {
     };
 
     // ring of three stages, any chunk count >= 1: chunk c+2 is issued behind the barrier that retires chunk c-1's stage
-    char* s0 = smem; char* s1 = smem + PH_STAGE_BYTES; char* s2 = smem + 2 * PH_STAGE_BYTES;
+    // (three chunks per trip with the stage addresses as compile-time offsets: a rotating pointer triple makes every fragment
+    //  address a run-time VALU add)
+    char* const s0 = smem; char* const s1 = smem + PH_STAGE_BYTES; char* const s2 = smem + 2 * PH_STAGE_BYTES;
+    auto step = [&](const char* cur, char* nxt, int c) {
+        if (c + 1 < nchunks) ph_sync<6>(); else ph_sync<0>();
+        if (c + 2 < nchunks) issue(nxt);
+        compute(cur);
+    };
     issue(s0);
     if (nchunks > 1) issue(s1);
-    for (int c = 0; c < nchunks; ++c) {
-        if (c + 1 < nchunks) ph_sync<6>(); else ph_sync<0>();
-        if (c + 2 < nchunks) issue(s2);
-        compute(s0);
-        char* t = s0; s0 = s1; s1 = s2; s2 = t;
+    for (int c = 0; c < nchunks; c += 3) {
+        step(s0, s2, c);
+        if (c + 1 < nchunks) step(s1, s0, c + 1);
+        if (c + 2 < nchunks) step(s2, s1, c + 2);
     }
 
     // ---- epilogue: lane holds column n = li of rows (r&3) + 8*(r>>2) + 4*h of every 32x32 tile
     const int mw = m0 + wm * 64, nw = n0 + wn * 64;
     const int yoff = pc.p * 2 * p.W + pc.q;
+    if (p.tsplit > 1) {      // partial tile of this tap group: plain rows, no bias / scale / accumulate (the fold applies them)
+        float* out = p.partial + (long long)grp * p.M * p.N;
+#pragma unroll
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int m = mw + i * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (m < p.M) out[(long long)m * p.N + nw + q * 32 + li] = acc[i][q][r];
+                }
+        return;
+    }
     if (mw + 64 <= p.M) ph_epilogue<true>(p, acc, mw, nw, li, h, yoff);     // wave-uniform: whole sub-tile inside M, no predicates
     else ph_epilogue<false>(p, acc, mw, nw, li, h, yoff);
+}
+
+// fold of a tap-split launch: y[m][n] (+)= out_scale * sum_g partial[g][m][n], fixed order, float4 per thread (N % 4 == 0)
+__global__ __launch_bounds__(256) void ph_tsplit_reduce(const float* __restrict__ part, int groups, long long mn, int N, float* __restrict__ y,
+                                                      long long ldy, float out_scale, int accumulate) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (4 * i >= mn) return;
+    float4 a = *reinterpret_cast<const float4*>(part + 4 * i);
+    for (int g = 1; g < groups; ++g) {
+        const float4 b = *reinterpret_cast<const float4*>(part + (long long)g * mn + 4 * i);
+        a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w;
+    }
+    const long long m = (4 * i) / N;
+    const int n = (int)(4 * i - m * N);
+    float4* dst = reinterpret_cast<float4*>(y + m * ldy + n);
+    a.x *= out_scale; a.y *= out_scale; a.z *= out_scale; a.w *= out_scale;
+    if (accumulate) { const float4 o = *dst; a.x += o.x; a.y += o.y; a.z += o.z; a.w += o.w; }
+    *dst = a;
 }
 
 // ---- weights of the upsample convolution ----------------------------------------------------------------------------------
@@ -329,10 +370,29 @@ bool upsample_conv_ps_supported(int B, int H, int W, int Cin, int Cout) {
 
 static int ph_launch(PhParams& p, hipStream_t st, const char* what) {
     p.tiles_m = (int)cdiv((long long)p.M, PH_BM); p.tiles_n = p.N / PH_BN;
-    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)p.ncls), block(PH_NT);
+    const dim3 grid((unsigned)(p.tiles_m * p.tiles_n), (unsigned)(p.tsplit > 1 ? p.tsplit : p.ncls)), block(PH_NT);
     hipLaunchKernelGGL(conv_ph_kernel, grid, block, 0, st, p);
     BD_LAUNCH_CHECK(what);
+    if (p.tsplit > 1) {
+        const long long mn = (long long)p.M * p.N;
+        hipLaunchKernelGGL(ph_tsplit_reduce, dim3((unsigned)cdiv(mn / 4, 256)), dim3(256), 0, st, p.partial, p.tsplit, mn, p.N, p.y, p.ldy,
+                           p.out_scale, p.accumulate);
+        BD_LAUNCH_CHECK("ph_tsplit_reduce");
+    }
     return BD_OK;
+}
+// tiles of a one-class launch on this device's CUs: below half a wave of workgroups the 16 taps are dealt to 4 groups
+static int ph_tap_groups(long long M, int N) {
+    static const int cus = [] {
+        int dev = 0, n = 256;
+        if (hipGetDevice(&dev) == hipSuccess) (void)hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev);
+        return n;
+    }();
+    return cdiv(M, PH_BM) * (N / PH_BN) * 2 <= cus ? 4 : 1;
+}
+size_t upsample_conv_dgrad_workspace_bytes(const bd_upsample_conv_desc& d) {
+    const long long M = (long long)d.B * d.H * d.W;
+    return ph_tap_groups(M, d.Cin) > 1 ? (size_t)4 * M * d.Cin * sizeof(float) : 0;
 }
 
 static int ph_common(PhParams& p, int B, int H, int W, int C, int N, const void* a, long long lda, const void* w, float* y, long long ldy,
@@ -387,6 +447,11 @@ int upsample_conv_dgrad(const bd_upsample_conv_desc& d, hipStream_t st) {
     PhClass& k = p.cls[0];
     k.p = k.q = 0; k.ntaps = 16;
     for (int t = 0; t < 16; ++t) { k.oy[t] = t / 4 - 1; k.ox[t] = t % 4 - 1; k.wt[t] = t; }
+    if (ph_tap_groups(p.M, p.N) > 1) {     // few tiles: four workgroups per tile, four taps each, + a fixed-order fold
+        const size_t need = upsample_conv_dgrad_workspace_bytes(d);
+        BD_CHECK(d.workspace && d.workspace_bytes >= need, BD_ERR_WORKSPACE, "bd_upsample_conv_dgrad: workspace %zu < %zu", d.workspace_bytes, need);
+        p.tsplit = 4; p.partial = reinterpret_cast<float*>(d.workspace);
+    }
     const int rec = prof_on() ? prof_begin("conv_ph_ups_dgrad", 2.0 * d.B * 4.0 * d.H * d.W * d.Cout * 9.0 * d.Cin,
                                            4.0 * d.B * d.H * d.W * (d.Cin + 4.0 * d.Cout) + 36.0 * d.Cin * d.Cout, st) : -1;
     const int rc = ph_launch(p, st, "conv_ph (upsample dgrad)");
@@ -434,6 +499,9 @@ extern "C" int bd_upsample_weights(const float* w, int Cin, int Cout, uint16_t* 
 extern "C" int bd_upsample_conv_fwd(const bd_upsample_conv_desc* d, bd_stream_t s) {
     BD_CHECK(d, BD_ERR_INVALID, "bd_upsample_conv_fwd: null descriptor");
     return bd::upsample_conv_fwd(*d, bd::S(s));
+}
+extern "C" size_t bd_upsample_conv_dgrad_workspace_bytes(const bd_upsample_conv_desc* d) {
+    return d ? bd::upsample_conv_dgrad_workspace_bytes(*d) : 0;
 }
 extern "C" int bd_upsample_conv_dgrad(const bd_upsample_conv_desc* d, bd_stream_t s) {
     BD_CHECK(d, BD_ERR_INVALID, "bd_upsample_conv_dgrad: null descriptor");

@@ -35,6 +35,7 @@ int upsample_conv_fwd(const bd_upsample_conv_desc& d, hipStream_t st);
 int upsample_conv_dgrad(const bd_upsample_conv_desc& d, hipStream_t st);
 int upsample_conv_wgrad(const bd_upsample_conv_desc& d, hipStream_t st);             // conv_ps.hip (PHASE form of the weight gradient)
 size_t upsample_conv_wgrad_workspace_bytes(const bd_upsample_conv_desc& d);
+size_t upsample_conv_dgrad_workspace_bytes(const bd_upsample_conv_desc& d);
 bool upsample_conv_ps_supported(int B, int H, int W, int Cin, int Cout);
 int conv3x3_s2_dgrad_ps(const bd_conv3x3_s2_dgrad_desc& d, hipStream_t st);
 int attn_fwd(const bd_attn_fwd_desc& d, hipStream_t st);                             // attn.hip
@@ -836,16 +837,22 @@ void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y
             d.x_split = U16(BP(c, b_xS)); d.ldx = C; d.dy_split = U16(BP(c, b_dyS)); d.lddy = C;
             d.et_split = U16(BP(c, b_et)); d.dx = GP(c, x); d.lddx = x.ld; d.accumulate = acc;
             d.dw = c.grads + pw; d.db = c.grads + pb;
-            const bool ph_d = phase_ok(c, H, W, C, C, 1);     // ONE class of 16 taps: needs >= 128 tiles of its own
+            // ONE class of 16 taps: >= 128 tiles of its own, or (taps dealt to four workgroups per tile) >= 32
+            const bool ph_d = phase_ok(c, H, W, C, C, upsample_conv_dgrad_workspace_bytes(d) ? 4 : 1);
             if (c.dry) {
-                const size_t n = upsample_conv_wgrad_workspace_bytes(d);
+                size_t n = upsample_conv_wgrad_workspace_bytes(d);
+                if (n > c.opws_need) c.opws_need = n;
+                n = upsample_conv_dgrad_workspace_bytes(d);
                 if (n > c.opws_need) c.opws_need = n;
                 if (!ph_d) note_conv(c);
                 return (int)BD_OK;
             }
             d.workspace_bytes = c.opws_bytes;
             BD_TRY(on_aux(c, [&](hipStream_t st, char* ws) { d.workspace = ws; return upsample_conv_wgrad(d, st); }));
-            if (ph_d) return upsample_conv_dgrad(d, c.st);      // 16 taps on dY sampled at stride 2: replaces the fine-grid dgrad + 2x2 sum
+            if (ph_d) {      // 16 taps on dY sampled at stride 2: replaces the fine-grid dgrad + 2x2 sum
+                d.workspace = c.opws;
+                return upsample_conv_dgrad(d, c.st);
+            }
             bd_conv3x3_ps_desc g = {};                           // literal data gradient on the fine grid + 2x2 sums
             g.B = c.B; g.H = 2 * H; g.W = 2 * W; g.K = C; g.N = C; g.direction = -1;
             g.x_split = U16(BP(c, b_dyS)); g.ldx = C; g.w_split = c.wT_split + 2 * pw; g.out_scale = 1.f;
@@ -1147,6 +1154,7 @@ extern "C" int bd_unet_stream_wait_aux(bd_unet* u, bd_stream_t stream) {
 }
 extern "C" int bd_unet_set_compute_mode(bd_unet* u, int mode) {
     BD_CHECK(u && (mode == BD_MODE_F32 || mode == BD_MODE_BF16X3), BD_ERR_INVALID, "bd_unet_set_compute_mode: bad arguments");
+    if (u->cfg.compute_mode != mode) u->lay_B = -1;   // the op-workspace bound depends on which kernels the mode selects: lay out again
     u->cfg.compute_mode = mode;
     return BD_OK;
 }

@@ -329,6 +329,8 @@ def upsample_conv_dgrad(dy_split, et_split, B, H, W, Cin, Cout, out=None, accumu
     dx = torch.empty(B, H, W, Cin, device=dy_split.device) if out is None else out
     d = L.UpsampleConvDesc(B=B, H=H, W=W, Cin=Cin, Cout=Cout, dy_split=L.ptr(dy_split), lddy=Cout, et_split=L.ptr(et_split),
                            dx=L.ptr(dx), lddx=_ld(dx), accumulate=int(accumulate))
+    ws = workspace(lib.bd_upsample_conv_dgrad_workspace_bytes(C.byref(d)), dy_split.device, "ups_dgrad")
+    d.workspace = L.ptr(ws); d.workspace_bytes = ws.numel()
     L.check(lib.bd_upsample_conv_dgrad(C.byref(d), L.stream()), "bd_upsample_conv_dgrad")
     return dx
 

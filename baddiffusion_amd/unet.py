@@ -186,6 +186,8 @@ class UNet2DModel(nn.Module):
     def set_compute_mode(self, mode):
         """'f32' (exact fp32 MFMA) or 'bf16x3' (split-bf16, ~2^-16 relative per product, 3 MFMAs on the bf16 pipe)."""
         L.check(self._lib.bd_unet_set_compute_mode(self._plan, COMPUTE_MODES[mode]), "bd_unet_set_compute_mode")
+        if getattr(self, "compute_mode", mode) != mode:
+            self._ws_pool = {}        # the workspace bound depends on which kernels the mode selects: pooled buffers may be too small
         self.compute_mode = mode
         return self
 

@@ -482,13 +482,14 @@ typedef struct {
     float* y; int64_t ldy;                      /* fwd out [B*4HW, Cout]                                           */
     float* dx; int64_t lddx; int accumulate;    /* dgrad out [B*HW, Cin], += when accumulate                       */
     float* dw; float* db;                       /* wgrad out [Cout,3,3,Cin] and (optional) [Cout]                  */
-    void* workspace; size_t workspace_bytes;    /* wgrad: bd_upsample_conv_wgrad_workspace_bytes                   */
+    void* workspace; size_t workspace_bytes;    /* wgrad / dgrad: bd_upsample_conv_{wgrad,dgrad}_workspace_bytes   */
 } bd_upsample_conv_desc;
 int bd_upsample_weights(const float* w /* [Cout,3,3,Cin] */, int Cin, int Cout, uint16_t* e_split, uint16_t* et_split, bd_stream_t stream);
 int bd_upsample_conv_fwd(const bd_upsample_conv_desc* d, bd_stream_t stream);
 int bd_upsample_conv_dgrad(const bd_upsample_conv_desc* d, bd_stream_t stream);
 int bd_upsample_conv_wgrad(const bd_upsample_conv_desc* d, bd_stream_t stream);
 size_t bd_upsample_conv_wgrad_workspace_bytes(const bd_upsample_conv_desc* d);
+size_t bd_upsample_conv_dgrad_workspace_bytes(const bd_upsample_conv_desc* d);   /* 0 unless the grid is small (taps dealt to 4 workgroups per tile) */
 
 typedef struct {
     int B, Ho, Wo, Cin, Cout, pad;              /* stride-2 conv: input grid 2Ho x 2Wo; pad 0 = F.pad(0,1,0,1) + padding 0, 1 = padding 1 */
