@@ -80,7 +80,7 @@ class UNet2DModel(nn.Module):
                  block_out_channels=(224, 448, 672, 896), layers_per_block=2, mid_block_scale_factor=1,
                  downsample_padding=1, act_fn="silu", attention_head_dim=8, norm_num_groups=32, norm_eps=1e-5,
                  resnet_time_scale_shift="default", add_attention=True, class_embed_type=None, num_class_embeds=None,
-                 max_chunk=512, compute_mode=None, **unused):
+                 max_chunk=2048, compute_mode=None, **unused):
         super().__init__()
         # ---- loud failures for what the reference class supports but BadDiffusion never uses -------------
         if len(down_block_types) != len(up_block_types):
@@ -119,7 +119,7 @@ class UNet2DModel(nn.Module):
             attention_head_dim=attention_head_dim, norm_num_groups=norm_num_groups, norm_eps=norm_eps,
             resnet_time_scale_shift=resnet_time_scale_shift, add_attention=add_attention,
             class_embed_type=class_embed_type, num_class_embeds=num_class_embeds)
-        self.max_chunk = int(max_chunk)
+        self.max_chunk = int(os.environ.get("BD_MAX_CHUNK", max_chunk))     # inference chunk (samples are independent); BD_MAX_CHUNK = A/B knob
 
         lib = L.load()
         c = L.UnetConfig()
