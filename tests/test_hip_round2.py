@@ -871,7 +871,8 @@ def test_thin_convs_direct_kernels(gpu, B, H, W, C):
         assert torch.equal(gw, gw2)
 
 
-@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 8, 8, 128, 128), (2, 16, 16, 256, 128), (5, 4, 4, 128, 256), (64, 16, 16, 256, 256), (1, 32, 64, 128, 128)])
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(3, 8, 8, 128, 128), (2, 16, 16, 256, 128), (5, 4, 4, 128, 256), (64, 16, 16, 256, 256), (1, 32, 64, 128, 128),
+                                             (2, 8, 8, 512, 512), (1, 2, 2, 128, 128)])
 def test_upsample_conv_phase_decomposition(gpu, B, H, W, Cin, Cout):
     """Upsample2D = conv3x3(nearest_up2(x)) (resnet.py:126-161) in its phase-decomposed form (conv_ph.hip: four 2x2-tap convolutions on
     the source grid / one 16-tap stride-2 sampled data gradient / 16 tap products folded to 9 for the weight gradient) against
@@ -909,7 +910,8 @@ def test_upsample_conv_phase_decomposition(gpu, B, H, W, Cin, Cout):
     assert relerr(gw, lit_w) < 3e-5
 
 
-@pytest.mark.parametrize("B,Ho,Wo,Cin,Cout,pad", [(3, 8, 8, 128, 128, 0), (2, 4, 16, 256, 128, 1), (64, 16, 16, 128, 128, 0), (4, 8, 8, 128, 256, 1)])
+@pytest.mark.parametrize("B,Ho,Wo,Cin,Cout,pad", [(3, 8, 8, 128, 128, 0), (2, 4, 16, 256, 128, 1), (64, 16, 16, 128, 128, 0), (4, 8, 8, 128, 256, 1),
+                                                  (2, 4, 4, 512, 512, 0), (1, 1, 1, 128, 128, 1)])
 def test_stride2_conv_dgrad_phase_decomposition(gpu, B, Ho, Wo, Cin, Cout, pad):
     """data gradient of Downsample2D's stride-2 convolution (resnet.py:199-208; pad 0 = F.pad(0,1,0,1) + padding 0, pad 1 = padding 1)
     as four parity classes with 4 / 2 / 2 / 1 taps on the output grid, against fp64 autograd and the implicit-GEMM path"""
