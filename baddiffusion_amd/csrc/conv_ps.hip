@@ -282,6 +282,168 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps_kernel(PsParams p) {
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
+// Round 3: the same 256 x 128 tile with the three VERTICAL taps of a column shift served from ONE LDS window.
+// The tile's pixels are consecutive, so the A tiles of taps (ky, kx), ky = 0..2, are the same rows shifted by W pixels: one window
+// of 256 + 2W rows (the tile plus one image row above and below) is DMA'd once per (32-channel block, kx) and the three ky taps read
+// it at row offsets 0 / W / 2W -- a constant byte offset, and (W/2) % 8 == 0 keeps the bank swizzle of a row unchanged.  Rows above /
+// below the image and columns shifted out of it read the zero page as before: no masks, no VALU in the loop.  L2 -> LDS bytes per
+// channel block: 3 x 40 KB + 9 x 16 KB = 264 KB instead of 9 x 48 KB = 432 KB.  W in {16, 32} (window <= 320 rows), K order = channel
+// block outer, kx, ky inner (another fp32 summation order than conv_ps_kernel: same products).
+// LDS: two A windows (2 x 40 KB) + a ring of three weight chunks (3 x 16 KB) = 128 KB.
+constexpr int PS3_WIN_ROWS = 320, PS3_A_BYTES = PS3_WIN_ROWS * 128, PS3_B_BYTES = 128 * 128;
+constexpr int PS3_LDS_BYTES = 2 * PS3_A_BYTES + 3 * PS3_B_BYTES;
+
+template <int EPI>
+__global__ __launch_bounds__(PS_NT, 2) void conv_ps3_kernel(PsParams p) {
+    __shared__ __attribute__((aligned(128))) char smem[PS3_LDS_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+    int tm, tn;
+    {
+        const unsigned L = blockIdx.x, T = gridDim.x, q = T >> 3;
+        const unsigned j = L < (q << 3) ? (L & 7) * q + (L >> 3) : L;
+        tm = j / p.tiles_n;
+        tn = j - tm * p.tiles_n;
+    }
+    const int m0 = tm * PS_BM, n0 = tn * PS_BN;
+
+    // ---- A window: wave w moves row groups (8 rows = one 1-KiB DMA) w, w+8, .., w+32 of the 320-row window; window row wr is
+    // pixel m0 - W + wr.  Per row: validity of the image row, and of the three column shifts.
+    const int dr = lane >> 3, ps = lane & 7;
+    const char* ap[5];
+    int vm[5];
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+        const int wr = (wave + 8 * j) * 8 + dr;
+        const int m = m0 - p.W + wr;                         // may be < 0 or past the image: masked below
+        const int x = m & (p.W - 1);
+        const int yrel = (wr >> p.lw) - 1;                   // image row relative to the tile's first row
+        const int y0 = (m0 >> p.lw) & (p.H - 1);
+        const int yy = y0 + yrel;
+        int mask = 0;
+        if ((unsigned)yy < (unsigned)p.H && wr < PS_BM + 2 * p.W) {      // (tiles never straddle images: H*W % 256 == 0, host-checked)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                if ((unsigned)(x + p.sign * (kx - 1)) < (unsigned)p.W) mask |= 1 << kx;
+        }
+        vm[j] = mask;
+        ap[j] = p.a + (long long)m * p.lda * 4 + ((ps ^ ps_swz(wr)) << 4);
+    }
+    const char* wp[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int r = (wave + 8 * j) * 8 + dr;
+        int n = n0 + r;
+        if (n >= p.N) n = p.N - 1;
+        wp[j] = p.w + (long long)n * 36 * p.C + ((ps ^ ps_swz(r)) << 4);
+    }
+    const int pix_bytes = (int)p.lda * 4;
+    const int ngroups = 3 * (p.C >> 5);          // (channel block, kx)
+    const int nchunks = 3 * ngroups;
+
+    // cursors (wave-uniform): next A group (cb, kx), next weight chunk (cb, kx, ky)
+    int ga_kx = 0, ga_cb = 0;
+    auto issue_a = [&](char* win) {
+        const int aoff = p.sign * (ga_kx - 1) * pix_bytes + ga_cb * 128;
+        const int bit = 1 << ga_kx;
+#pragma unroll
+        for (int j = 0; j < 5; ++j) ps_dma16((vm[j] & bit) ? ap[j] + aoff : reinterpret_cast<const char*>(kPsZero), win + (wave + 8 * j) * 1024);
+        if (++ga_kx == 3) { ga_kx = 0; ++ga_cb; }
+    };
+    int gb_ky = 0, gb_kx = 0, gb_cb = 0;
+    auto issue_b = [&](char* slot) {
+        const int woff = ((gb_ky * 3 + gb_kx) * p.C + gb_cb * 32) * 4;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) ps_dma16(wp[j] + woff, slot + (wave + 8 * j) * 1024);
+        if (++gb_ky == 3) { gb_ky = 0; if (++gb_kx == 3) { gb_kx = 0; ++gb_cb; } }
+    };
+
+    int foff[2][2];
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) foff[s][pl] = li * 128 + (((pl * 4 + s * 2 + h) ^ ps_swz(li)) << 4);
+    const int abase = wm * 64 * 128, bbase = wn * 64 * 128;
+    // vertical tap ky of the forward gather reads window rows r + ky*W; the data-gradient gather (sign -1) mirrors it
+    const int wrow_bytes = p.W * 128;
+
+    floatx16 acc[2][2];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    auto compute = [&](const char* win, const char* bslot, int ky) {
+        const char* a0 = win + abase + (p.sign > 0 ? ky : 2 - ky) * wrow_bytes;
+        const char* b0 = bslot + bbase;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            bf16x8 ah[2], al[2], bh[2], bl[2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                ah[i] = *reinterpret_cast<const bf16x8*>(a0 + i * 4096 + foff[s][0]);
+                al[i] = *reinterpret_cast<const bf16x8*>(a0 + i * 4096 + foff[s][1]);
+                bh[i] = *reinterpret_cast<const bf16x8*>(b0 + i * 4096 + foff[s][0]);
+                bl[i] = *reinterpret_cast<const bf16x8*>(b0 + i * 4096 + foff[s][1]);
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[q], acc[i][q], 0, 0, 0);
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int q = 0; q < 2; ++q) acc[i][q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[q], acc[i][q], 0, 0, 0);
+        }
+    };
+
+    char* const A0 = smem; char* const A1 = smem + PS3_A_BYTES;
+    char* const B0 = smem + 2 * PS3_A_BYTES; char* const B1 = B0 + PS3_B_BYTES; char* const B2 = B1 + PS3_B_BYTES;
+
+    // issue order per wave: A(0) [5 DMAs], B(0) [2], B(1) [2]; then behind the barrier of chunk c = 3g + ky:
+    //   ky == 0: A(g+1) [5] and B(c+2) [2];  ky == 1, 2: B(c+2) [2].
+    // Chunk c needs B(c) -- and everything issued before it, i.e. A(g) -- landed: DMAs issued after B(c) are
+    //   ky == 0: B(c+1) = 2;   ky == 1: A(g+1) + B(c+1) = 7;   ky == 2: B(c+1) = 2.
+    issue_a(A0);
+    issue_b(B0);
+    issue_b(B1);
+    auto sync2 = [&]() { asm volatile("s_waitcnt vmcnt(2) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+    auto sync7 = [&]() { asm volatile("s_waitcnt vmcnt(7) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+    auto sync0 = [&]() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory"); __builtin_amdgcn_s_barrier(); };
+    // two groups (six chunks) per trip so that the A windows and the three weight slots are compile-time addresses
+    for (int g = 0; g < ngroups; g += 2) {
+        const bool more1 = g + 1 < ngroups, more2 = g + 2 < ngroups;
+        // group g on A0: chunks 3g .. 3g+2 on slots (3g) % 3 = 0, 1, 2 (3g is a multiple of 3)
+        sync2(); if (more1) issue_a(A1); issue_b(B2); compute(A0, B0, 0);
+        if (more1) sync7(); else sync2();
+        if (more1) issue_b(B0); compute(A0, B1, 1);
+        if (more1) sync2(); else sync0();
+        if (more1) issue_b(B1); compute(A0, B2, 2);
+        if (!more1) break;
+        // group g + 1 on A1
+        sync2(); if (more2) issue_a(A0); issue_b(B2); compute(A1, B0, 0);
+        if (more2) sync7(); else sync2();
+        if (more2) issue_b(B0); compute(A1, B1, 1);
+        if (more2) sync2(); else sync0();
+        if (more2) issue_b(B1); compute(A1, B2, 2);
+    }
+    (void)nchunks;
+
+    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
+    if (mw + 64 <= p.M) ps_epilogue<EPI, 2, true>(p, acc, mw, nw, li, h);
+    else ps_epilogue<EPI, 2, false>(p, acc, mw, nw, li, h);
+}
+
+// ---------------------------------------------------------------------------------------------------------------------
 // 128 x 128 tile variant for the SMALL layers (8x8 / 4x4 images: too few 256 x 128 tiles to fill the chip): same operands,
 // same fragment layout, 8 waves of 32 x 64, two LDS stages (64 KB -> two workgroups per CU, which de-phase), and the K
 // chunks (tap, 32 channels) split over `ksplit` workgroups per tile: partial slabs + a fixed-order second pass that also
@@ -1007,7 +1169,11 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
 #ifdef BD_PS_ABLATION
         p.ablate = getenv("BD_PS_ABLATE") ? atoi(getenv("BD_PS_ABLATE")) : 0;
 #endif
-#define PS_LAUNCH(E) hipLaunchKernelGGL((conv_ps_kernel<E>), grid, block, 0, st, p)
+        // vertical-tap sharing variant (conv_ps3_kernel): image rows of 16 or 32 pixels, whole images per tile row block
+        static const bool v3_off = getenv("BD_PS_V3") && atoi(getenv("BD_PS_V3")) == 0;
+        const bool v3 = !v3_off && (d.W == 16 || d.W == 32) && ((long long)d.H * d.W) % PS_BM == 0 && M % PS_BM == 0;
+#define PS_LAUNCH(E) do { if (v3) hipLaunchKernelGGL((conv_ps3_kernel<E>), grid, block, 0, st, p); \
+                          else hipLaunchKernelGGL((conv_ps_kernel<E>), grid, block, 0, st, p); } while (0)
         switch (epi) {          // every combination has its own instantiation: the epilogue's addends are compile-time
             case 0: PS_LAUNCH(0); break;
             case 1: PS_LAUNCH(1); break;
