@@ -20,7 +20,7 @@ SOURCES = [  # (file, extra flags)
     ("elementwise.hip", ["-ffp-contract=off"]),
     ("groupnorm.hip", []),
     ("igemm.hip", []),
-    ("conv_ps.hip", []),
+    ("conv_ps.hip", ["-DBD_PS_ABLATION"] if os.environ.get("BD_BUILD_ABLATION") == "1" else []),
     ("conv_ph.hip", []),
     ("attn.hip", []),
     ("metrics.hip", ["-ffp-contract=off"]),

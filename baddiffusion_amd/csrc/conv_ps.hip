@@ -750,6 +750,9 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
             ps_dma16(in ? asrc[j] : reinterpret_cast<const char*>(kPsZero), stage + (wave + NW * j) * 1024);
             asrc[j] += a_adv;
         }
+#ifdef BD_PS_ABLATION
+        if (!(p.ablate & 8) || ((pp >> 5) % 3) == 0)     // 8: the X operand fetched for one chunk in three (timing model of vertical-tap sharing)
+#endif
         ps_dma16(ok ? bsrc[j] : reinterpret_cast<const char*>(kPsZero), stage + WG_OP_BYTES + (wave + NW * j) * 1024);
         bsrc[j] += b_adv;
     };
