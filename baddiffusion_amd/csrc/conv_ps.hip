@@ -950,6 +950,192 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
     }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// Round 3: weight gradient with the three VERTICAL taps of a column shift in one workgroup (W in {16, 32}).
+// dW[co][(ky, kx)][ci] = sum_p dY[p][co] * X[p + (ky-1) W + (kx-1)][ci]: for a fixed kx the three ky taps contract the SAME dY rows
+// with X rows W pixels apart, and consecutive 32-pixel chunks slide that window by 32: every X pixel is DMA'd ONCE into a ring of
+// eight 16-pixel units and read by the three taps from three chunks; the dY fragments are read once for three taps.  Tile = 128 co x
+// (3 taps x 128 ci), 8 waves of 32 x (3 x 64), 96 accumulator registers; L2 -> LDS bytes per MFMA a third of conv_ps_wgrad_kernel's.
+// A tap whose X row falls outside the image is skipped for that 16-pixel step (a step never straddles image rows: W % 16 == 0), so no
+// zero rows are needed for the vertical direction; columns shifted out of the image read the zero page as before.
+// LDS: two dY stages (2 x 16 KB) + the X ring (64 KB) = 96 KB, one workgroup per CU.
+constexpr int WG3_RING_UNITS = 8, WG3_UNIT_BYTES = 16 * 512;
+constexpr int WG3_LDS_BYTES = 2 * WG_OP_BYTES + WG3_RING_UNITS * WG3_UNIT_BYTES;
+
+__global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
+    __shared__ __attribute__((aligned(128))) char smem[WG3_LDS_BYTES];
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    int tm, tn, zz;
+    {
+        const unsigned L = blockIdx.x, T = gridDim.x, q = T >> 3;
+        const unsigned j = L < (q << 3) ? (L & 7) * q + (L >> 3) : L;
+        const unsigned ntiles = p.tiles_m * p.tiles_n;
+        zz = j / ntiles;
+        const unsigned tile = j - zz * ntiles;
+        tm = tile / p.tiles_n;
+        tn = tile - tm * p.tiles_n;
+    }
+    const int co0 = tm * WG_BM;
+    const int ncb = p.Cin / WG_BN;                 // 128-channel blocks of X
+    const int kx = tn / ncb, ci0 = (tn - kx * ncb) * WG_BN;
+    const int dxt = kx - 1;
+    const int nchunks = p.P >> 5;                  // host: P % 32 == 0
+    const int c_begin = zz * p.cps;
+    int c_end = c_begin + p.cps;
+    if (c_end > nchunks) c_end = nchunks;
+
+    // ---- DMA: wave w moves pixel pairs w and w + 8 of a 32-pixel chunk; lane: pixel k = 2*pair + lane/32, 16-byte slot lane%32
+    const int ps = lane & 31;
+    int kpix[2];
+    const char* abase_g[2]; const char* bbase_g[2];
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int k = 2 * (wave + 8 * j) + (lane >> 5);
+        kpix[j] = k;
+        const int ls = ps ^ ((k & 3) << 2);
+        abase_g[j] = p.dy + co0 * 4 + ls * 16;
+        bbase_g[j] = p.x + ci0 * 4 + ls * 16;
+    }
+    char* const ring = smem + 2 * WG_OP_BYTES;
+    auto issue_dy = [&](int c) {
+        char* stage = smem + (c & 1) * WG_OP_BYTES;
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const long long pp = (long long)c * 32 + kpix[j];
+            ps_dma16(abase_g[j] + pp * p.lddy * 4, stage + (wave + 8 * j) * 1024);
+        }
+    };
+    // X pixels [32 v + W, 32 v + 32 + W) of (possibly virtual, v < c_begin) chunk v: the rows the LAST vertical tap of chunk v needs
+    auto issue_x = [&](int v) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int s0 = v * 32 + p.W + 2 * (wave + 8 * j);            // first pixel of the pair (wave-uniform)
+            const int s = s0 + (lane >> 5);
+            const int x = s & (p.W - 1);
+            const bool ok = s >= 0 && s < p.P && (unsigned)(x + dxt) < (unsigned)p.W;
+            const int unit = ((s0 + 4096) >> 4) & (WG3_RING_UNITS - 1);
+            ps_dma16(ok ? bbase_g[j] + (long long)(s + dxt) * p.ldx * 4 : reinterpret_cast<const char*>(kPsZero),
+                     ring + unit * WG3_UNIT_BYTES + (s0 & 15) * 512);
+        }
+    };
+
+    // ---- fragment addresses (ds_read_b64_tr_b16): as in conv_ps_wgrad_kernel, relative to a 16-pixel unit
+    const int sl = lane & 15, hb = (lane >> 4) & 1, h = lane >> 5;
+    const int kq = sl >> 2, rq = sl & 3;
+    const int lane_base = (8 * h + kq) * 512 + hb * 32 + rq * 8;
+    int xw[4];
+#pragma unroll
+    for (int v = 0; v < 4; ++v) xw[v] = (v ^ kq) << 6;
+    auto foff = [&](int t, int plane) { return lane_base + xw[(t & 1) * 2 + plane] + (t >> 1) * 256; };
+    unsigned aoff[2], boff[2][2];
+#pragma unroll
+    for (int pl = 0; pl < 2; ++pl) aoff[pl] = (unsigned)foff(wm, pl);
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) boff[q][pl] = (unsigned)foff(wn * 2 + q, pl);
+    const unsigned smem_addr = (unsigned)(uintptr_t)(lds_ptr)smem;
+    const unsigned ring_addr = smem_addr + 2 * WG_OP_BYTES;
+
+    floatx16 acc[3][2], accb;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        accb[r] = 0.f;
+#pragma unroll
+        for (int t = 0; t < 3; ++t) { acc[t][0][r] = 0.f; acc[t][1][r] = 0.f; }
+    }
+    const bool do_db = p.want_db && tn == 0 && wn == 0;   // wave-uniform
+    bf16x8 ones;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
+
+    auto tap_mfmas = [&](floatx16 (&a)[2], bf16x8 ah, bf16x8 al, unsigned xbase) {
+        ps_short4 b0[2][2], b1[2][2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                b0[q][pl] = ps_tr_read<0>(xbase + boff[q][pl]);
+                b1[q][pl] = ps_tr_read<4 * 512>(xbase + boff[q][pl]);
+            }
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(b0[0][0]), "+v"(b1[0][0]), "+v"(b0[0][1]), "+v"(b1[0][1]), "+v"(b0[1][0]), "+v"(b1[1][0]), "+v"(b0[1][1]), "+v"(b1[1][1]));
+        bf16x8 bh[2], bl[2];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) { bh[q] = ps_tr_join(b0[q][0], b1[q][0]); bl[q] = ps_tr_join(b0[q][1], b1[q][1]); }
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], a[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[q], a[q], 0, 0, 0);
+#pragma unroll
+        for (int q = 0; q < 2; ++q) a[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[q], a[q], 0, 0, 0);
+    };
+
+    const int wu = p.W >> 4;       // units per image row
+    auto compute = [&](int c) {
+        const unsigned dbase = smem_addr + (unsigned)((c & 1) * WG_OP_BYTES);
+#pragma unroll
+        for (int S = 0; S < 2; ++S) {
+            ps_short4 a0[2], a1[2];
+#pragma unroll
+            for (int pl = 0; pl < 2; ++pl) {
+                a0[pl] = S ? ps_tr_read<16 * 512>(dbase + aoff[pl]) : ps_tr_read<0>(dbase + aoff[pl]);
+                a1[pl] = S ? ps_tr_read<16 * 512 + 4 * 512>(dbase + aoff[pl]) : ps_tr_read<4 * 512>(dbase + aoff[pl]);
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]));
+            const bf16x8 ah = ps_tr_join(a0[0], a1[0]), al = ps_tr_join(a0[1], a1[1]);
+            const int p0 = c * 32 + S * 16;                          // first pixel of this 16-pixel step (one image row segment)
+            const int y = (p0 >> p.lw) & (p.H - 1);
+            const int u0 = (p0 + 4096) >> 4;                         // ring unit of the step's own pixels
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                if ((unsigned)(y + ky - 1) >= (unsigned)p.H) continue;                       // wave-uniform
+                const unsigned xbase = ring_addr + (unsigned)(((u0 + (ky - 1) * wu) & (WG3_RING_UNITS - 1)) * WG3_UNIT_BYTES);
+                tap_mfmas(acc[ky], ah, al, xbase);
+            }
+            if (do_db) {
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);
+                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, accb, 0, 0, 0);
+            }
+        }
+    };
+
+    if (c_begin < c_end) {
+        for (int v = c_begin - (p.W >> 4); v < c_begin; ++v) issue_x(v);     // halo: X rows [32 c_begin - W, 32 c_begin + W)
+        issue_dy(c_begin); issue_x(c_begin);
+        for (int c = c_begin; c < c_end; ++c) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c + 1 < c_end) { issue_dy(c + 1); issue_x(c + 1); }
+            compute(c);
+        }
+    }
+
+    // ---- epilogue: lane holds column n = li of rows (r&3) + 8*(r>>2) + 4*h; three tap tiles per wave
+    const int li = lane & 31;
+    const int M = p.Cout, N = 9 * p.Cin;
+    float* out = p.out + (p.ksplit > 1 ? (long long)zz * M * N : 0);
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int nn = (ky * 3 + kx) * p.Cin + ci0 + wn * 64 + q * 32 + li;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(long long)m * N + nn] = acc[ky][q][r];
+            }
+        }
+    if (do_db && li == 0) {
+        float* o = p.ksplit > 1 ? p.out + (long long)p.ksplit * M * N + (long long)zz * M : p.db;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = accb[r];
+    }
+}
+
 // fixed-order sum of the K-split slabs (float4 per thread); the tail threads fold the bias rows
 __global__ __launch_bounds__(256) void conv_ps_wgrad_reduce(const float* __restrict__ part, int ksplit, long long mn, int M,
                                                             float* __restrict__ dw, float* __restrict__ db, int brows) {
@@ -1224,8 +1410,14 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
 bool conv3x3_ps_wgrad_supported(int B, int H, int W, int Cin, int Cout) {
     return B > 0 && ilog2x(H) >= 0 && ilog2x(W) >= 0 && Cin % WG_BN == 0 && Cout % WG_BM == 0;
 }
+// vertical-tap sharing form (conv_ps_wgrad3_kernel): image rows of 16 or 32 pixels, whole 32-pixel chunks
+static bool ps_wgrad_v3(const bd_conv3x3_ps_wgrad_desc& d) {
+    static const bool off = getenv("BD_PS_WG3") && atoi(getenv("BD_PS_WG3")) == 0;
+    return !off && (d.W == 16 || d.W == 32) && ((long long)d.B * d.H * d.W) % 32 == 0;
+}
 static void ps_wgrad_split(const bd_conv3x3_ps_wgrad_desc& d, int& ksplit, int& cps) {
-    const long long tiles = (long long)(d.Cout / WG_BM) * (9 * d.Cin / WG_BN);
+    const bool v3 = ps_wgrad_v3(d);
+    const long long tiles = (long long)(d.Cout / WG_BM) * ((v3 ? 3 : 9) * d.Cin / WG_BN);
     const int nchunks = (int)cdiv((long long)d.B * d.H * d.W, 32);
     static const int slots = [] {
         int dev = 0, cus = 256;
@@ -1233,8 +1425,9 @@ static void ps_wgrad_split(const bd_conv3x3_ps_wgrad_desc& d, int& ksplit, int& 
         const char* e = getenv("BD_PS_WG_SLOTS");
         return e ? atoi(e) : 2 * cus;   // two 64-KB workgroups per CU (two LDS stages each): the pair de-phases, 141 vs 189 us
     }();
+    static const int slots3 = getenv("BD_PS_WG3_SLOTS") ? atoi(getenv("BD_PS_WG3_SLOTS")) : slots / 2;   // 96 KB of LDS: one workgroup per CU
     static const int mincps = getenv("BD_PS_WG_MINCPS") ? atoi(getenv("BD_PS_WG_MINCPS")) : 8;   // chunks per split at least (4x4 layers: 8 slabs instead of 14; 4 / 16 measured +0.2 / +0.1 ms)
-    int ks = (int)(slots / tiles);
+    int ks = (int)((v3 ? slots3 : slots) / tiles);
     if (ks < 1) ks = 1;
     if (ks > nchunks / mincps) ks = nchunks / mincps > 0 ? nchunks / mincps : 1;
     cps = (int)cdiv(nchunks, ks);
@@ -1255,7 +1448,8 @@ int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
     p.dy = reinterpret_cast<const char*>(d.dy_split); p.x = reinterpret_cast<const char*>(d.x_split);
     p.lddy = d.lddy; p.ldx = d.ldx; p.Cin = d.Cin; p.Cout = d.Cout; p.H = d.H; p.W = d.W; p.lw = ilog2x(d.W);
     p.P = d.B * d.H * d.W;
-    p.tiles_m = d.Cout / WG_BM; p.tiles_n = 9 * d.Cin / WG_BN; p.ntaps = 9;
+    const bool v3 = ps_wgrad_v3(d);
+    p.tiles_m = d.Cout / WG_BM; p.tiles_n = (v3 ? 3 : 9) * d.Cin / WG_BN; p.ntaps = 9;
     ps_wgrad_split(d, p.ksplit, p.cps);
     p.want_db = d.db != nullptr;
     const long long mn = (long long)d.Cout * 9 * d.Cin;
@@ -1282,7 +1476,8 @@ int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
     else if (nw == 4) hipLaunchKernelGGL((conv_ps_wgrad_kernel<3, 4>), grid, dim3(256), 0, st, p);
     else
 #endif
-    if (stages == 2) hipLaunchKernelGGL((conv_ps_wgrad_kernel<2, 8>), grid, dim3(512), 0, st, p);
+    if (v3) hipLaunchKernelGGL(conv_ps_wgrad3_kernel, grid, dim3(512), 0, st, p);
+    else if (stages == 2) hipLaunchKernelGGL((conv_ps_wgrad_kernel<2, 8>), grid, dim3(512), 0, st, p);
     else hipLaunchKernelGGL((conv_ps_wgrad_kernel<3, 8>), grid, dim3(512), 0, st, p);
     BD_LAUNCH_CHECK("conv_ps_wgrad");
     if (p.ksplit > 1) {
