@@ -1052,20 +1052,34 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-    auto tap_mfmas = [&](floatx16 (&a)[2], bf16x8 ah, bf16x8 al, unsigned xbase) {
-        ps_short4 b0[2][2], b1[2][2];
+    // one 16-pixel step of one tap: X fragments (two 32-channel tiles x hi / lo x two pixel halves)
+    struct BFrag { ps_short4 b0[2][2], b1[2][2]; };
+    auto readB = [&](BFrag& f, unsigned xbase) {
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
             for (int pl = 0; pl < 2; ++pl) {
-                b0[q][pl] = ps_tr_read<0>(xbase + boff[q][pl]);
-                b1[q][pl] = ps_tr_read<4 * 512>(xbase + boff[q][pl]);
+                f.b0[q][pl] = ps_tr_read<0>(xbase + boff[q][pl]);
+                f.b1[q][pl] = ps_tr_read<4 * 512>(xbase + boff[q][pl]);
             }
+    };
+    auto waitB = [&](BFrag& f) {
         asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(b0[0][0]), "+v"(b1[0][0]), "+v"(b0[0][1]), "+v"(b1[0][1]), "+v"(b0[1][0]), "+v"(b1[1][0]), "+v"(b0[1][1]), "+v"(b1[1][1]));
+                     : "+v"(f.b0[0][0]), "+v"(f.b1[0][0]), "+v"(f.b0[0][1]), "+v"(f.b1[0][1]), "+v"(f.b0[1][0]), "+v"(f.b1[1][0]), "+v"(f.b0[1][1]),
+                       "+v"(f.b1[1][1]));
+    };
+    struct AFrag { ps_short4 a0[2], a1[2]; };
+    auto readA = [&](AFrag& f, unsigned dbase, int S) {
+#pragma unroll
+        for (int pl = 0; pl < 2; ++pl) {
+            f.a0[pl] = S ? ps_tr_read<16 * 512>(dbase + aoff[pl]) : ps_tr_read<0>(dbase + aoff[pl]);
+            f.a1[pl] = S ? ps_tr_read<16 * 512 + 4 * 512>(dbase + aoff[pl]) : ps_tr_read<4 * 512>(dbase + aoff[pl]);
+        }
+    };
+    auto tap_mfmas = [&](floatx16 (&a)[2], bf16x8 ah, bf16x8 al, const BFrag& f) {
         bf16x8 bh[2], bl[2];
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { bh[q] = ps_tr_join(b0[q][0], b1[q][0]); bl[q] = ps_tr_join(b0[q][1], b1[q][1]); }
+        for (int q = 0; q < 2; ++q) { bh[q] = ps_tr_join(f.b0[q][0], f.b1[q][0]); bl[q] = ps_tr_join(f.b0[q][1], f.b1[q][1]); }
 #pragma unroll
         for (int q = 0; q < 2; ++q) a[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], a[q], 0, 0, 0);
 #pragma unroll
@@ -1075,30 +1089,41 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
     };
 
     const int wu = p.W >> 4;       // units per image row
+    // six (16-pixel step, tap) stages per chunk, statically scheduled: the fragments of stage i+1 are read while the MFMAs of stage i
+    // run.  A tap whose X row is outside the image skips its MFMAs (wave-uniform); its reads hit a live ring slot and are dropped.
     auto compute = [&](int c) {
         const unsigned dbase = smem_addr + (unsigned)((c & 1) * WG_OP_BYTES);
+        const int p0 = c * 32;
+        const int u0 = (p0 + 4096) >> 4;
+        unsigned xb[6]; bool ok[6];
 #pragma unroll
-        for (int S = 0; S < 2; ++S) {
-            ps_short4 a0[2], a1[2];
+        for (int i = 0; i < 6; ++i) {
+            const int S = i / 3, ky = i - 3 * S;
+            const int y = ((p0 + 16 * S) >> p.lw) & (p.H - 1);
+            ok[i] = (unsigned)(y + ky - 1) < (unsigned)p.H;
+            xb[i] = ring_addr + (unsigned)(((u0 + S + (ky - 1) * wu) & (WG3_RING_UNITS - 1)) * WG3_UNIT_BYTES);
+        }
+        AFrag fa[2]; BFrag fb[2];
+        readA(fa[0], dbase, 0);
+        readB(fb[0], xb[0]);
+        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0].a0[0]), "+v"(fa[0].a1[0]), "+v"(fa[0].a0[1]), "+v"(fa[0].a1[1]));
+        waitB(fb[0]);
 #pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                a0[pl] = S ? ps_tr_read<16 * 512>(dbase + aoff[pl]) : ps_tr_read<0>(dbase + aoff[pl]);
-                a1[pl] = S ? ps_tr_read<16 * 512 + 4 * 512>(dbase + aoff[pl]) : ps_tr_read<4 * 512>(dbase + aoff[pl]);
-            }
-            asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(a0[0]), "+v"(a1[0]), "+v"(a0[1]), "+v"(a1[1]));
-            const bf16x8 ah = ps_tr_join(a0[0], a1[0]), al = ps_tr_join(a0[1], a1[1]);
-            const int p0 = c * 32 + S * 16;                          // first pixel of this 16-pixel step (one image row segment)
-            const int y = (p0 >> p.lw) & (p.H - 1);
-            const int u0 = (p0 + 4096) >> 4;                         // ring unit of the step's own pixels
-#pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                if ((unsigned)(y + ky - 1) >= (unsigned)p.H) continue;                       // wave-uniform
-                const unsigned xbase = ring_addr + (unsigned)(((u0 + (ky - 1) * wu) & (WG3_RING_UNITS - 1)) * WG3_UNIT_BYTES);
-                tap_mfmas(acc[ky], ah, al, xbase);
-            }
-            if (do_db) {
+        for (int i = 0; i < 6; ++i) {
+            const int S = i / 3, ky = i - 3 * S;
+            if (i + 1 < 6) readB(fb[(i + 1) & 1], xb[i + 1]);
+            if (i == 1) readA(fa[1], dbase, 1);
+            __builtin_amdgcn_sched_barrier(0);
+            const bf16x8 ah = ps_tr_join(fa[S].a0[0], fa[S].a1[0]), al = ps_tr_join(fa[S].a0[1], fa[S].a1[1]);
+            if (ok[i]) tap_mfmas(acc[ky], ah, al, fb[i & 1]);
+            if (do_db && ky == 0) {
                 accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);
                 accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, accb, 0, 0, 0);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if (i + 1 < 6) {
+                if (i == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1].a0[0]), "+v"(fa[1].a1[0]), "+v"(fa[1].a0[1]), "+v"(fa[1].a1[1]));
+                waitB(fb[(i + 1) & 1]);
             }
         }
     };
