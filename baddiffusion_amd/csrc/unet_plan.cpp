@@ -29,6 +29,7 @@ bool conv3x3_wgrad_is_thin(const bd_conv3x3_wgrad_desc& d);
 int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st);                         // conv_ps.hip
 bool conv3x3_ps_supported(int B, int H, int W, int K_channels, int N_channels);
 int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st);
+size_t conv3x3_ps_wgrad_workspace_bytes(const bd_conv3x3_ps_wgrad_desc& d);
 bool conv3x3_ps_wgrad_supported(int B, int H, int W, int Cin, int Cout);
 int upsample_weights(const float* w, int Cin, int Cout, uint16_t* e_split, uint16_t* et_split, hipStream_t st);   // conv_ph.hip
 int upsample_conv_fwd(const bd_upsample_conv_desc& d, hipStream_t st);
@@ -352,7 +353,12 @@ struct bd_unet {
     }
     int conv_pw(Ctx& c, bd_conv3x3_ps_wgrad_desc& d) const {
         d.workspace_bytes = c.opws_bytes;
-        if (c.dry) { note_conv(c); return BD_OK; }
+        if (c.dry) {
+            note_conv(c);
+            const size_t n = conv3x3_ps_wgrad_workspace_bytes(d);      // K-split slabs of this layer (grow with the tile of the shared-tap form)
+            if (n > c.opws_need) c.opws_need = n;
+            return BD_OK;
+        }
         // BD_AUX_MAXPIX (A/B knob): weight gradients over more pixels than this stay on the main stream -- they fill the chip
         // on their own, and beside the dgrad chain they mostly trade clock for overlap
         static const long long maxpix = getenv("BD_AUX_MAXPIX") ? atoll(getenv("BD_AUX_MAXPIX")) : (1ll << 62);
