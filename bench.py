@@ -36,8 +36,8 @@ _PMC_OPERANDS = {"conv_fwd": ("ConvKC", ("WgtKC", "WgtKCs")), "conv_dgrad": ("TC
                  "conv_wgrad": ("DenseRC", ("ConvRC", "ConvRCs")), "gemm_nt": ("DenseKC", ("DenseKC",)),
                  "gemm_nn": ("DenseKC", ("DenseRC",)), "gemm_tn": ("DenseRC", ("DenseRC",))}
 # kernel classes of the LDS-DMA family (conv_ps.hip) -> kernel-name patterns whose HBM traffic makes up one call
-_PMC_PS = {"conv_ps_wgrad": (r"conv_ps_wgrad_kernel<", r"conv_ps_wgrad_reduce"), "conv_ps_fwd": (r"conv_ps_kernel<[12]>",),
-           "conv_ps_dgrad": (r"conv_ps_kernel<0>",), "conv_ps128_fwd": (r"conv_ps128_kernel<", r"conv_ps128_reduce"),
+_PMC_PS = {"conv_ps_wgrad": (r"conv_ps_wgrad3?_kernel", r"conv_ps_wgrad_reduce"), "conv_ps_fwd": (r"conv_ps3?_kernel<[12]>",),
+           "conv_ps_dgrad": (r"conv_ps3?_kernel<0>",), "conv_ps128_fwd": (r"conv_ps128_kernel<", r"conv_ps128_reduce"),
            "conv_ps128_dgrad": (r"conv_ps128_kernel<", r"conv_ps128_reduce")}
 PMC_FILE = "profiles/r03_pmc_bench_{mode}.json"       # falls back to the round-2 file when this round's is absent
 
