@@ -1216,7 +1216,8 @@ static int unet_aux_init(bd_unet* u) {
     if (u->aux_stream) return BD_OK;
     int lo = 0, hi = 0;
     BD_HIP_TRY(hipDeviceGetStreamPriorityRange(&lo, &hi));   // lowest priority: in backward the dgrad chain is the critical path
-    BD_HIP_TRY(hipStreamCreateWithPriority(&u->aux_stream, hipStreamNonBlocking, lo));
+    const int prio = getenv("BD_AUX_PRIO") ? atoi(getenv("BD_AUX_PRIO")) : lo;     // (A/B knob; `lo` = lowest)
+    BD_HIP_TRY(hipStreamCreateWithPriority(&u->aux_stream, hipStreamNonBlocking, prio));
     BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_fork, hipEventDisableTiming));
     BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join[0], hipEventDisableTiming));
     BD_HIP_TRY(hipEventCreateWithFlags(&u->aux_ev_join[1], hipEventDisableTiming));
