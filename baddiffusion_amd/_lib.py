@@ -122,6 +122,18 @@ class ConvS2DgradDesc(C.Structure):
                 ("wT_split", vp), ("dx", vp), ("lddx", i64), ("accumulate", i32)]
 
 
+class GemmSpDesc(C.Structure):
+    _fields_ = [("M", i32), ("N", i32), ("K", i32), ("batch", i32), ("a", vp), ("lda", i64), ("a_bs", i64), ("a_kmajor", i32),
+                ("b", vp), ("ldb", i64), ("b_bs", i64), ("b_kmajor", i32), ("c", vp), ("ldc", i64), ("c_bs", i64),
+                ("c_split", vp), ("ldcs", i64), ("cs_bs", i64), ("bias", vp), ("residual", vp), ("ldr", i64), ("r_bs", i64),
+                ("alpha", f32), ("out_scale", f32), ("accumulate", i32), ("a_colsum", vp), ("workspace", vp), ("workspace_bytes", sz)]
+
+
+class AttnSpDesc(C.Structure):
+    _fields_ = [("B", i32), ("heads", i32), ("N", i32), ("dh", i32), ("qkv_split", vp), ("ld", i64), ("scale", f32), ("o_split", vp),
+                ("ldo", i64), ("pt_split", vp), ("do_split", vp), ("lddo", i64), ("dst_split", vp), ("dqkv_split", vp), ("lddqkv", i64)]
+
+
 class AttnFwdDesc(C.Structure):
     _fields_ = [("B", i32), ("heads", i32), ("N", i32), ("dh", i32), ("q", vp), ("k", vp), ("v", vp), ("ld", i64), ("scale", f32),
                 ("o", vp), ("ldo", i64), ("p_out", vp), ("lse", vp)]
@@ -171,6 +183,11 @@ SIGNATURES = {
     "bd_upsample_conv_wgrad_workspace_bytes": (sz, [C.POINTER(UpsampleConvDesc)]),
     "bd_upsample_conv_dgrad_workspace_bytes": (sz, [C.POINTER(UpsampleConvDesc)]),
     "bd_conv3x3_s2_dgrad_ps": (i32, [C.POINTER(ConvS2DgradDesc), vp]),
+    "bd_gemm_sp_workspace_bytes": (sz, [C.POINTER(GemmSpDesc)]),
+    "bd_gemm_sp": (i32, [C.POINTER(GemmSpDesc), vp]),
+    "bd_attn_sp_supported": (i32, [i32, i32]),
+    "bd_attn_sp_fwd": (i32, [C.POINTER(AttnSpDesc), vp]),
+    "bd_attn_sp_bwd": (i32, [C.POINTER(AttnSpDesc), vp]),
     "bd_conv3x3_ps_wgrad": (i32, [C.POINTER(ConvPsWgradDesc), vp]),
     "bd_conv3x3_ps_wgrad_workspace_bytes": (sz, [C.POINTER(ConvPsWgradDesc)]),
     "bd_conv3x3_fwd": (i32, [C.POINTER(ConvFwdDesc), vp]),

@@ -22,6 +22,8 @@ SOURCES = [  # (file, extra flags)
     ("igemm.hip", []),
     ("conv_ps.hip", ["-DBD_PS_ABLATION"] if os.environ.get("BD_BUILD_ABLATION") == "1" else []),
     ("conv_ph.hip", []),
+    ("gemm_sp.hip", []),
+    ("attn_sp.hip", ["-DBD_AS_ABLATION"] if os.environ.get("BD_BUILD_ABLATION") == "1" else []),
     ("attn.hip", []),
     ("metrics.hip", ["-ffp-contract=off"]),
     ("conv.cpp", ["-x", "hip"]),

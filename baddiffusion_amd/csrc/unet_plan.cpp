@@ -41,6 +41,12 @@ bool upsample_conv_ps_supported(int B, int H, int W, int Cin, int Cout);
 int conv3x3_s2_dgrad_ps(const bd_conv3x3_s2_dgrad_desc& d, hipStream_t st);
 int attn_fwd(const bd_attn_fwd_desc& d, hipStream_t st);                             // attn.hip
 bool attn_fwd_supported(int N, int dh);
+int gemm_sp(const bd_gemm_sp_desc& d, hipStream_t st);                              // gemm_sp.hip
+size_t gemm_sp_workspace_bytes(const bd_gemm_sp_desc& d);
+bool gemm_sp_supported(int M, int N, int K);
+int attn_sp_fwd(const bd_attn_sp_desc& d, hipStream_t st);                          // attn_sp.hip
+int attn_sp_bwd(const bd_attn_sp_desc& d, hipStream_t st);
+bool attn_sp_supported(int N, int dh);
 int split_wt_batched(const float* params, uint16_t* out, const long long* off, const int* cin, const int* cout, int n, hipStream_t st);
 
 struct View {
@@ -235,6 +241,18 @@ struct bd_unet {
             return BD_OK;
         }
         return igemm_launch(g, c.st);
+    }
+    // GEMM on split planes (gemm_sp.hip); aux: a weight gradient, on the side stream
+    int gemm_s(Ctx& c, bd_gemm_sp_desc& g, bool aux = false) const {
+        g.workspace_bytes = c.opws_bytes;
+        if (c.dry) {
+            const size_t n = gemm_sp_workspace_bytes(g);
+            if (n > c.opws_need) c.opws_need = n;
+            return BD_OK;
+        }
+        if (aux) return on_aux(c, [&](hipStream_t st, char* ws) { g.workspace = ws; return gemm_sp(g, st); });
+        g.workspace = c.opws;
+        return gemm_sp(g, c.st);
     }
     static bd_operand dense(const float* p, int64_t ld, int kc) {
         bd_operand o = {};
@@ -659,13 +677,53 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
     const int b_dys = scale != 1.f ? scratch((int64_t)N * C) : -1;
     const int b_bs = scratch(3 * C), b_do = scratch((int64_t)N * C), b_dp = scratch((int64_t)heads * N * N);
     const int b_dqkv = scratch((int64_t)N * 3 * C), b_dn = scratch((int64_t)N * C);
+    const int b_dyS = scratch((int64_t)N * C);
     const float inv = 1.f / scale;
 
     auto batched = [=](bd_igemm_desc& g, int B) {
         g.batch_outer = B; g.batch_inner = heads;
     };
+    // Round 3: the whole block on SPLIT PLANES (gemm_sp.hip + attn_sp.hip): GroupNorm writes planes, the QKV projection reads and writes
+    // planes, the attention core (scores, softmax, value product: one launch forward, two backward) keeps the [N, N] matrices on chip and
+    // hands planes to the output projection; the backward mirrors it.  The same buffers hold planes instead of fp32 (same bytes); the
+    // weights' planes are the per-step bd_split_bf16 copy (K-contiguous rows: the layout a [N][K] weight wants forward, and the K-major
+    // operand of its data gradient as it stands).  N = 256 tokens, head dim 256 (attn_sp_supported); the mid block (4 x 4) stays below.
+    auto use_sp = [=](const Ctx& c) {
+        return cfg.compute_mode == BD_MODE_BF16X3 && (c.dry || c.w_split) && attn_sp_supported(N, dh) &&
+               gemm_sp_supported((int)((int64_t)c.B * N), C, C) && gemm_sp_supported(3 * C, C, 32);
+    };
     F([=](Ctx& c) {
         const int M = (int)rows(c, x);
+        if (use_sp(c)) {
+            bd_gn_fwd_desc g = {};
+            g.B = c.B; g.HW = N; g.C = C; g.G = G; g.eps = cfg.norm_eps; g.silu = 0;
+            g.x = VP(c, x); g.ldx = x.ld; g.gamma = c.params + pgw; g.beta = c.params + pgb;
+            g.y = nullptr; g.ldy = C; g.y_split = U16(BP(c, b_n)); g.ldys = C;
+            g.mean = MEANP(c, b_st, G); g.rstd = RSTDP(c, b_st, G);
+            g.workspace = c.opws; g.workspace_bytes = c.opws_bytes;
+            if (c.dry) {
+                const size_t n = bd_gn_workspace_bytes(c.B, C);
+                if (n > c.opws_need) c.opws_need = n;
+            } else {
+                BD_TRY(bd_gn_fwd(&g, (bd_stream_t)c.st));
+            }
+            bd_gemm_sp_desc q = {};      // qkv = n Wqkv^T + b  -> planes
+            q.M = M; q.N = 3 * C; q.K = C; q.batch = 1;
+            q.a = U16(BP(c, b_n)); q.lda = C; q.b = c.w_split + 2 * pqw; q.ldb = C;
+            q.c_split = U16(BP(c, b_qkv)); q.ldcs = 3 * C; q.bias = c.params + pqb; q.alpha = 1.f; q.out_scale = 1.f;
+            BD_TRY(gemm_s(c, q));
+            if (!c.dry) {
+                bd_attn_sp_desc a = {};
+                a.B = c.B; a.heads = heads; a.N = N; a.dh = dh; a.qkv_split = U16(BP(c, b_qkv)); a.ld = 3 * C; a.scale = sm_scale;
+                a.o_split = U16(BP(c, b_o)); a.ldo = C; a.pt_split = c.training ? U16(BP(c, b_p)) : nullptr;
+                BD_TRY(attn_sp_fwd(a, c.st));
+            }
+            bd_gemm_sp_desc o = {};      // y = (o Wp^T + b + x) / scale
+            o.M = M; o.N = C; o.K = C; o.batch = 1;
+            o.a = U16(BP(c, b_o)); o.lda = C; o.b = c.w_split + 2 * ppw; o.ldb = C;
+            o.c = VP(c, y); o.ldc = y.ld; o.bias = c.params + ppb; o.residual = VP(c, x); o.ldr = x.ld; o.alpha = 1.f; o.out_scale = inv;
+            return gemm_s(c, o);
+        }
         BD_TRY(gn_fwd(c, x, pgw, pgb, BP(c, b_n), C, b_st, 0));
         BD_TRY(linear_fwd(c, BP(c, b_n), C, c.params + pqw, c.params + pqb, BP(c, b_qkv), 3 * C, M, 3 * C, C));
         float* qkv = BP(c, b_qkv);
@@ -708,6 +766,37 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
         if (b_dys >= 0) {
             BD_TRY(add(c, dy, lddy, BP(c, b_dys), C, M, C, inv, 0));
             dy = BP(c, b_dys); lddy = C;
+        }
+        if (use_sp(c)) {
+            BD_TRY(split_rows(c, dy, lddy, M, C, BP(c, b_dyS)));
+            bd_gemm_sp_desc w = {};      // dWp = dy^T o, dbp = column sums of dy  (side stream)
+            w.M = C; w.N = C; w.K = M; w.batch = 1;
+            w.a = U16(BP(c, b_dyS)); w.lda = C; w.a_kmajor = 1; w.b = U16(BP(c, b_o)); w.ldb = C; w.b_kmajor = 1;
+            w.c = c.grads + ppw; w.ldc = C; w.a_colsum = c.grads + ppb; w.alpha = 1.f; w.out_scale = 1.f;
+            BD_TRY(gemm_s(c, w, true));
+            bd_gemm_sp_desc g = {};      // dO = dy Wp -> planes
+            g.M = M; g.N = C; g.K = C; g.batch = 1;
+            g.a = U16(BP(c, b_dyS)); g.lda = C; g.b = c.w_split + 2 * ppw; g.ldb = C; g.b_kmajor = 1;
+            g.c_split = U16(BP(c, b_do)); g.ldcs = C; g.alpha = 1.f; g.out_scale = 1.f;
+            BD_TRY(gemm_s(c, g));
+            if (!c.dry) {
+                bd_attn_sp_desc a = {};
+                a.B = c.B; a.heads = heads; a.N = N; a.dh = dh; a.qkv_split = U16(BP(c, b_qkv)); a.ld = 3 * C; a.scale = sm_scale;
+                a.pt_split = U16(BP(c, b_p)); a.do_split = U16(BP(c, b_do)); a.lddo = C; a.dst_split = U16(BP(c, b_dp));
+                a.dqkv_split = U16(BP(c, b_dqkv)); a.lddqkv = 3 * C;
+                BD_TRY(attn_sp_bwd(a, c.st));
+            }
+            bd_gemm_sp_desc wq = {};     // dWqkv = dqkv^T n, dbqkv = column sums of dqkv  (side stream)
+            wq.M = 3 * C; wq.N = C; wq.K = M; wq.batch = 1;
+            wq.a = U16(BP(c, b_dqkv)); wq.lda = 3 * C; wq.a_kmajor = 1; wq.b = U16(BP(c, b_n)); wq.ldb = C; wq.b_kmajor = 1;
+            wq.c = c.grads + pqw; wq.ldc = C; wq.a_colsum = c.grads + pqb; wq.alpha = 1.f; wq.out_scale = 1.f;
+            BD_TRY(gemm_s(c, wq, true));
+            bd_gemm_sp_desc dn = {};     // dn = dqkv Wqkv
+            dn.M = M; dn.N = C; dn.K = 3 * C; dn.batch = 1;
+            dn.a = U16(BP(c, b_dqkv)); dn.lda = 3 * C; dn.b = c.w_split + 2 * pqw; dn.ldb = C; dn.b_kmajor = 1;
+            dn.c = BP(c, b_dn); dn.ldc = C; dn.alpha = 1.f; dn.out_scale = 1.f;
+            BD_TRY(gemm_s(c, dn));
+            return gn_bwd(c, x, pgw, pgb, b_st, BP(c, b_dn), C, 0, dy, lddy);
         }
         float* qkv = BP(c, b_qkv); float* dqkv = BP(c, b_dqkv); float* P = BP(c, b_p); float* dP = BP(c, b_dp);
         float* dO = BP(c, b_do);

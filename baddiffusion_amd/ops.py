@@ -423,6 +423,44 @@ def gemm(a, b, trans_a=False, trans_b=True, bias=None, alpha=1.0, tile=0, ksplit
     return c if batched else c[0]
 
 
+def unsplit_rows(s):
+    """Split planes int16 [..., C/32, 2, 32] -> fp32 [..., C] (hi + lo, exact): test / inspection helper, plain torch."""
+    hi = (s[..., 0, :].to(torch.int32) << 16).view(torch.float32)
+    lo = (s[..., 1, :].to(torch.int32) << 16).view(torch.float32)
+    return (hi + lo).reshape(*s.shape[:-3], s.shape[-3] * 32)
+
+
+def gemm_sp(a_split, b_split, M, N, K, a_kmajor=False, b_kmajor=False, batch=1, bias=None, residual=None, alpha=1.0, out_scale=1.0,
+            want_f32=True, want_split=False, out=None, accumulate=False, want_colsum=False):
+    """C = out_scale * (alpha * A B^T + bias + residual) on split planes (include/bd_hip.h bd_gemm_sp).  a_split: planes of A [batch, M, K]
+    (or [batch, K, M] when a_kmajor); b_split: planes of B [batch, N, K] (or [batch, K, N] when b_kmajor), or un-batched (shared by the
+    batch).  Returns (c fp32 or None, c_split or None[, colsum])."""
+    lib = L.load(); _need_cuda(a_split, b_split, bias, residual)
+    dev = a_split.device
+    d = L.GemmSpDesc()
+    d.M, d.N, d.K, d.batch = M, N, K, batch
+    ar, ac = (K, M) if a_kmajor else (M, K)
+    br, bc = (K, N) if b_kmajor else (N, K)
+    d.a = L.ptr(a_split); d.lda = ac; d.a_bs = ar * ac if a_split.numel() * 2 == batch * ar * ac * 4 else 0; d.a_kmajor = int(a_kmajor)
+    d.b = L.ptr(b_split); d.ldb = bc; d.b_bs = br * bc if b_split.numel() * 2 == batch * br * bc * 4 else 0; d.b_kmajor = int(b_kmajor)
+    c = out if out is not None else (torch.empty(batch, M, N, device=dev) if want_f32 else None)
+    cs = torch.empty(batch, M, N // 32, 2, 32, dtype=torch.int16, device=dev) if want_split else None
+    d.c = L.ptr(c); d.ldc = N; d.c_bs = M * N
+    d.c_split = L.ptr(cs); d.ldcs = N; d.cs_bs = M * N
+    d.bias = L.ptr(bias)
+    if residual is not None:
+        residual = residual.contiguous()
+        d.residual = L.ptr(residual); d.ldr = N; d.r_bs = M * N
+    d.alpha = alpha; d.out_scale = out_scale; d.accumulate = int(accumulate)
+    colsum_t = torch.empty(M, device=dev) if want_colsum else None
+    d.a_colsum = L.ptr(colsum_t)
+    need = lib.bd_gemm_sp_workspace_bytes(C.byref(d))
+    ws = workspace(need, dev)
+    d.workspace = L.ptr(ws); d.workspace_bytes = ws.numel()
+    L.check(lib.bd_gemm_sp(C.byref(d), L.stream()), "bd_gemm_sp")
+    return (c, cs, colsum_t) if want_colsum else (c, cs)
+
+
 # ------------------------------------------------------------------------------------------------ small ops
 def colsum(x, rows_per_group):
     lib = L.load(); _need_cuda(x)
@@ -461,6 +499,35 @@ def attn_fwd(qkv, heads, scale, want_p=False, want_lse=False):
     if want_lse:
         out.append(lse)
     return out[0] if len(out) == 1 else tuple(out)
+
+
+def attn_sp_fwd(qkv_split, B, heads, scale, want_pt=True, C_=None):
+    """Attention core forward on the planes of the QKV projection's output [B*N, 3C/32, 2, 32] (include/bd_hip.h bd_attn_sp_fwd):
+    returns (o_split [B*N, C/32, 2, 32], pt_split [B*heads, N, N/32, 2, 32] or None)."""
+    lib = L.load(); _need_cuda(qkv_split)
+    rows, blocks = qkv_split.shape[0], qkv_split.shape[1]
+    N = rows // B
+    Cc = C_ or blocks * 32 // 3            # C_: the planes' rows are padded beyond 3C (row stride = blocks * 32)
+    o = torch.empty(rows, Cc // 32, 2, 32, dtype=torch.int16, device=qkv_split.device)
+    pt = torch.empty(B * heads, N, N // 32, 2, 32, dtype=torch.int16, device=qkv_split.device) if want_pt else None
+    d = L.AttnSpDesc(B=B, heads=heads, N=N, dh=Cc // heads, qkv_split=L.ptr(qkv_split), ld=blocks * 32, scale=scale, o_split=L.ptr(o), ldo=Cc,
+                     pt_split=L.ptr(pt))
+    L.check(lib.bd_attn_sp_fwd(C.byref(d), L.stream()), "bd_attn_sp_fwd")
+    return o, pt
+
+
+def attn_sp_bwd(qkv_split, pt_split, do_split, B, heads, scale):
+    """Attention core backward: returns (dqkv_split [B*N, 3C/32, 2, 32], dst_split = planes of scale * dS^T)."""
+    lib = L.load(); _need_cuda(qkv_split, pt_split, do_split)
+    rows, blocks = qkv_split.shape[0], qkv_split.shape[1]
+    N = rows // B
+    Cc = blocks * 32 // 3
+    dqkv = torch.empty_like(qkv_split)
+    dst = torch.empty_like(pt_split)
+    d = L.AttnSpDesc(B=B, heads=heads, N=N, dh=Cc // heads, qkv_split=L.ptr(qkv_split), ld=3 * Cc, scale=scale, pt_split=L.ptr(pt_split),
+                     do_split=L.ptr(do_split), lddo=Cc, dst_split=L.ptr(dst), dqkv_split=L.ptr(dqkv), lddqkv=3 * Cc)
+    L.check(lib.bd_attn_sp_bwd(C.byref(d), L.stream()), "bd_attn_sp_bwd")
+    return dqkv, dst
 
 
 def softmax_fwd(s):

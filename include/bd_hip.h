@@ -499,6 +499,53 @@ typedef struct {
 } bd_conv3x3_s2_dgrad_desc;
 int bd_conv3x3_s2_dgrad_ps(const bd_conv3x3_s2_dgrad_desc* d, bd_stream_t stream);
 
+/* Dense (batched) GEMM on split planes -- the attention block's GEMMs (attention.py:85-186: query / key / value / proj_attn Linear
+ * layers, baddbmm(q, k^T), bmm(probs, v)) and their backward, without converting an operand on the way into LDS:
+ *     C[m][n] = out_scale * (alpha * sum_k A[m][k] B[n][k] + bias[n] + residual[m][n])   (+ C[m][n] when accumulate)
+ * a / b are split planes (bd_split_rows layout; ld and batch strides in 4-byte units, as for the fp32 tensor they replace):
+ *   K-contiguous (x_kmajor = 0): rows = M (a) or N (b, "weights [N][K]"), K along the row;
+ *   K-major      (x_kmajor = 1): rows = K, the M (a) or N (b) index along the row (both operands of a weight gradient, V of P V).
+ * The result is written as fp32 (c), as split planes (c_split: the next GEMM's operand), or both.  a_colsum (optional, both operands
+ * K-major, no batch): a_colsum[m] = sum_k A[k][m], the bias gradient of a Linear layer, from the same launch.
+ * M, N % 128 == 0, K % 32 == 0; operand planes 128-byte aligned.  Long-K products with few tiles split K over workgroups with a
+ * fixed-order second pass (deterministic): workspace >= bd_gemm_sp_workspace_bytes().                                           */
+typedef struct {
+    int M, N, K, batch;                          /* batch <= 1: one product                                        */
+    const uint16_t* a; int64_t lda, a_bs; int a_kmajor;
+    const uint16_t* b; int64_t ldb, b_bs; int b_kmajor;
+    float* c; int64_t ldc, c_bs;                 /* fp32 output [batch][M][ldc] or NULL                            */
+    uint16_t* c_split; int64_t ldcs, cs_bs;      /* split-plane output (rows of ldcs 4-byte units) or NULL         */
+    const float* bias;                           /* [N] or NULL                                                    */
+    const float* residual; int64_t ldr, r_bs;    /* [batch][M][ldr] or NULL                                        */
+    float alpha, out_scale;
+    int accumulate;                              /* c += ...  (needs c)                                            */
+    float* a_colsum;                             /* [M] or NULL                                                    */
+    void* workspace; size_t workspace_bytes;
+} bd_gemm_sp_desc;
+size_t bd_gemm_sp_workspace_bytes(const bd_gemm_sp_desc* d);
+int bd_gemm_sp(const bd_gemm_sp_desc* d, bd_stream_t stream);
+
+/* Attention core on split planes (attention.py:148-162 and its backward), N = 256 tokens, head dim 256:
+ *   forward : o = softmax(scale * q k^T) v                         [+ pt_split = P^T planes, needed by the backward]
+ *   backward: dq = scale * dS k, dk = scale * dS^T q, dv = P^T dO,  dS = P o (dP - rowsum(P o dP)), dP = dO v^T
+ * qkv_split: planes of the QKV projection's output [B*N, ld] (q | k | v column blocks, head h at column h*dh of each);
+ * o_split / do_split [B*N, C]; pt_split / dst_split [B*heads, N, N] planes of the TRANSPOSED probability / score-gradient matrices
+ * (rows = keys); dqkv_split: planes in the layout of qkv_split.  No [N, N] fp32 matrix is written.  The [N, N] products, the softmax
+ * and their backward run in three launches per block instead of eight.  Other shapes: BD_ERR_UNSUPPORTED (bd_attn_sp_supported). */
+typedef struct {
+    int B, heads, N, dh;
+    const uint16_t* qkv_split; int64_t ld;
+    float scale;
+    uint16_t* o_split; int64_t ldo;            /* forward out */
+    uint16_t* pt_split;                        /* forward out (NULL: inference), backward in */
+    const uint16_t* do_split; int64_t lddo;    /* backward in */
+    uint16_t* dst_split;                       /* backward scratch [B*heads, N, N] planes */
+    uint16_t* dqkv_split; int64_t lddqkv;      /* backward out */
+} bd_attn_sp_desc;
+int bd_attn_sp_supported(int N, int dh);
+int bd_attn_sp_fwd(const bd_attn_sp_desc* d, bd_stream_t stream);
+int bd_attn_sp_bwd(const bd_attn_sp_desc* d, bd_stream_t stream);
+
 /* What the matrix pipe alone sustains on THIS board, now: v_mfma_f32_32x32x16_bf16 on register operands only (no memory
  * traffic), 2 workgroups of 512 threads per CU, `iters` x 12 MFMAs per wave, launched `launches` times back to back and timed
  * with a hipEvent pair on `stream` (blocks until done).  random_operands = 0: small constant integers (data-independent

@@ -935,3 +935,73 @@ def test_stride2_conv_dgrad_phase_decomposition(gpu, B, Ho, Wo, Cin, Cout, pad):
     assert relerr(acc, prev + gx) < 1e-6
     old = ops.conv3x3_dgrad(dy.cuda(), w.cuda(), (B, H, W, Cin), stride=2, pad=pad, asym=(pad == 0), mode=1)
     assert relerr(gx, old) < 3e-5
+
+
+@pytest.mark.parametrize("akm,bkm", [(False, False), (False, True), (True, True), (True, False)])
+@pytest.mark.parametrize("M,N,K,batch", [(256, 128, 256, 3), (128, 384, 96, 1), (384, 256, 4096, 1)])
+def test_gemm_on_split_planes(gpu, akm, bkm, M, N, K, batch):
+    """bd_gemm_sp (the attention block's Linear layers and batched products, attention.py:85-186) in its four operand forms --
+    K-contiguous / K-major A and B -- with fp32 and split-plane results, bias, residual, out_scale, accumulate; long K takes the
+    split-K path (fixed-order second pass), where the column sums of A (a Linear layer's bias gradient) ride along."""
+    from baddiffusion_amd import ops
+    g = torch.Generator().manual_seed(M + 3 * N + K + batch + 2 * akm + bkm)
+    A = torch.randn(batch, M, K, generator=g).cuda(); Bm = torch.randn(batch, N, K, generator=g).cuda() * 0.1
+    a_s = ops.split_rows((A.transpose(1, 2) if akm else A).contiguous())
+    b_s = ops.split_rows((Bm.transpose(1, 2) if bkm else Bm).contiguous())
+    bias = torch.randn(N, generator=g).cuda(); res = torch.randn(batch, M, N, generator=g).cuda()
+    ref = 0.7 * (0.25 * A.double() @ Bm.double().transpose(1, 2) + bias.double() + res.double())
+    c, cs = ops.gemm_sp(a_s, b_s, M, N, K, a_kmajor=akm, b_kmajor=bkm, batch=batch, bias=bias, residual=res, alpha=0.25, out_scale=0.7,
+                        want_split=True)
+    assert relerr(c, ref) < 2e-5
+    assert relerr(ops.unsplit_rows(cs), ref) < 2e-5
+    assert torch.equal(ops.unsplit_rows(cs), ops.unsplit_rows(ops.split_rows(c)).view(batch, M, N))   # the planes ARE the split of the fp32 result
+    prev = torch.randn(batch, M, N, generator=g).cuda()
+    acc, _ = ops.gemm_sp(a_s, b_s, M, N, K, a_kmajor=akm, b_kmajor=bkm, batch=batch, out=prev.clone(), accumulate=True)
+    assert relerr(acc, prev.double() + A.double() @ Bm.double().transpose(1, 2)) < 2e-5
+    if akm and bkm and batch == 1:
+        c2, _, colsum = ops.gemm_sp(a_s, b_s, M, N, K, a_kmajor=True, b_kmajor=True, want_colsum=True)
+        assert relerr(c2, A.double() @ Bm.double().transpose(1, 2)) < 2e-5
+        assert relerr(colsum, A[0].double().sum(1)) < 2e-5
+    # shapes outside the kernel's tiling are refused, not mangled
+    with pytest.raises(RuntimeError):
+        ops.gemm_sp(a_s, b_s, M - 32, N, K, a_kmajor=akm, b_kmajor=bkm, batch=batch)
+
+
+@pytest.mark.parametrize("B,heads", [(1, 1), (3, 1), (2, 2)])
+def test_attention_core_on_split_planes(gpu, B, heads):
+    """bd_attn_sp_fwd / bd_attn_sp_bwd: softmax(scale q k^T) v and its backward (attention.py:148-162) without an [N, N] fp32 matrix,
+    against fp64; P^T / dS^T planes are what the two backward kernels hand to each other.  N = 256 tokens, head dim 256."""
+    from baddiffusion_amd import ops
+    N, dh = 256, 256
+    Cc = heads * dh
+    g = torch.Generator().manual_seed(10 * B + heads)
+    qkv = torch.randn(B * N, 3 * Cc, generator=g).cuda(); do = torch.randn(B * N, Cc, generator=g).cuda()
+    scale = dh ** -0.5
+    qs, dos = ops.split_rows(qkv), ops.split_rows(do)
+    o_s, pt_s = ops.attn_sp_fwd(qs, B, heads, scale)
+    o_inf, none = ops.attn_sp_fwd(qs, B, heads, scale, want_pt=False)
+    assert none is None and relerr(ops.unsplit_rows(o_inf), ops.unsplit_rows(o_s)) < 1e-5   # the inference form (no P^T) is its own instantiation
+    o_again, pt_again = ops.attn_sp_fwd(qs, B, heads, scale)
+    assert torch.equal(o_s, o_again) and torch.equal(pt_s, pt_again)                          # run-to-run: bit-identical
+    dqkv_s, dst_s = ops.attn_sp_bwd(qs, pt_s, dos, B, heads, scale)
+    D = lambda t: t.double()
+    def heads_of(x):   # [B*N, heads*dh] -> [B*heads, N, dh]
+        return D(x).view(B, N, heads, dh).permute(0, 2, 1, 3).reshape(B * heads, N, dh)
+    q, k, v = (heads_of(qkv[:, i * Cc:(i + 1) * Cc]) for i in range(3))
+    P = torch.softmax(scale * q @ k.transpose(1, 2), -1)
+    O = P @ v
+    dO = heads_of(do)
+    dP = dO @ v.transpose(1, 2)
+    dS = P * (dP - (P * dP).sum(-1, keepdim=True))
+    unheads = lambda x: x.view(B, heads, N, dh).permute(0, 2, 1, 3).reshape(B * N, Cc)
+    # norm-relative tolerances: 5e-5 forward, 1e-4 for the gradients (dS = P o (dP - delta) cancels; the task's bound is 1e-3)
+    assert relerr(ops.unsplit_rows(o_s), unheads(O)) < 5e-5
+    assert relerr(ops.unsplit_rows(pt_s), P.transpose(1, 2)) < 5e-5
+    assert relerr(ops.unsplit_rows(dst_s), scale * dS.transpose(1, 2)) < 1e-4
+    dqkv = ops.unsplit_rows(dqkv_s)
+    assert relerr(dqkv[:, :Cc], unheads(scale * dS @ k)) < 1e-4
+    assert relerr(dqkv[:, Cc:2 * Cc], unheads(scale * dS.transpose(1, 2) @ q)) < 1e-4
+    assert relerr(dqkv[:, 2 * Cc:], unheads(P.transpose(1, 2) @ dO)) < 1e-4
+    # other sequence lengths / head sizes keep the unfused path: the entry refuses them
+    with pytest.raises(RuntimeError):
+        ops.attn_sp_fwd(ops.split_rows(torch.randn(2 * 64, 3 * 256).cuda()), 2, 1, scale)
