@@ -388,11 +388,20 @@ __global__ __launch_bounds__(256) void gemm_sp_reduce(SpParams p) {
         *reinterpret_cast<uint4*>(o + 64) = make_uint4(lo[0], lo[1], lo[2], lo[3]);
     }
 }
-__global__ __launch_bounds__(256) void gemm_sp_colsum_reduce(const float* __restrict__ rows, int ksplit, int M, float* __restrict__ out) {
-    const int m = blockIdx.x * 256 + threadIdx.x;
+// column-sum rows of the K split: one thread per column, eight slab loads in flight (a serial chain of `ksplit` dependent-latency loads took 11 us for 64 slabs), summed in slab order
+__global__ __launch_bounds__(64) void gemm_sp_colsum_reduce(const float* __restrict__ rows, int ksplit, int M, float* __restrict__ out) {
+    const int m = blockIdx.x * 64 + threadIdx.x;
     if (m >= M) return;
     float v = 0.f;
-    for (int s = 0; s < ksplit; ++s) v += rows[(long long)s * M + m];
+    int s = 0;
+    for (; s + 8 <= ksplit; s += 8) {
+        float t[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) t[j] = rows[(long long)(s + j) * M + m];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v += t[j];
+    }
+    for (; s < ksplit; ++s) v += rows[(long long)s * M + m];
     out[m] = v;
 }
 
@@ -475,7 +484,7 @@ int gemm_sp(const bd_gemm_sp_desc& d, hipStream_t st) {
         const long long work = (long long)d.M * (d.N / 8);
         hipLaunchKernelGGL(gemm_sp_reduce, dim3((unsigned)cdiv(work, 256)), dim3(256), 0, st, p);
         if (p.want_colsum)
-            hipLaunchKernelGGL(gemm_sp_colsum_reduce, dim3((unsigned)cdiv(d.M, 256)), dim3(256), 0, st,
+            hipLaunchKernelGGL(gemm_sp_colsum_reduce, dim3((unsigned)cdiv(d.M, 64)), dim3(64), 0, st,
                                p.partial + (long long)p.ksplit * d.M * d.N, p.ksplit, d.M, d.a_colsum);
         BD_LAUNCH_CHECK("gemm_sp_reduce");
     }
