@@ -220,7 +220,7 @@ def run_sampling(model, kind, n, mode, world, rank, dev, lib, want_roofline=True
     init = torch.randn(n, 3, 32, 32, generator=torch.Generator().manual_seed(rank)).to(dev)
     gen = torch.Generator(device=dev).manual_seed(1 + rank)
     pipe(batch_size=n, init=init[:min(n, 64)], generator=gen, num_inference_steps=min(steps, 5), output_type=None)   # warm-up
-    pipe(batch_size=n, init=init, generator=gen, num_inference_steps=2, output_type=None)                             # + the full chunk shape
+    pipe(batch_size=n, init=init, generator=gen, num_inference_steps=5 if pndm else 2, output_type=None)            # + the full chunk shape (PNDM: >= 4 steps)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -243,7 +243,7 @@ def run_sampling(model, kind, n, mode, world, rank, dev, lib, want_roofline=True
            "images_finite": bool(np.isfinite(np.asarray(out.images)).all())}
     if want_roofline:
         lib.bd_prof_reset(); lib.bd_prof_enable(1)
-        pipe(batch_size=n, init=init[:min(n, model.max_chunk)], generator=gen, num_inference_steps=3, output_type=None)
+        pipe(batch_size=n, init=init[:min(n, model.max_chunk)], generator=gen, num_inference_steps=5 if pndm else 3, output_type=None)
         lib.bd_prof_enable(0)
         torch.cuda.synchronize()
         cl = _read_classes(lib)
