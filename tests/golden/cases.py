@@ -35,6 +35,8 @@ def backdoor_images():
 RESNET_CASES = {"res_128_128": (128, 128, 8), "res_128_256": (128, 256, 8), "res_512_256": (512, 256, 4)}
 # name -> (C, hw, head_dim)
 ATTN_CASES = {"attn_256_h1": (256, 8, None), "attn_256_hd8": (256, 4, 8), "attn_128_h1": (128, 4, None)}
+# the attention blocks the split-plane path takes (256 tokens = 16 x 16, head dim 256): one head as in the CIFAR topology, and two heads
+ATTN_SP_CASES = {"attn_256_n256": (256, 16, None), "attn_512_n256_hd256": (512, 16, 256)}
 # name -> (C, hw, padding)
 DOWN_CASES = {"down_128_p0": (128, 8, 0), "down_128_p1": (128, 8, 1)}
 UP_CASES = {"up_128": (128, 4)}
@@ -50,8 +52,8 @@ def _module_shapes(name):
         if cin != cout:
             s["conv_shortcut.weight"] = (cout, cin, 1, 1); s["conv_shortcut.bias"] = (cout,)
         return s
-    if name in ATTN_CASES:
-        C = ATTN_CASES[name][0]
+    if name in ATTN_CASES or name in ATTN_SP_CASES:
+        C = (ATTN_CASES.get(name) or ATTN_SP_CASES[name])[0]
         s = {"group_norm.weight": (C,), "group_norm.bias": (C,)}
         for n in ("query", "key", "value", "proj_attn"):
             s[n + ".weight"] = (C, C); s[n + ".bias"] = (C,)
@@ -82,7 +84,7 @@ def resnet_inputs(name):
 
 
 def attn_inputs(name):
-    C, hw, _ = ATTN_CASES[name]
+    C, hw, _ = ATTN_CASES.get(name) or ATTN_SP_CASES[name]
     return _r(51, MOD_B, C, hw, hw), _r(52, MOD_B, C, hw, hw)
 
 

@@ -18,6 +18,8 @@ Fixtures:
   full_size.npz G10 BASELINE configs[1] at its real size (DDPM-CIFAR10-32 topology, B=128 train step) and the real
                     DDPM-CELEBA-HQ-256 network at 256x256, B=1 (forward + backward): what the reference computes, so the
                     full-size GPU tests compare with the reference and not with the product's other arithmetic mode
+  attn_planes.npz G11 AttentionBlock forward + backward at 16 x 16 (256 tokens, head dim 256; one and two heads): the shapes the
+                    split-plane attention path takes (modules.npz has 8 x 8 / 4 x 4 blocks, which stay on the unfused path)
   pndm.npz      G9  PNDMScheduler timesteps + full chains with a stand-in model, the scheduler every `--sched` other than
                     DDPM / DDIM ends up as (pipeline_pndm.py:46 converts whatever it is given), PNDMPipeline images
 """
@@ -206,6 +208,19 @@ def g5():
     save("modules.npz", **out)
 
 
+def g11():
+    from tests.golden.cases import ATTN_SP_CASES
+    out = {}
+    for name, (C, hw, hd) in ATTN_SP_CASES.items():
+        P = module_params(name)
+        m = load_sub(AttentionBlock(C, num_head_channels=hd, norm_num_groups=32, eps=1e-6), P, "")
+        x, dy = attn_inputs(name); x.requires_grad_(True)
+        y = m(x); y.backward(dy)
+        out[f"{name}_y"] = y; out[f"{name}_dx"] = x.grad
+        out.update(grads_summary(m, name + "_"))
+    save("attn_planes.npz", **out)
+
+
 def ref_unet(cfg, P):
     m = UNet2DModel(sample_size=cfg.sample_size, in_channels=cfg.in_channels, out_channels=cfg.out_channels,
                     block_out_channels=cfg.block_out_channels, down_block_types=cfg.down_block_types,
@@ -360,6 +375,6 @@ def g10():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
     for w in which:
         globals()[w]()

@@ -3,7 +3,8 @@
 resnet.py:199-208, Upsample2D resnet.py:126-161 -- outputs, input gradients, time-embedding gradients, norm + first 8
 values of every parameter gradient).  Each block is composed from the C-ABI entry points exactly as the plan
 (csrc/unet_plan.cpp) wires them, once through the igemm convolutions (exact fp32 and split-bf16) and once through the
-LDS-DMA split-plane family (bd_conv3x3_ps / bd_conv3x3_ps_wgrad / bd_split_rows / bd_split_wt).
+LDS-DMA split-plane family (bd_conv3x3_ps / bd_conv3x3_ps_wgrad / bd_split_rows / bd_split_wt); the 16 x 16 attention blocks also through
+bd_gemm_sp / bd_attn_sp_fwd / bd_attn_sp_bwd against tests/golden/attn_planes.npz (G11).
 Tolerance 1e-3 relative (north_star); observed ~1e-5."""
 import numpy as np
 import pytest
@@ -175,6 +176,49 @@ def test_attention_block_vs_reference(ops, golden, name, mode):
     grads["group_norm.weight"], grads["group_norm.bias"] = dgw, dgb
     dx = dx + dyh
     assert rel(nchw(dx.reshape(B, hw, hw, Cc)), g[f"{name}_dx"]) < 1e-3
+    check_grads(grads, g, name)
+
+
+@pytest.mark.parametrize("name", list(C.ATTN_SP_CASES))
+def test_attention_block_on_split_planes_vs_reference(ops, golden, name):
+    """AttentionBlock (attention.py:121-174) forward + backward at 16 x 16 through the split-plane path exactly as the plan wires it
+    (unet_plan.cpp node_attention, use_sp): GroupNorm -> planes, bd_gemm_sp (QKV projection, planes out), bd_attn_sp_fwd, bd_gemm_sp (output
+    projection + bias + residual); backward: planes of dy, bd_gemm_sp weight / data gradients, bd_attn_sp_bwd, GroupNorm backward --
+    against what the reference's own module computed (tests/golden/attn_planes.npz, G11): y, dx, every parameter gradient."""
+    g = golden("attn_planes")
+    Cc, hw, hd = C.ATTN_SP_CASES[name]
+    heads = 1 if hd is None else Cc // hd
+    N = hw * hw
+    P = {k: v.cuda() for k, v in C.module_params(name).items()}
+    x, dy = C.attn_inputs(name)
+    B = x.shape[0]
+    M = B * N
+    xh, dyh = nhwc(x).reshape(B, N, Cc), nhwc(dy).reshape(B, N, Cc)
+    scale = 1.0 / (Cc / heads) ** 0.5
+    wqkv = torch.cat([P["query.weight"], P["key.weight"], P["value.weight"]]).contiguous()
+    bqkv = torch.cat([P["query.bias"], P["key.bias"], P["value.bias"]]).contiguous()
+    wq_s, wp_s = ops.split_rows(wqkv), ops.split_rows(P["proj_attn.weight"].contiguous())
+    n, m0, r0 = ops.gn_fwd(xh, P["group_norm.weight"], P["group_norm.bias"], G, EPS, False)
+    n_s = ops.split_rows(n.reshape(M, Cc))
+    _, qkv_s = ops.gemm_sp(n_s, wq_s, M, 3 * Cc, Cc, bias=bqkv, want_f32=False, want_split=True)
+    qkv_s = qkv_s.reshape(M, 3 * Cc // 32, 2, 32)
+    o_s, pt_s = ops.attn_sp_fwd(qkv_s, B, heads, scale)
+    y, _ = ops.gemm_sp(o_s, wp_s, M, Cc, Cc, bias=P["proj_attn.bias"], residual=xh.reshape(1, M, Cc))
+    assert rel(nchw(y.reshape(B, hw, hw, Cc)), g[f"{name}_y"]) < 1e-4
+    # ---- backward
+    dy_s = ops.split_rows(dyh.reshape(M, Cc))
+    dwp, _, dbp = ops.gemm_sp(dy_s, o_s, Cc, Cc, M, a_kmajor=True, b_kmajor=True, want_colsum=True)
+    _, do_s = ops.gemm_sp(dy_s, wp_s, M, Cc, Cc, b_kmajor=True, want_f32=False, want_split=True)
+    dqkv_s, _ = ops.attn_sp_bwd(qkv_s, pt_s, do_s.reshape(M, Cc // 32, 2, 32), B, heads, scale)
+    dwqkv, _, dbqkv = ops.gemm_sp(dqkv_s, n_s, 3 * Cc, Cc, M, a_kmajor=True, b_kmajor=True, want_colsum=True)
+    dn, _ = ops.gemm_sp(dqkv_s, wq_s, M, Cc, 3 * Cc, b_kmajor=True)
+    dx, dgw, dgb = ops.gn_bwd(xh, P["group_norm.weight"], P["group_norm.bias"], m0, r0, dn.reshape(B, N, Cc), G, False)
+    dx = dx + dyh
+    assert rel(nchw(dx.reshape(B, hw, hw, Cc)), g[f"{name}_dx"]) < 1e-3
+    grads = {"proj_attn.weight": dwp[0], "proj_attn.bias": dbp, "group_norm.weight": dgw, "group_norm.bias": dgb}
+    for i, nm in enumerate(("query", "key", "value")):
+        grads[nm + ".weight"] = dwqkv[0][i * Cc:(i + 1) * Cc]
+        grads[nm + ".bias"] = dbqkv[i * Cc:(i + 1) * Cc]
     check_grads(grads, g, name)
 
 

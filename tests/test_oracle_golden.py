@@ -184,6 +184,19 @@ def test_modules_vs_reference(golden):
         _grads_ok(P, g, name)
 
 
+def test_oracle_attention_at_16x16_vs_reference(golden):
+    """G11: the AttentionBlock shapes the split-plane GPU path takes (256 tokens, head dim 256; one and two heads) -- the oracle's block
+    against the reference's module, so the GPU test's comparison target is pinned on the CPU side too"""
+    g = golden("attn_planes")
+    for name, (Cc, hw, hd) in C.ATTN_SP_CASES.items():
+        P = {k: v.requires_grad_(True) for k, v in C.module_params(name).items()}
+        x, dy = C.attn_inputs(name); x.requires_grad_(True)
+        y = U.attention_block(P, "", x, 32, 1e-6, hd)
+        y.backward(dy)
+        close(y, g[f"{name}_y"], 1e-5, 1e-5); close(x.grad, g[f"{name}_dx"], 1e-4, 1e-5)
+        _grads_ok(P, g, name)
+
+
 # ------------------------------------------------------------------ G6 / G7 whole UNet + one train step
 def _train_step_check(cfg, seed, B, tag, g, lr=2e-4):
     _, a, ac = sched_ref.make_tables()
