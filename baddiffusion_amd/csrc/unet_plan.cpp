@@ -380,7 +380,10 @@ struct bd_unet {
         // BD_AUX_MAXPIX (A/B knob): weight gradients over more pixels than this stay on the main stream -- they fill the chip
         // on their own, and beside the dgrad chain they mostly trade clock for overlap
         static const long long maxpix = getenv("BD_AUX_MAXPIX") ? atoll(getenv("BD_AUX_MAXPIX")) : (1ll << 62);
-        if ((long long)d.B * d.H * d.W > maxpix) { d.workspace = c.opws; return conv3x3_ps_wgrad(d, c.st); }
+        // BD_AUX_MINPIX (A/B knob): weight gradients over fewer pixels than this stay on the main stream too -- at 4 x 4 / 8 x 8 a launch is
+        // 10-30 us and the fork / join events cost as much as the overlap returns
+        static const long long minpix = getenv("BD_AUX_MINPIX") ? atoll(getenv("BD_AUX_MINPIX")) : 0;
+        if ((long long)d.B * d.H * d.W > maxpix || (long long)d.B * d.H * d.W < minpix) { d.workspace = c.opws; return conv3x3_ps_wgrad(d, c.st); }
         return on_aux(c, [&](hipStream_t st, char* ws) { d.workspace = ws; return conv3x3_ps_wgrad(d, st); });
     }
     static uint16_t* U16(float* p) { return reinterpret_cast<uint16_t*>(p); }

@@ -11,7 +11,8 @@ ends = [e for (s, e, n, q) in ev if "adam_clip" in n]
 k = int(sys.argv[2]) if len(sys.argv) > 2 else 3
 t0, t1 = ends[-k - 1], ends[-k]
 win = [(max(s, t0), min(e, t1), n, q) for (s, e, n, q) in ev if e > t0 and s < t1]
-mf = lambda n: any(x in n for x in ("igemm", "conv_ps_kernel", "conv_ps128_kernel", "conv_ps_wgrad_kernel", "wgrad_thin"))
+mf = lambda n: any(x in n for x in ("igemm", "conv_ps_kernel", "conv_ps3_kernel", "conv_ps128_kernel", "conv_ps_wgrad_kernel", "conv_ps_wgrad3_kernel",
+                                    "conv_ph_kernel", "gemm_sp_kernel", "attn_sp_", "wgrad_thin"))
 pts = []
 for s, e, n, q in win:
     c = 0 if mf(n) else 1
