@@ -419,8 +419,9 @@ static void sp_split(const bd_gemm_sp_desc& d, int& ksplit, int& cps) {
     const long long tiles = (long long)(d.M / SP_T) * (d.N / SP_T) * (d.batch > 0 ? d.batch : 1);
     static const int forced = getenv("BD_SP_KSPLIT") ? atoi(getenv("BD_SP_KSPLIT")) : 0;
     ksplit = 1;
+    static const int slots = getenv("BD_SP_SLOTS") ? atoi(getenv("BD_SP_SLOTS")) : sp_cus();   // (A/B knob)
     if (d.batch <= 1 && tiles < sp_cus() && nch >= 32) {   // one workgroup per CU: the slabs are written and read once more each
-        ksplit = (int)cdiv(sp_cus(), tiles);
+        ksplit = (int)cdiv(slots, tiles);
         if (ksplit > nch / 8) ksplit = nch / 8;
     }
     if (forced > 0 && d.batch <= 1) ksplit = forced < nch ? forced : nch;

@@ -250,7 +250,8 @@ struct bd_unet {
             if (n > c.opws_need) c.opws_need = n;
             return BD_OK;
         }
-        if (aux) return on_aux(c, [&](hipStream_t st, char* ws) { g.workspace = ws; return gemm_sp(g, st); });
+        static const bool aux_on = !(getenv("BD_SP_WG_AUX") && atoi(getenv("BD_SP_WG_AUX")) == 0);   // (A/B knob: weight gradients on the main stream)
+        if (aux && aux_on) return on_aux(c, [&](hipStream_t st, char* ws) { g.workspace = ws; return gemm_sp(g, st); });
         g.workspace = c.opws;
         return gemm_sp(g, c.st);
     }
