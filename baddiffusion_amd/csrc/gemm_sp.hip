@@ -4,11 +4,11 @@
 //
 // Same arithmetic as igemm.hip / conv_ps.hip (x = hi + lo, lo*hi + hi*lo + hi*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate), but
 // both operands arrive as split planes (per row, every 32-column block is one 128-byte line: 64 B of bf16 hi | 64 B of bf16 lo -- the
-// bytes of the fp32 tensor they replace) and the result can LEAVE as split planes too, so a chain of GEMMs (QKV projection -> Q K^T
-// -> softmax -> P V -> output projection, and the eight GEMMs of its backward, attention.py:85-186) never converts an operand on the
-// way into LDS: the main loop has no VALU work on the data.  igemm.hip splits fp32 operands in registers between the global load and
-// the LDS store; on these K = 256 GEMMs (8 chunks per tile) that conversion and the serial load -> compute -> store of one resident
-// workgroup per CU held them at 170-250 TFLOP/s against ~400 for the convolutions.
+// bytes of the fp32 tensor they replace) and the result can LEAVE as split planes too, so a chain of products (QKV projection ->
+// attention core -> output projection, and the backward chain, attention.py:85-186) passes planes from kernel to kernel and nobody converts
+// an operand on the way into LDS.  Measured: per launch this kernel is at PARITY with the register-staged igemm on
+// the K = 256 shapes (both ~8 us + flops at ~270 TFLOP/s: the L2 -> LDS fill bound of a 128 x 128 tile) -- it is in the plan because the
+// attention core (attn_sp.hip) wants planes in and hands planes out, which is where the step time went down.
 //
 // Either operand may be K-CONTIGUOUS (rows = M or N, a K chunk of a row = one line: weights [N][K], activations [M][K]) or K-MAJOR
 // (rows = K, the M / N index runs along the row: the "pixel-major" operands of a weight gradient, V in P V, K in dS K):
