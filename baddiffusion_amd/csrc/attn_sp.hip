@@ -22,7 +22,9 @@
 //            streamed operand in K-major units [32 rows][128 columns] (16 KB, ring of eight, four units in flight), fragments by
 //            ds_read_b64_tr_b16; the output's two 128-column halves are two sweeps over the 256 rows.
 // LDS 144 KB, registers beyond 256 (accumulators in AGPRs): one workgroup per CU, 256 workgroups at B = 128.
-// N = 256 (16 x 16 feature maps), head dim 128 or 256; other shapes keep the unfused path.
+// N = 256 (16 x 16 feature maps), head dim 256; other shapes keep the unfused path.
+// Measured: 43 / 48 / 49 us at B = 128 against 71 + 118 for the unfused launches; each kernel moves exactly its
+// algorithmic bytes behind the L2 at 3.8-4.1 TB/s, and that -- not the CU side -- is what it waits for.
 #include "common.h"
 
 #include <cstdlib>
