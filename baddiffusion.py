@@ -344,20 +344,32 @@ def checkpoint(config, engine, pipeline, cur_epoch, cur_step):
     torch.save({"m": engine.m.cpu(), "v": engine.v.cpu(), "opt_step": engine.opt_step, "micro": engine.micro},
                os.path.join(config.ckpt_path, "optimizer.bin"))
     # + the random-number state, so that a resumed run draws the noise / timesteps the uninterrupted run would have drawn
-    torch.save({"epoch": cur_epoch, "step": cur_step, "cpu_rng": torch.get_rng_state(),
+    torch.save({"epoch": cur_epoch, "step": cur_step, "world": _world_size(), "cpu_rng": torch.get_rng_state(),
                 "cuda_rng": torch.cuda.get_rng_state() if torch.cuda.is_available() else None}, config.data_ckpt_path)
     pipeline.save_pretrained(config.output_dir)
     if config.is_save_all_model_epochs:
         pipeline.save_pretrained(os.path.join(config.output_dir, config.ep_model_dir, f"ep{cur_epoch}"))
 
 
-def save_rank_rng(config, rank):
+def _world_size():
+    import torch.distributed as dist
+    return dist.get_world_size() if (dist.is_available() and dist.is_initialized()) else 1
+
+
+def capture_rank_rng(cur_epoch, cur_step):
+    """This rank's random-number state, tagged with the checkpoint it belongs to ({epoch, step, world})."""
+    return {"epoch": cur_epoch, "step": cur_step, "world": _world_size(), "cpu_rng": torch.get_rng_state(),
+            "cuda_rng": torch.cuda.get_rng_state() if torch.cuda.is_available() else None}
+
+
+def save_rank_rng(config, rank, state):
     """ranks > 0: their own random-number state next to rank 0's data.ckpt (every rank draws its own noise / timesteps, so a
-    resumed multi-rank run needs one state per rank; rank 0's lives in data.ckpt itself, written by checkpoint())"""
+    resumed multi-rank run needs one state per rank; rank 0's lives in data.ckpt itself, written by checkpoint()).  The file
+    carries the {epoch, step, world} of the checkpoint it belongs to: restore_training_state() refuses a state from another
+    checkpoint (a crash between the two writes, ranks failing at different steps, a stale file of another world size)."""
     if rank == 0:
         return
-    torch.save({"cpu_rng": torch.get_rng_state(), "cuda_rng": torch.cuda.get_rng_state() if torch.cuda.is_available() else None},
-               f"{config.data_ckpt_path}.rank{rank}")
+    torch.save(state, f"{config.data_ckpt_path}.rank{rank}")
 
 
 def restore_training_state(config, engine, rank=0):
@@ -377,10 +389,15 @@ def restore_training_state(config, engine, rank=0):
         epoch, step = st["epoch"], st["step"]
         if rank > 0:
             own = f"{config.data_ckpt_path}.rank{rank}"
-            if os.path.exists(own):
-                st = torch.load(own, map_location="cpu")
+            tag = (epoch, step, st.get("world", _world_size()))
+            mine = torch.load(own, map_location="cpu") if os.path.exists(own) else None
+            if mine is not None and (mine.get("epoch"), mine.get("step"), mine.get("world")) == tag and tag[2] == _world_size():
+                st = mine
             else:
-                print(f"[rank {rank}] no RNG state of its own in the checkpoint: re-seeding with seed + rank (not bit-identical)")
+                why = "no RNG state of its own in the checkpoint" if mine is None else \
+                    f"its RNG state file belongs to another checkpoint ({mine.get('epoch')}, {mine.get('step')}, world {mine.get('world')}) " \
+                    f"than data.ckpt {tag}"
+                print(f"[rank {rank}] {why}: re-seeding with seed + rank (not bit-identical)")
                 torch.manual_seed(config.seed + rank)
                 st = {}
         if st.get("cpu_rng") is not None:
@@ -404,6 +421,7 @@ def train_loop(config, model, noise_sched, get_pipeline, dsl, device, world, ran
     log = open(os.path.join(config.output_dir, "log.jsonl"), "a") if rank == 0 else None
     cur_step = start_step
     epoch = start_epoch
+    saved_at = None
     try:
         for epoch in range(int(start_epoch), int(config.epoch)):
             t0 = time.time()
@@ -416,24 +434,32 @@ def train_loop(config, model, noise_sched, get_pipeline, dsl, device, world, ran
                 if log is not None and step % 50 == 0:
                     rec = {"loss": float(loss), "lr": engine.current_lr(), "epoch": epoch, "step": cur_step}
                     log.write(json.dumps(rec) + "\n"); log.flush()
+            ckpt_now = (epoch + 1) % config.save_model_epochs == 0 or epoch == config.epoch - 1
+            rng_now = capture_rank_rng(epoch, cur_step) if (rank > 0 and ckpt_now) else None
             if rank == 0:
                 print(f"epoch {epoch}: {time.time() - t0:.1f} s, loss {float(loss):.5f}")
                 pipeline = get_pipeline(unet=model, scheduler=noise_sched)
                 if (epoch + 1) % config.save_image_epochs == 0 or epoch == config.epoch - 1:
                     sampling(config, epoch, pipeline, dsl)
-                if (epoch + 1) % config.save_model_epochs == 0 or epoch == config.epoch - 1:
+                if ckpt_now:
                     checkpoint(config, engine, pipeline, epoch, cur_step)
-            elif (epoch + 1) % config.save_model_epochs == 0 or epoch == config.epoch - 1:
-                save_rank_rng(config, rank)
+            if ckpt_now and world > 1:
+                # rank files are written AFTER rank 0's checkpoint exists (rank 0 samples for minutes first): a crash in between
+                # leaves the previous, mutually consistent set; the tags catch whatever is left inconsistent
+                import torch.distributed as dist
+                dist.barrier()
+                save_rank_rng(config, rank, rng_now)
+            saved_at = (epoch, cur_step) if ckpt_now else saved_at
     except Exception:
         traceback.print_exc()          # the reference swallows the exception too (:635-637) but we re-raise below
         raise
     finally:
-        if rank == 0:
-            pipeline = get_pipeline(unet=model, scheduler=noise_sched)
-            checkpoint(config, engine, pipeline, epoch, cur_step)
-        else:
-            save_rank_rng(config, rank)
+        if saved_at != (epoch, cur_step):      # (the regular end-of-run checkpoint above already holds exactly this state)
+            if rank == 0:
+                pipeline = get_pipeline(unet=model, scheduler=noise_sched)
+                checkpoint(config, engine, pipeline, epoch, cur_step)
+            else:       # no barrier on the error path (a failed rank would never arrive): the tags decide on restore
+                save_rank_rng(config, rank, capture_rank_rng(epoch, cur_step))
         if log is not None:
             log.close()
     return get_pipeline(unet=model, scheduler=noise_sched)

@@ -134,11 +134,6 @@ class AttnSpDesc(C.Structure):
                 ("ldo", i64), ("pt_split", vp), ("do_split", vp), ("lddo", i64), ("dst_split", vp), ("dqkv_split", vp), ("lddqkv", i64)]
 
 
-class AttnFwdDesc(C.Structure):
-    _fields_ = [("B", i32), ("heads", i32), ("N", i32), ("dh", i32), ("q", vp), ("k", vp), ("v", vp), ("ld", i64), ("scale", f32),
-                ("o", vp), ("ldo", i64), ("p_out", vp), ("lse", vp)]
-
-
 class UnetConfig(C.Structure):
     _fields_ = [("sample_size", i32), ("in_channels", i32), ("out_channels", i32), ("num_blocks", i32),
                 ("block_out_channels", i32 * 8), ("down_attn", i32 * 8), ("up_attn", i32 * 8),
@@ -196,7 +191,6 @@ SIGNATURES = {
     "bd_conv3x3_workspace_bytes": (sz, [i32] * 8),
     "bd_colsum": (i32, [vp, i64, i64, i32, i64, vp, i64, i32, vp]),
     "bd_sum2x2": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, vp]),
-    "bd_attn_fwd": (i32, [C.POINTER(AttnFwdDesc), vp]),
     "bd_softmax_fwd": (i32, [vp, vp, i64, i32, vp]),
     "bd_softmax_bwd": (i32, [vp, vp, vp, i64, i32, vp]),
     "bd_silu_fwd": (i32, [vp, vp, i64, vp]),
@@ -226,6 +220,7 @@ SIGNATURES = {
     "bd_unet_backward": (i32, [vp, i32, vp, vp, i64, vp, i64, vp, vp, sz, vp]),
     "bd_unet_num_segments": (i32, [vp]),
     "bd_unet_set_aux_stream": (i32, [vp, i32]),
+    "bd_unet_set_static_weights": (i32, [vp, i32]),
     "bd_unet_segment_range": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
     "bd_unet_segment_num_ranges": (i32, [vp, i32]),
     "bd_unet_segment_range_k": (i32, [vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]),

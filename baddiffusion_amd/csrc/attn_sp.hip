@@ -700,9 +700,13 @@ int attn_sp_fwd(const bd_attn_sp_desc& d, hipStream_t st) {
 #ifdef BD_AS_ABLATION
     p.dbg = as_dbg_buf();
 #endif
+    // bench.py roofline: S = Q K^T and O = P V (4 B N^2 dh flop per head); bytes = q, k, v in, o (+ P^T for training) out
+    const double bh = (double)d.B * d.heads, nn = (double)d.N * d.N, nd = (double)d.N * d.dh;
+    const int rec = prof_on() ? prof_begin("attn_sp_fwd", 4.0 * bh * nn * d.dh, 4.0 * bh * (4.0 * nd + (d.pt_split ? nn : 0.0)), st) : -1;
     if (d.pt_split) hipLaunchKernelGGL(attn_sp_fwd_kernel<true>, grid, dim3(AS_NT), 0, st, p);
     else hipLaunchKernelGGL(attn_sp_fwd_kernel<false>, grid, dim3(AS_NT), 0, st, p);
     BD_LAUNCH_CHECK("attn_sp_fwd");
+    prof_end(rec, st);
 #ifdef BD_AS_ABLATION
     as_dbg_print("fwd  S | softmax | O run | tail stores", (int)grid.x, st);
 #endif
@@ -721,11 +725,18 @@ int attn_sp_bwd(const bd_attn_sp_desc& d, hipStream_t st) {
     p.dst = reinterpret_cast<char*>(d.dst_split);
     p.dqkv = reinterpret_cast<char*>(d.dqkv_split); p.lddqkv = d.lddqkv * 4;
     const dim3 grid((unsigned)(d.B * d.heads * 2));
+    // bench.py roofline.  A: dP = dO V^T, dQ = dS K (4 B N^2 dh flop per head; reads k, v, dO, P^T; writes dq, dS^T).
+    // B: dV = P^T dO, dK = dS^T Q (same flops; reads P^T, dS^T, dO, q; writes dk, dv).
+    const double bh = (double)d.B * d.heads, nn = (double)d.N * d.N, nd = (double)d.N * d.dh;
+    int rec = prof_on() ? prof_begin("attn_sp_bwd_a", 4.0 * bh * nn * d.dh, 4.0 * bh * (4.0 * nd + 2.0 * nn), st) : -1;
     hipLaunchKernelGGL(attn_sp_bwd_a_kernel, grid, dim3(AS_NT), 0, st, p);
+    prof_end(rec, st);
 #ifdef BD_AS_ABLATION
     p.dbg = as_dbg_buf();
 #endif
+    rec = prof_on() ? prof_begin("attn_sp_bwd_b", 4.0 * bh * nn * d.dh, 4.0 * bh * (4.0 * nd + 2.0 * nn), st) : -1;
     hipLaunchKernelGGL(attn_sp_bwd_b_kernel, grid, dim3(AS_NT), 0, st, p);
+    prof_end(rec, st);
     BD_LAUNCH_CHECK("attn_sp_bwd");
 #ifdef BD_AS_ABLATION
     as_dbg_print("bwdB slab1 | run1 | slab2+prologue | run2", (int)grid.x, st);

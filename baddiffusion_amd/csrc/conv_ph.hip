@@ -323,7 +323,7 @@ __global__ __launch_bounds__(256) void ups_weff_kernel(const float* __restrict__
         *reinterpret_cast<uint2*>(o) = make_uint2(ph_pack_hi(v0, v1), ph_pack_hi(v2, v3));
         *reinterpret_cast<uint2*>(o + 32) = make_uint2(ph_pack_lo(v0, v1), ph_pack_lo(v2, v3));
     }
-    {   // E^T: row ci = cib*32 + r, 4 consecutive co
+    if (et_out) {   // E^T: row ci = cib*32 + r, 4 consecutive co  (the data gradient's operand: null for inference)
         const float v0 = t[c4][r], v1 = t[c4 + 1][r], v2 = t[c4 + 2][r], v3 = t[c4 + 3][r];
         unsigned short* o = et_out + 2 * (((long long)(cib * 32 + r) * 16 + e) * Cout + cob * 32) + c4;
         *reinterpret_cast<uint2*>(o) = make_uint2(ph_pack_hi(v0, v1), ph_pack_hi(v2, v3));
@@ -411,7 +411,7 @@ static int ph_common(PhParams& p, int B, int H, int W, int C, int N, const void*
 }
 
 int upsample_weights(const float* w, int Cin, int Cout, uint16_t* e_split, uint16_t* et_split, hipStream_t st) {
-    BD_CHECK(w && e_split && et_split, BD_ERR_INVALID, "bd_upsample_weights: null pointer");
+    BD_CHECK(w && e_split, BD_ERR_INVALID, "bd_upsample_weights: null pointer");
     BD_CHECK(Cin % 32 == 0 && Cout % 32 == 0 && Cin > 0 && Cout > 0, BD_ERR_UNSUPPORTED, "bd_upsample_weights: channels %% 32 must be 0");
     hipLaunchKernelGGL(ups_weff_kernel, dim3(Cin / 32, Cout / 32, 16), dim3(256), 0, st, w, Cin, Cout, e_split, et_split);
     BD_LAUNCH_CHECK("ups_weff");

@@ -476,6 +476,13 @@ int gemm_sp(const bd_gemm_sp_desc& d, hipStream_t st) {
     const long long grid = (long long)p.tiles_m * p.tiles_n * batch * p.ksplit;
     BD_CHECK(grid < (1ll << 31), BD_ERR_UNSUPPORTED, "bd_gemm_sp: grid too large");
     const dim3 g((unsigned)grid), b(SP_NT);
+    int rec = -1;
+    if (prof_on()) {   // bench.py roofline: algorithmic flops, unique operand + output bytes (planes are 4 B per element like fp32)
+        const double nb = batch;
+        const double outs = (d.c ? 1.0 : 0.0) + (d.c_split ? 1.0 : 0.0) + (d.residual ? 1.0 : 0.0) + (d.accumulate ? 1.0 : 0.0);
+        rec = prof_begin(d.a_kmajor && d.b_kmajor ? "gemm_sp_tn" : (d.b_kmajor ? "gemm_sp_nn" : (d.a_kmajor ? "gemm_sp_tn_a" : "gemm_sp_nt")),
+                         2.0 * d.M * d.N * (double)d.K * nb, 4.0 * nb * ((double)d.M * d.K + (double)d.N * d.K + outs * d.M * d.N), st);
+    }
     if (d.a_kmajor && d.b_kmajor) hipLaunchKernelGGL((gemm_sp_kernel<true, true>), g, b, 0, st, p);
     else if (d.a_kmajor) hipLaunchKernelGGL((gemm_sp_kernel<true, false>), g, b, 0, st, p);
     else if (d.b_kmajor) hipLaunchKernelGGL((gemm_sp_kernel<false, true>), g, b, 0, st, p);
@@ -489,6 +496,7 @@ int gemm_sp(const bd_gemm_sp_desc& d, hipStream_t st) {
                                p.partial + (long long)p.ksplit * d.M * d.N, p.ksplit, d.M, d.a_colsum);
         BD_LAUNCH_CHECK("gemm_sp_reduce");
     }
+    prof_end(rec, st);
     return BD_OK;
 }
 

@@ -39,8 +39,6 @@ size_t upsample_conv_wgrad_workspace_bytes(const bd_upsample_conv_desc& d);
 size_t upsample_conv_dgrad_workspace_bytes(const bd_upsample_conv_desc& d);
 bool upsample_conv_ps_supported(int B, int H, int W, int Cin, int Cout);
 int conv3x3_s2_dgrad_ps(const bd_conv3x3_s2_dgrad_desc& d, hipStream_t st);
-int attn_fwd(const bd_attn_fwd_desc& d, hipStream_t st);                             // attn.hip
-bool attn_fwd_supported(int N, int dh);
 int gemm_sp(const bd_gemm_sp_desc& d, hipStream_t st);                              // gemm_sp.hip
 size_t gemm_sp_workspace_bytes(const bd_gemm_sp_desc& d);
 bool gemm_sp_supported(int M, int N, int K);
@@ -61,6 +59,9 @@ struct Buf {
     int region = R_VALUE, group = 0;
     int64_t off = 0;  // floats, filled by layout()
     int gbuf = -1;    // grad buffer of a value buffer
+    // optional: decided per (batch, training) at layout time -- a buffer only one of several kernel paths uses takes no room
+    // when the plan selects another path for that batch (b_xuS vs b_xS / E / E^T of the upsample convolutions)
+    std::function<bool(int, int)> live;
 };
 
 struct Param {
@@ -146,7 +147,10 @@ struct bd_unet {
     int64_t p_tw = 0, p_tb = 0;  // offsets of the batched time_emb_proj weight / bias
     int b_tproj = -1, b_dtproj = -1, b_embs = -1;
     std::vector<long long> wt_off; std::vector<int> wt_cin, wt_cout;   // 3x3 conv weights with a transposed split copy
-    struct UpsW { int64_t pw; int C; int b_e, b_et; };                 // upsample convolutions: E / E^T planes rebuilt every forward
+    struct UpsW { int64_t pw; int C, H, W; int b_e, b_et; };           // upsample convolutions on the phase path: E (/ E^T when training) planes
+    // weight preprocessing (split copy, E planes) is skipped while the caller promises constant weights (bd_unet_set_static_weights):
+    // a sampling loop runs 50-1000 forwards over the same parameters
+    int static_weights = 0; const void* prep_params = nullptr; const void* prep_ws = nullptr; int prep_B = -1;
     std::vector<UpsW> upsw;
 
     // ---------------------------------------------------------------- construction helpers
@@ -694,7 +698,7 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
     // operand of its data gradient as it stands).  N = 256 tokens, head dim 256 (attn_sp_supported); the mid block (4 x 4) stays below.
     auto use_sp = [=](const Ctx& c) {
         return cfg.compute_mode == BD_MODE_BF16X3 && (c.dry || c.w_split) && attn_sp_supported(N, dh) &&
-               gemm_sp_supported((int)((int64_t)c.B * N), C, C) && gemm_sp_supported(3 * C, C, 32);
+               gemm_sp_supported((int)((int64_t)(c.LB > 0 ? c.LB : c.B) * N), C, C) && gemm_sp_supported(3 * C, C, 32);
     };
     F([=](Ctx& c) {
         const int M = (int)rows(c, x);
@@ -731,17 +735,7 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
         BD_TRY(gn_fwd(c, x, pgw, pgb, BP(c, b_n), C, b_st, 0));
         BD_TRY(linear_fwd(c, BP(c, b_n), C, c.params + pqw, c.params + pqb, BP(c, b_qkv), 3 * C, M, 3 * C, C));
         float* qkv = BP(c, b_qkv);
-        // Fused QK^T -> softmax -> PV (attn.hip): S / P stay on chip, P is written only when backward will need it.  OPT-IN
-        // (BD_ATTN_FUSED=1): with fp32 operands split on the way into LDS the kernel is load-latency bound and measures
-        // 80 us against 74 us for the three unfused launches at B = 128, N = 256, d = 256, so the
-        // default stays unfused until the QKV projection can hand over split planes for a DMA-fed version.
-        static const bool fuse_on = getenv("BD_ATTN_FUSED") && atoi(getenv("BD_ATTN_FUSED")) == 1;
-        if (fuse_on && cfg.compute_mode == BD_MODE_BF16X3 && attn_fwd_supported(N, dh)) {
-            bd_attn_fwd_desc a = {};
-            a.B = c.B; a.heads = heads; a.N = N; a.dh = dh; a.q = qkv; a.k = qkv + C; a.v = qkv + 2 * C; a.ld = 3 * C;
-            a.scale = sm_scale; a.o = BP(c, b_o); a.ldo = C; a.p_out = c.training ? BP(c, b_p) : nullptr;
-            if (!c.dry) BD_TRY(attn_fwd(a, c.st));
-        } else {
+        {
             {   // S = scale * Q K^T
                 bd_igemm_desc g = {};
                 g.A = dense(qkv, 3 * C, 1); g.A.bs_outer = (int64_t)N * 3 * C; g.A.bs_inner = dh;
@@ -900,7 +894,15 @@ void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y
     // phase-decomposed path (round 3): x as split planes on the SOURCE grid + the pre-summed tap planes E / E^T of this layer
     const int b_xS = new_buf((int64_t)H * W * C, 0, R_VALUE);
     const int b_e = new_buf(0, (int64_t)16 * C * C, R_VALUE), b_et = new_buf(0, (int64_t)16 * C * C, R_VALUE);
-    if (C % 128 == 0) upsw.push_back({pw, C, b_e, b_et});
+    if (C % 128 == 0) upsw.push_back({pw, C, H, W, b_e, b_et});
+    {   // which of the two operand sets exists is the plan's path choice for the batch the workspace is laid out for
+        auto phase_at = [=](int B) { Ctx q; q.dry = true; q.B = q.LB = B; return phase_ok(q, H, W, C, C); };
+        auto ps_at = [=](int B) { Ctx q; q.dry = true; q.B = q.LB = B; return ps_ok(q, 2 * H, 2 * W, C, C); };
+        bufs[b_xuS].live = [=](int B, int) { return !phase_at(B) && ps_at(B); };
+        bufs[b_xS].live = [=](int B, int) { return phase_at(B); };
+        bufs[b_e].live = [=](int B, int) { return phase_at(B); };
+        bufs[b_et].live = [=](int B, int training) { return training && phase_at(B); };
+    }
     F([=](Ctx& c) {
         if (phase_ok(c, H, W, C, C)) {
             BD_TRY(split_rows(c, VP(c, x), x.ld, (int64_t)c.B * H * W, C, BP(c, b_xS)));
@@ -1168,7 +1170,7 @@ void bd_unet::layout(int B, int training) {
     if (lay_B == B && lay_train == training) return;
     auto al = [](int64_t x) { return (x + 63) / 64 * 64; };
     int64_t v = 0, g = 0;
-    for (auto& b : bufs) if (b.region == R_VALUE) { b.off = v; v += al(b.per_sample * B + b.fixed); }
+    for (auto& b : bufs) if (b.region == R_VALUE) { b.off = v; if (!b.live || b.live(B, training)) v += al(b.per_sample * B + b.fixed); }
     value_floats = v;
     for (auto& b : bufs) if (b.region == R_GRAD) { b.off = v + g; g += al(b.per_sample * B + b.fixed); }
     grad_floats = training ? g : 0;
@@ -1251,6 +1253,12 @@ extern "C" int bd_unet_stream_wait_aux(bd_unet* u, bd_stream_t stream) {
     BD_HIP_TRY(hipStreamWaitEvent(S(stream), u->aux_ev_seg, 0));
     return BD_OK;
 }
+extern "C" int bd_unet_set_static_weights(bd_unet* u, int enabled) {
+    BD_CHECK(u, BD_ERR_INVALID, "bd_unet_set_static_weights: null plan");
+    u->static_weights = enabled ? 1 : 0;
+    u->prep_params = nullptr; u->prep_ws = nullptr; u->prep_B = -1;     // turning it on or off always re-reads the weights once
+    return BD_OK;
+}
 extern "C" int bd_unet_set_compute_mode(bd_unet* u, int mode) {
     BD_CHECK(u && (mode == BD_MODE_F32 || mode == BD_MODE_BF16X3), BD_ERR_INVALID, "bd_unet_set_compute_mode: bad arguments");
     if (u->cfg.compute_mode != mode) u->lay_B = -1;   // the op-workspace bound depends on which kernels the mode selects: lay out again
@@ -1328,12 +1336,16 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
     BD_CHECK(aligned16(params), BD_ERR_INVALID, "bd_unet_forward: params must be 16-byte aligned");
     c.params = params; c.x = x; c.ldx = ldx; c.t = t; c.t_stride = t_stride; c.out = out; c.ldo = ldo; c.st = S(stream);
     c.training = training != 0;
-    if (c.w_split) {   // split the weights once; forward convs and (same workspace) the backward dgrads read the copy
+    const bool prepared = u->static_weights && !training && u->prep_params == (const void*)params && u->prep_ws == workspace && u->prep_B == B;
+    if (c.w_split && !prepared) {   // split the weights once; forward convs and (same workspace) the backward dgrads read the copy
         BD_TRY(bd_split_bf16(params, (int64_t)wsplit_elems(u), const_cast<uint16_t*>(c.w_split), stream));
-        // pre-summed tap planes of the upsample convolutions (both forward pipelines read them: before the fork)
+        // pre-summed tap planes of the upsample convolutions that take the phase path (both forward pipelines read them: before
+        // the fork); the transposed set E^T is the data gradient's operand: training only
         for (const auto& uw : u->upsw)
-            if (upsample_conv_ps_supported(B, 1, 1, uw.C, uw.C))
-                BD_TRY(upsample_weights(params + uw.pw, uw.C, uw.C, bd_unet::U16(u->BP(c, uw.b_e)), bd_unet::U16(u->BP(c, uw.b_et)), c.st));
+            if (u->phase_ok(c, uw.H, uw.W, uw.C, uw.C))
+                BD_TRY(upsample_weights(params + uw.pw, uw.C, uw.C, bd_unet::U16(u->BP(c, uw.b_e)),
+                                        training ? bd_unet::U16(u->BP(c, uw.b_et)) : nullptr, c.st));
+        u->prep_params = u->static_weights && !training ? (const void*)params : nullptr; u->prep_ws = workspace; u->prep_B = B;
     }
     // transposed split planes of the 3x3 conv weights for the backward's data gradients: one launch, needed only in training
     auto transpose_weights = [&](hipStream_t st) -> int {
@@ -1411,6 +1423,12 @@ extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float*
         BD_TRY(unet_aux_init(u));
         c.st2 = u->aux_stream; c.ev_fork = u->aux_ev_fork; c.ev_join[0] = u->aux_ev_join[0]; c.ev_join[1] = u->aux_ev_join[1];
         if (seg > 0 && u->aux_defer) { c.pend[0] = u->aux_pend[0]; c.pend[1] = u->aux_pend[1]; }
+        else if (u->aux_pend[0] || u->aux_pend[1]) {
+            // a pass that starts (seg 0 / whole backward) while marks of an earlier, unfinished pass are still set: its weight gradients
+            // may still be reading the scratch arenas -- order this pass behind everything that pass put on the side stream
+            BD_HIP_TRY(hipStreamWaitEvent(c.st, u->aux_ev_seg, 0));
+            u->aux_pend[0] = u->aux_pend[1] = false;
+        }
     }
     // grad-init flags must reflect everything executed before this segment: replay them (host-only)
     for (auto it = u->bwd.rbegin(); it != u->bwd.rend(); ++it) {

@@ -479,28 +479,6 @@ def sum2x2(du):
     return dx
 
 
-def attn_fwd(qkv, heads, scale, want_p=False, want_lse=False):
-    """Fused attention forward on the QKV projection's output qkv [B, N, 3C] (q | k | v column blocks, head h at column
-    h*dh of each): returns o [B, N, C] (+ probabilities [B*heads, N, N], + row log-sum-exp [B*heads, N])."""
-    lib = L.load(); _need_cuda(qkv)
-    B, N, C3 = qkv.shape
-    Cc = C3 // 3
-    dh = Cc // heads
-    o = torch.empty(B, N, Cc, device=qkv.device)
-    pm = torch.empty(B * heads, N, N, device=qkv.device) if want_p else None
-    lse = torch.empty(B * heads, N, device=qkv.device) if want_lse else None
-    base = qkv.data_ptr()
-    d = L.AttnFwdDesc(B=B, heads=heads, N=N, dh=dh, q=base, k=base + 4 * Cc, v=base + 8 * Cc, ld=C3, scale=scale, o=L.ptr(o), ldo=Cc,
-                      p_out=L.ptr(pm), lse=L.ptr(lse))
-    L.check(lib.bd_attn_fwd(C.byref(d), L.stream()), "bd_attn_fwd")
-    out = [o]
-    if want_p:
-        out.append(pm)
-    if want_lse:
-        out.append(lse)
-    return out[0] if len(out) == 1 else tuple(out)
-
-
 def attn_sp_fwd(qkv_split, B, heads, scale, want_pt=True, C_=None):
     """Attention core forward on the planes of the QKV projection's output [B*N, 3C/32, 2, 32] (include/bd_hip.h bd_attn_sp_fwd):
     returns (o_split [B*N, C/32, 2, 32], pt_split [B*heads, N, N/32, 2, 32] or None)."""

@@ -24,6 +24,21 @@ class ImagePipelineOutput:
         self.movie = movie if movie is not None else []
 
 
+def _static_weights(call):
+    """The sampling loop evaluates the UNet num_inference_steps times over the same parameters: promise that to the plan so it
+    prepares the weights (split-plane copy, upsample tap planes) once per loop instead of once per evaluation."""
+    import functools
+
+    @functools.wraps(call)
+    def wrapped(self, *a, **kw):
+        sw = getattr(self.unet, "static_weights", None)
+        if sw is None:
+            return call(self, *a, **kw)
+        with sw():
+            return call(self, *a, **kw)
+    return wrapped
+
+
 class _PipelineBase:
     supports_u8 = True      # output_type="u8" returns device uint8 images (batch_sampling_save's overlapped PNG path)
 
@@ -97,6 +112,7 @@ class _PipelineBase:
 
 
 class DDPMPipeline(_PipelineBase):
+    @_static_weights
     @torch.no_grad()
     def __call__(self, batch_size=1, generator=None, num_inference_steps=1000, start_from=0, output_type="pil", init=None,
                  save_every_step=False, return_dict=True, **kwargs):
@@ -136,6 +152,7 @@ class DDIMPipeline(_PipelineBase):
         scheduler = DDIMScheduler.from_config(scheduler.config)
         super().__init__(unet, scheduler)
 
+    @_static_weights
     @torch.no_grad()
     def __call__(self, batch_size=1, generator=None, eta=0.0, num_inference_steps=50, use_clipped_model_output=None,
                  output_type="pil", init=None, save_every_step=False, return_dict=True, **kwargs):
@@ -184,6 +201,7 @@ class PNDMPipeline(_PipelineBase):
     def decode(self, image, *args, **kwargs):
         return image
 
+    @_static_weights
     @torch.no_grad()
     def __call__(self, batch_size=1, num_inference_steps=50, start_from=0, generator=None, output_type="pil", init=None,
                  save_every_step=False, return_dict=True, **kwargs):

@@ -33,21 +33,42 @@ class DPReducer:
     produces them (RCCL over xGMI on the GPUs; gloo on CPU tensors in the tests).  The loss gradient is
     pre-scaled by 1/world, so the sum is the global-batch mean gradient."""
 
-    def __init__(self, flat, process_group=None):
+    def __init__(self, flat, process_group=None, force=False, shadow=None):
         self.flat, self.pg = flat, process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
+        self.shadow = shadow          # ordering check (TrainEngine(dp_check=True)): what the collective's stream saw, see there
         self.works = []
         self.bytes = 0
 
     def reduce_range(self, lo, hi):
-        if self.world > 1 and hi > lo:
+        if self.active and hi > lo:
             self.works.append(dist.all_reduce(self.flat[lo:hi], group=self.pg, async_op=True))
             self.bytes += 4 * (hi - lo)
+            if self.shadow is not None:
+                # snapshot the range on the stream that ISSUED the collective, right behind it: it reads the gradient at the
+                # point in time the collective's kernels may read it
+                self.shadow[lo:hi].copy_(self.flat[lo:hi])
 
     def finish(self):
         for w in self.works:
             w.wait()
         self.works = []
+
+
+def ensure_single_rank_group(backend=None):
+    """A 1-rank process group in this process (BD_FORCE_DP=1: the data-parallel code path -- comm stream, side-stream event
+    wait, async RCCL all-reduce per finished gradient range -- on ONE GPU, so that its stream ordering runs on hardware before
+    a multi-GPU node exists).  No-op when a group is already initialised."""
+    if dist.is_available() and dist.is_initialized():
+        return
+    import socket
+    backend = backend or os.environ.get("BD_DIST_BACKEND", "nccl")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    kw = {"device_id": torch.device("cuda", torch.cuda.current_device())} if backend == "nccl" else {}
+    dist.init_process_group(backend, init_method=f"tcp://127.0.0.1:{port}", world_size=1, rank=0, **kw)
 
 
 def plan_segments(model):
@@ -73,7 +94,7 @@ def plan_segment_ranges(model):
 class TrainEngine:
     def __init__(self, model, noise_sched, lr=2e-4, betas=(0.9, 0.999), eps=1e-8, max_grad_norm=1.0,
                  lr_warmup_steps=500, num_training_steps=None, loss_type="l2", process_group=None,
-                 grad_accum_steps=1, use_graph=None):
+                 grad_accum_steps=1, use_graph=None, force_dp=None, dp_check=False):
         if not model.flat.is_cuda:
             raise RuntimeError("TrainEngine needs the model on a GPU")
         self.model, self.sched = model, noise_sched
@@ -81,7 +102,19 @@ class TrainEngine:
         self.warmup, self.total_steps = lr_warmup_steps, num_training_steps
         self.loss_type = loss_type
         self.pg = process_group
+        # force_dp / BD_FORCE_DP=1: take the data-parallel path at world == 1 too (a 1-rank RCCL group is created when the
+        # process has none).  dp_check: the optimizer consumes a SNAPSHOT of every gradient range taken on the collective's
+        # stream right behind the all-reduce, and the gradient buffer is filled with NaN before every backward -- a collective
+        # that is not ordered behind the kernels producing its range (side-stream weight gradients, the GroupNorm parameter
+        # fold on the main stream) then ships NaNs / stale values into the weights instead of passing unnoticed (a sum over one
+        # rank is the identity whenever it runs).
+        if force_dp is None:
+            force_dp = os.environ.get("BD_FORCE_DP", "0") == "1"
+        self.force_dp = bool(force_dp)
+        if self.force_dp:
+            ensure_single_rank_group()
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
+        self.dp = self.world > 1 or self.force_dp
         self.accum = int(grad_accum_steps)
         dev = model.flat.device
         n = model.num_flat
@@ -100,12 +133,13 @@ class TrainEngine:
         # step from the host instead of ~700.  Single-process, no gradient accumulation; BD_TRAIN_GRAPH=0/1 overrides.
         if use_graph is None:
             use_graph = os.environ.get("BD_TRAIN_GRAPH", "0") == "1"
-        self.use_graph = bool(use_graph) and self.world == 1 and self.accum == 1
+        self.use_graph = bool(use_graph) and not self.dp and self.accum == 1
         self._graphs = {}
         # deferred join of the weight-gradient side stream (include/bd_hip.h: bd_unet_set_deferred_join); BD_DEFER_JOIN=0 = A/B
         self._defer = os.environ.get("BD_DEFER_JOIN", "1") != "0"
         L.check(self._lib.bd_unet_set_deferred_join(model._plan, 1 if self._defer else 0), "bd_unet_set_deferred_join")
-        self._comm = torch.cuda.Stream(device=dev) if (self.world > 1 and self._defer) else None
+        self._comm = torch.cuda.Stream(device=dev) if (self.dp and self._defer) else None
+        self._dp_shadow = torch.zeros(n, device=dev) if (dp_check and self.dp) else None
         self.collective_bytes = 0
         self.alphas, self.alphas_cumprod = noise_sched.device_tables(dev)
         self.sync_state()
@@ -132,7 +166,11 @@ class TrainEngine:
         pred, ws = model._run_forward(flat, xn, t, training=True)
         loss, dpred = ops.loss_fwd_bwd(pred, tg, self.loss_type, grad_scale=1.0 / (self.world * self.accum))
         B = xn.shape[0]
-        red = DPReducer(self.grads, self.pg)
+        if self._dp_shadow is not None:
+            self.grads.fill_(float("nan"))
+            for plo, phi in model._pads:
+                self.grads[plo:phi].zero_()
+        red = DPReducer(self.grads, self.pg, force=self.force_dp, shadow=self._dp_shadow)
         lo, hi = ctypes.c_int64(), ctypes.c_int64()
         main = torch.cuda.current_stream()
         for s in range(self._nseg):
@@ -140,7 +178,7 @@ class TrainEngine:
                 model._plan, s, B, flat.data_ptr(), xn.data_ptr(), xn.shape[-1], dpred.data_ptr(), dpred.shape[-1],
                 self.grads.data_ptr(), ws.data_ptr(), ws.numel(), L.stream(), ctypes.byref(lo), ctypes.byref(hi)),
                 "bd_unet_backward_segment")
-            if self.world == 1:
+            if not self.dp:
                 continue
             # The segment's weight gradients may still be running on the plan's side stream (deferred join): the collective
             # is issued from a third stream that waits for (a) the main stream's position -- GroupNorm parameter fold, bias
@@ -157,6 +195,8 @@ class TrainEngine:
                 for (rlo, rhi) in self._seg_ranges[s]:
                     red.reduce_range(rlo, rhi)
         red.finish()          # the main stream waits for every collective (work.wait() orders the CURRENT stream)
+        if self._comm is not None:
+            main.wait_stream(self._comm)      # ... and for whatever else the issuing stream did behind them (dp_check snapshots)
         self.collective_bytes = red.bytes
         model._release_ws(ws)
         return loss
@@ -264,5 +304,5 @@ class TrainEngine:
             if self.micro % self.accum == 0:
                 self.optimizer_step(self.acc)
         else:
-            self.optimizer_step(self.grads)
+            self.optimizer_step(self.grads if self._dp_shadow is None else self._dp_shadow)
         return loss

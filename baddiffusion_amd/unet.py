@@ -16,6 +16,7 @@ import numpy as np
 import ctypes as C
 import math
 from collections import OrderedDict
+from contextlib import contextmanager
 
 import torch
 from torch import nn
@@ -119,7 +120,10 @@ class UNet2DModel(nn.Module):
             attention_head_dim=attention_head_dim, norm_num_groups=norm_num_groups, norm_eps=norm_eps,
             resnet_time_scale_shift=resnet_time_scale_shift, add_attention=add_attention,
             class_embed_type=class_embed_type, num_class_embeds=num_class_embeds)
-        self.max_chunk = int(os.environ.get("BD_MAX_CHUNK", max_chunk))     # inference chunk (samples are independent); BD_MAX_CHUNK = A/B knob
+        # inference chunk (samples are independent).  `max_chunk` is the upper bound; the chunk actually used is the largest
+        # one whose workspace fits the device memory that is free at the time (effective_chunk), halved again if the allocation
+        # fails -- B = 2048 wants 62 GiB on the CIFAR topology.  BD_MAX_CHUNK = A/B knob.
+        self.max_chunk = int(os.environ.get("BD_MAX_CHUNK", max_chunk))
 
         lib = L.load()
         c = L.UnetConfig()
@@ -274,6 +278,31 @@ class UNet2DModel(nn.Module):
     def workspace_bytes(self, B, training):
         return self._lib.bd_unet_workspace_bytes(self._plan, int(B), int(bool(training)))
 
+    def effective_chunk(self, B):
+        """Largest inference chunk <= min(B, max_chunk) whose workspace fits in 85 % of the currently free device memory (a
+        pooled workspace of that size counts as free: it is reused).  Halves until it fits; never below 1."""
+        chunk = max(1, min(int(B), self.max_chunk))
+        dev = self.flat.device
+        if dev.type != "cuda":
+            return chunk
+        free, _ = torch.cuda.mem_get_info(dev)
+        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # the caching allocator's idle blocks
+        while chunk > 1:
+            if self._ws_pool.get((chunk, False, str(dev))) or self.workspace_bytes(chunk, False) <= 0.85 * free:
+                break
+            chunk = (chunk + 1) // 2
+        return chunk
+
+    @contextmanager
+    def static_weights(self):
+        """Inside this block the parameters are promised constant: inference forwards skip the per-forward weight preprocessing
+        after the first one (bd_unet_set_static_weights; the sampling loops of pipelines.py run 50-1000 evaluations)."""
+        L.check(self._lib.bd_unet_set_static_weights(self._plan, 1), "bd_unet_set_static_weights")
+        try:
+            yield self
+        finally:
+            L.check(self._lib.bd_unet_set_static_weights(self._plan, 0), "bd_unet_set_static_weights")
+
     def _acquire_ws(self, B, training):
         key = (B, bool(training), str(self.flat.device))
         pool = self._ws_pool.setdefault(key, [])
@@ -361,19 +390,32 @@ class UNet2DModel(nn.Module):
                 raise NotImplementedError("gradient w.r.t. the UNet input is not provided (the reference never needs it)")
             out = _UNetFn.apply(self.flat, x_nhwc, t, self)
         else:
-            if B > self.max_chunk:   # samples are independent: chunking is exact and bounds the workspace
-                outs = []
-                for s in range(0, B, self.max_chunk):
-                    tt = t if t.numel() == 1 else t[s: s + self.max_chunk]
-                    o, _ = self._run_forward(self.flat.detach(), x_nhwc[s: s + self.max_chunk], tt, False)
-                    outs.append(o)
-                out = torch.cat(outs, 0)
-            else:
-                out, _ = self._run_forward(self.flat.detach(), x_nhwc, t, False)
+            out = self._forward_chunked(x_nhwc, t, self.effective_chunk(B))
         sample_out = out.permute(0, 3, 1, 2)     # logical NCHW view of the NHWC buffer (channels_last strides)
         if not return_dict:
             return (sample_out,)
         return UNet2DOutput(sample=sample_out)
+
+    def _forward_chunked(self, x_nhwc, t, chunk):
+        """Inference over `chunk`-sample pieces (samples are independent: chunking is exact and bounds the workspace).  A failed
+        workspace allocation halves the chunk and starts over instead of failing the call."""
+        B = x_nhwc.shape[0]
+        while True:
+            try:
+                if B <= chunk:
+                    return self._run_forward(self.flat.detach(), x_nhwc, t, False)[0]
+                outs = []
+                for s in range(0, B, chunk):
+                    tt = t if t.numel() == 1 else t[s: s + chunk]
+                    outs.append(self._run_forward(self.flat.detach(), x_nhwc[s: s + chunk], tt, False)[0])
+                return torch.cat(outs, 0)
+            except torch.cuda.OutOfMemoryError:
+                if chunk <= 1:
+                    raise
+                self._ws_pool = {k: v for k, v in self._ws_pool.items() if k[1]}     # drop pooled inference workspaces
+                torch.cuda.empty_cache()
+                chunk = (min(chunk, B) + 1) // 2
+                self.max_chunk = min(self.max_chunk, chunk)
 
     # ------------------------------------------------------------------ diffusers-layout I/O (SURVEY f-2)
     def config_dict(self):

@@ -9,8 +9,11 @@ poison_rate 0.1, BOX_14 trigger, fp32, synthetic data.  One "step" = poison-blen
         bench.py --gpus N --steps K --warmup W
 
 Prints ONE JSON line on rank 0.  Inputs (uint8 images, noise, timesteps) are resident in HBM before the timed
-region.  `roofline` is measured live with hipEvent pairs around every igemm launch (bd_prof_*), `cpu_baseline`
-is the CPU oracle (pure PyTorch fp32 restatement of the reference path) timed on this box's host cores.
+region, which carries no instrumentation.  `roofline` is measured live with hipEvent pairs around every GEMM-class
+launch (bd_prof_*) of extra untimed steps behind it, `cpu_baseline` is the CPU oracle (pure PyTorch fp32 restatement
+of the reference path) timed on this box's host cores.  The line also carries `sampling` (DDIM-50 x 2048, DDPM-1000 x
+256), `celeba` (the 256x256 DDPM-CELEBA-HQ-256 step at B = 4) -- each with its own `roofline` and `cpu_baseline` --
+`sustained`, and `dp_path_at_world_1` (trainer.py's data-parallel branch under RCCL on a 1-rank group).
 """
 import argparse
 import ctypes
@@ -38,25 +41,35 @@ _PMC_OPERANDS = {"conv_fwd": ("ConvKC", ("WgtKC", "WgtKCs")), "conv_dgrad": ("TC
 # kernel classes of the LDS-DMA family (conv_ps.hip) -> kernel-name patterns whose HBM traffic makes up one call
 _PMC_PS = {"conv_ps_wgrad": (r"conv_ps_wgrad3?_kernel", r"conv_ps_wgrad_reduce"), "conv_ps_fwd": (r"conv_ps3?_kernel<[12]>",),
            "conv_ps_dgrad": (r"conv_ps3?_kernel<0>",), "conv_ps128_fwd": (r"conv_ps128_kernel<", r"conv_ps128_reduce"),
-           "conv_ps128_dgrad": (r"conv_ps128_kernel<", r"conv_ps128_reduce")}
-PMC_FILE = "profiles/r03_pmc_bench_{mode}.json"       # falls back to the round-2 file when this round's is absent
+           "conv_ps128_dgrad": (r"conv_ps128_kernel<", r"conv_ps128_reduce"),
+           "conv_ph_ups_fwd": (r"conv_ph_kernel",), "conv_ph_ups_dgrad": (r"conv_ph_kernel",), "conv_ph_s2_dgrad": (r"conv_ph_kernel",),
+           "conv_ph_ups_wgrad": (r"conv_ps_wgrad_kernel<2, 8, true>", r"conv_ps_wgrad_reduce"),
+           "attn_sp_fwd": (r"attn_sp_fwd_kernel",), "attn_sp_bwd_a": (r"attn_sp_bwd_a_kernel",), "attn_sp_bwd_b": (r"attn_sp_bwd_b_kernel",),
+           "gemm_sp_nt": (r"gemm_sp_kernel<false, false>",), "gemm_sp_nn": (r"gemm_sp_kernel<false, true>",),
+           "gemm_sp_tn": (r"gemm_sp_kernel<true, true>", r"gemm_sp_reduce")}
+PMC_ROUNDS = ("r04", "r03", "r02")                     # this round's file first; an older one is used only when it is absent, and flagged
+PMC_FILE = "profiles/{rnd}_pmc_bench_{wl}{mode}.json"   # wl = "" (CIFAR train step), "celeba_" (256x256 train step), "ddim50_" (sampling)
 
 
-def _pmc_traffic(cls, launches_per_step=None):
+def _pmc_traffic(cls, workload=""):
     """HBM-side bytes per call of kernel class `cls` from the committed rocprofv3 PMC passes of this same command
     (scripts/pmc_bench.sh -> profiles/r02_pmc_bench_<mode>.json; FETCH_SIZE x2 per MI355X_MICROARCH.md's gfx950
     correction for 16 B/lane reads, + WRITE_SIZE; KB -> bytes; launch-weighted over the kernel instantiations of the
     class, split-K second passes included).  Returns (bytes, source) -- (None, reason) when that file or kernel is
     absent: counters cannot be collected from inside the timed process, so this is read from a committed file."""
     import re
-    mode = "bf16x3" if ("bf16x3" in cls or cls.startswith("conv_ps")) else "f32"
-    rel = PMC_FILE.format(mode=mode)
-    path = os.path.join(ROOT, rel)
-    if not os.path.exists(path):
-        rel = rel.replace("r03_", "r02_")
+    mode = "bf16x3" if ("bf16x3" in cls or cls.startswith("conv_ps") or cls.startswith("conv_ph") or "_sp_" in cls) else "f32"
+    wl = workload + "_" if workload else ""
+    rel = path = None
+    for rnd in PMC_ROUNDS:
+        rel = PMC_FILE.format(rnd=rnd, wl=wl, mode=mode)
         path = os.path.join(ROOT, rel)
-    if not os.path.exists(path):
-        return None, f"{rel} not found"
+        if os.path.exists(path):
+            break
+    else:
+        return None, f"{PMC_FILE.format(rnd=PMC_ROUNDS[0], wl=wl, mode=mode)} not found"
+    if not rel.startswith(f"profiles/{PMC_ROUNDS[0]}_"):
+        rel += f" (FALLBACK: this round's {PMC_ROUNDS[0]} file is absent)"
     kernels = json.load(open(path))["kernels"]
     by = lambda v: (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
     if cls in _PMC_PS:
@@ -125,12 +138,14 @@ def _cpu_baseline_worker(kind="train"):
     steps (UNet forward + scheduler step, batch 16) -- and print one JSON line per step."""
     from oracle import sched_ref, train_ref
     from oracle import unet_ref as U
-    cfg = U.CIFAR10_32
+    celeba = kind == "celeba"       # the 256x256 DDPM-CELEBA-HQ-256 network (113.7 M parameters), batch 1: one step is ~10-30 s of CPU
+    cfg = U.CELEBA_HQ_256 if celeba else U.CIFAR10_32
     cores = _host_cores()
     torch.set_num_threads(cores)
     P = U.gen_params(cfg, 0)
     _, a, ac = sched_ref.make_tables()
-    B = 16
+    B = 1 if celeba else 16
+    S = 256 if celeba else 32
     if kind == "sample":      # BASELINE.md section 4: 10 DDPM sampling steps at batch 16, extrapolated to 1000 / 50
         x = torch.randn(B, 3, 32, 32, generator=torch.Generator().manual_seed(0))
         gz = torch.Generator().manual_seed(1)
@@ -143,9 +158,9 @@ def _cpu_baseline_worker(kind="train"):
                 print(json.dumps({"step": step, "s": time.time() - t0, "cores": torch.get_num_threads(), "B": B}), flush=True)
         return
     g = torch.Generator().manual_seed(0)
-    x0 = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    x0 = torch.rand(B, 3, S, S, generator=g) * 2 - 1
     R = torch.zeros_like(x0)
-    eps = torch.randn(B, 3, 32, 32, generator=g)
+    eps = torch.randn(B, 3, S, S, generator=g)
     t = torch.randint(0, 1000, (B,), generator=g)
     state = {}
     for step in range(64):
@@ -182,11 +197,15 @@ def cpu_baseline(seconds_budget=40.0, kind="train"):
     p.kill()
     if not recs:
         return {"value": None, "unit": "images/s", "cores": None, "cpu_model": _cpu_model(), "kind": "port",
-                "sample": f"no oracle {kind} step (batch 16) finished within {seconds_budget:.0f} s on this host"}
+                "sample": f"no oracle {kind} step finished within {seconds_budget:.0f} s on this host"}
     timed = [r["s"] for r in recs[2:]] or [r["s"] for r in recs[-1:]]
     timed.sort()
     med = timed[len(timed) // 2]
     B = recs[0]["B"]
+    if kind == "celeba":
+        return {"value": B / med, "unit": "images/s", "cores": recs[0]["cores"], "cpu_model": _cpu_model(), "kind": "port",
+                "sample": f"{len(timed)} timed train step(s) ({len(recs) - len(timed)} warm-up) of the 256x256 DDPM-CELEBA-HQ-256 UNet, batch {B}, "
+                          f"poison_rate 0.0, fp32, oracle/train_ref.py on the host CPU (median {med:.2f} s/step, budget {seconds_budget:.0f} s)"}
     if kind == "sample":
         return {"seconds_per_step": med, "batch": B, "cores": recs[0]["cores"], "cpu_model": _cpu_model(), "kind": "port",
                 "timed_steps": len(timed)}
@@ -251,8 +270,11 @@ def run_sampling(model, kind, n, mode, world, rank, dev, lib, want_roofline=True
             d = cl[0]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             peak = FP32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 3
+            traffic, tsrc = _pmc_traffic(d["kernel"], "ddim50")     # same kernels, same chunk shapes in both sampling loops
             res["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
-                               "frac": ach / peak, "traffic": None, "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+                               "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
+                               "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+                               "avg_launch_us": d["ms"] * 1e3 / d["launches"],
                                "share_of_gemm_class_time": d["ms"] / sum(c["ms"] for c in cl),
                                "note": "hipEvent pairs on the launch stream, 3 untimed UNet evaluations of one chunk; the two half-batch "
                                        "forward pipelines share the chip, so this is an in-schedule figure"}
@@ -336,10 +358,75 @@ def setup_train(celeba, B, mode, dev, rank, use_graph=False):
     noise = torch.randn(NPOOL, B, 3, S_IMG, S_IMG, generator=g).to(dev)
     ts = torch.randint(0, 1000, (NPOOL, B), generator=g).to(dev)
 
-    def step(i):
+    def inputs(i):
         s0 = (i * B) % (NIMG - B + 1)
-        return eng.train_step(images[s0:s0 + B], flags[s0:s0 + B], trigger, target, noise[i % NPOOL], ts[i % NPOOL])
+        return images[s0:s0 + B], flags[s0:s0 + B], trigger, target, noise[i % NPOOL], ts[i % NPOOL]
+
+    def step(i):
+        return eng.train_step(*inputs(i))
+    step.inputs = inputs
     return model, eng, step, {"trigger": trigger_name, "target": target_name, "target_source": src, "S": S_IMG}
+
+
+def profile_steps(lib, model, step, first, n, barrier):
+    """(classes in the product's two-stream schedule, classes with the side stream off, n): per-launch hipEvent pairs on the
+    launch stream over `n` extra untimed steps each.  In the two-stream schedule the weight-gradient GEMMs share the chip with
+    the dgrad / GroupNorm chain, so their durations there include that sharing; every rank runs these steps (DP collectives
+    must stay matched)."""
+    lib.bd_prof_reset(); lib.bd_prof_enable(1)
+    for i in range(n):
+        step(first + i)
+    lib.bd_prof_enable(0)
+    barrier()
+    classes = _read_classes(lib)
+    lib.bd_unet_set_aux_stream(model._plan, 0)
+    lib.bd_prof_reset(); lib.bd_prof_enable(1)
+    for i in range(2):
+        step(first + n + i)
+    lib.bd_prof_enable(0)
+    barrier()
+    classes_iso = _read_classes(lib)
+    lib.bd_unet_set_aux_stream(model._plan, 1)
+    lib.bd_prof_reset()
+    return classes, classes_iso, n
+
+
+def roofline_object(classes, classes_iso, prof_steps, mode, ms, probe, workload=""):
+    """`roofline` of the dominant kernel class (most time in the profiled steps) + the per-class tables."""
+    if not classes:
+        return None, [], []
+    d = classes[0]
+    ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
+    # split-bf16 issues 3 bf16 MFMA products per algorithmic multiply: its ceiling for ALGORITHMIC flops is
+    # the dense bf16 peak / 3 (833 TF), above the exact-fp32 MFMA peak (157 TF) the f32 mode is bound by
+    peak = FP32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 3
+    traffic, traffic_source = _pmc_traffic(d["kernel"], workload)
+    plim = probe["random_operands_tflops"] if probe else None
+    r = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": peak,
+         "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
+         "mfma_flops_per_algorithmic_flop": 1 if mode == "f32" else 3,
+         "mfma_dense_peak": FP32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS,
+         "mfma_power_limited_peak_measured": plim,
+         "mfma_power_limited_peak_source": probe["source"] if probe else None,
+         "mfma_constant_operand_peak_measured": probe["constant_operands_tflops"] if probe else None,
+         "frac_of_power_limited_peak": ach / (plim / 3) if plim else None,
+         "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
+         "launches_per_step": d["launches"] / prof_steps, "sampled_steps": prof_steps,
+         "sampled_steps_note": "extra untimed steps behind the timed region (same two-stream schedule); the timed steps carry no events",
+         "avg_launch_us": d["ms"] * 1e3 / d["launches"],
+         "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+         "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
+         "alg_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
+         "share_of_step": d["ms"] / prof_steps / ms,
+         "gflop_per_step_all_classes": sum(c["flops"] for c in classes) / prof_steps / 1e9}
+    iso = next((c for c in classes_iso if c["kernel"] == d["kernel"]), None)
+    if iso:   # the same kernel class with the side stream off (stand-alone launch durations, untimed steps)
+        ai = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
+        r["standalone"] = {"achieved": ai, "frac": ai / peak, "avg_launch_us": iso["ms"] * 1e3 / iso["launches"],
+                           "frac_of_power_limited_peak": ai / (plim / 3) if plim else None,
+                           "note": "2 extra untimed steps with bd_unet_set_aux_stream(0): no overlap with other kernels"}
+    rnd = lambda cl: [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in cl]
+    return r, rnd(classes), rnd(classes_iso)
 
 
 def timed_steps(step, first, n, barrier, dev, world, prof=None):
@@ -383,6 +470,8 @@ def main():
     ap.add_argument("--sampling-n", default="2048,256", help="samples per GPU of the DDIM-50 and DDPM-1000 loops (BASELINE configs[4]'s "
                                                              "eval_max_batch 2048; the reference's default eval batch 256)")
     ap.add_argument("--no-celeba", action="store_true", help="skip the 256x256 batch-4 train step of the default line")
+    ap.add_argument("--no-dp-probe", action="store_true", help="skip the N = 1 measurement of the data-parallel communication path "
+                                                               "(TrainEngine(force_dp=True): RCCL on a 1-rank group)")
     ap.add_argument("--sustain", type=float, default=10.0, help="seconds of back-to-back train steps after the timed region "
                                                                 "(a sustained figure on a power-limited part); 0 = skip")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("BD_TRAIN_GRAPH", "0")),
@@ -441,36 +530,14 @@ def main():
         if i == 0:
             torch.cuda.synchronize(); log(f"first step done, loss {float(loss):.5f}")
     log("warmup done")
-    # roofline: hipEvent pairs around every GEMM-class launch of every PROF_EVERY-th timed step (the pairs cost ~5 % of
-    # a step when recorded on all of them, so the timed region samples)
-    PROF_EVERY = 10
-    prof_state = {"n": 0}
-    if not args.no_prof:
-        lib.bd_prof_reset()
-
-    def prof(i, begin):
-        if args.no_prof or not (i % PROF_EVERY == PROF_EVERY - 1 or args.steps < PROF_EVERY):
-            return
-        lib.bd_prof_enable(1 if begin else 0)
-        prof_state["n"] += 1 if begin else 0
-    dt, loss, per_step = timed_steps(step, args.warmup, args.steps, barrier, dev, world, prof)
-    prof_steps = prof_state["n"]
+    # The timed region carries NO instrumentation (round 3 bracketed 2 of the 20 timed steps with hipEvent pairs, ~5 % each).
+    dt, loss, per_step = timed_steps(step, args.warmup, args.steps, barrier, dev, world)
     final_loss = float(loss)
     log(f"timed region done: {dt / args.steps * 1e3:.2f} ms/step")
-    classes, classes_iso = [], []
-    if not args.no_prof:
-        classes = _read_classes(lib)
-        # In the timed region the weight-gradient GEMMs share the chip with the dgrad / GroupNorm chain (side stream), so
-        # their per-launch durations there include that sharing.  Two extra UNTIMED steps with the side stream off give
-        # the kernels' stand-alone durations (every rank runs them: the DP collectives must stay matched).
-        lib.bd_unet_set_aux_stream(model._plan, 0)
-        lib.bd_prof_reset(); lib.bd_prof_enable(1)
-        for i in range(2):
-            step(args.warmup + args.steps + i)
-        lib.bd_prof_enable(0)
-        barrier()
-        classes_iso = _read_classes(lib)
-        lib.bd_unet_set_aux_stream(model._plan, 1)
+    # roofline: hipEvent pairs around every GEMM-class launch (bd_prof_*) of PROF_STEPS extra, UNTIMED steps of the same
+    # two-stream schedule, then of two more with the side stream off (stand-alone launch durations)
+    PROF_STEPS = 3
+    classes, classes_iso, prof_steps = profile_steps(lib, model, step, args.warmup + args.steps, PROF_STEPS, barrier) if not args.no_prof else ([], [], 0)
 
     sustained = None
     if args.sustain > 0:
@@ -481,6 +548,30 @@ def main():
         sustained = {"seconds": sdt, "steps": n_sus, "ms_per_step": sdt / n_sus * 1e3, "value": world * B * n_sus / sdt,
                      "ms_per_step_median": sper[len(sper) // 2], "ms_per_step_p90": sper[int(len(sper) * 0.9)]}
         log(f"sustained: {n_sus} steps in {sdt:.1f} s = {sdt / n_sus * 1e3:.2f} ms/step")
+
+    dp_probe = None
+    if world == 1 and not celeba and not args.no_dp_probe:
+        # the data-parallel communication path at N = 1 (task 3): a second engine over the same model with
+        # force_dp -- comm stream, side-stream event wait, one async RCCL all_reduce per finished gradient range on a 1-rank group
+        try:
+            from baddiffusion_amd.trainer import TrainEngine
+            from baddiffusion_amd.schedulers import DDPMScheduler
+            eng2 = TrainEngine(model, DDPMScheduler(num_train_timesteps=1000), lr=2e-4, lr_warmup_steps=500, num_training_steps=469 * 50,
+                               force_dp=True)
+            def step2(i, _e=eng2):
+                return _e.train_step(*step.inputs(i))
+            for i in range(3):
+                step2(i)
+            ddt, _, dper = timed_steps(step2, 3, 10, barrier, dev, world)
+            pdt, _, _ = timed_steps(step, 3, 10, barrier, dev, world)      # the ordinary step again, back to back on the same clocks
+            dp_probe = {"ms_per_step": ddt / 10 * 1e3, "ms_per_step_plain_back_to_back": pdt / 10 * 1e3,
+                        "overhead_ms": (ddt - pdt) / 10 * 1e3, "backend": dist.get_backend(), "world": dist.get_world_size(),
+                        "collectives_per_step": sum(len(rs) for rs in eng2._seg_ranges), "bytes_per_step": int(eng2.collective_bytes),
+                        "note": "TrainEngine(force_dp=True): trainer.py's DP branch on one GPU; tests/test_hip_round4.py checks its stream ordering"}
+            log(f"dp path at world 1: {ddt / 10 * 1e3:.2f} ms/step (plain {pdt / 10 * 1e3:.2f})")
+            del eng2
+        except Exception as e:      # a box without a working RCCL init must not lose the headline line
+            dp_probe = {"error": f"{type(e).__name__}: {e}"}
 
     probe = None
     if args.mode != "f32":
@@ -520,6 +611,10 @@ def main():
                 "step_frac_of_hbm_roofline": (16688e6 * 4 + 6.65e9) / 8e12 / (cdt / 10),
                 "workload": f"BASELINE configs[3] topology: {cnames['trigger']} trigger, {cnames['target']} target, clip 1.0 + Adam"}
         log(f"celeba256 B=4: {cdt / 10 * 1e3:.2f} ms/step")
+        if not args.no_prof:
+            ccl, ccl_iso, cn = profile_steps(lib, cmodel, cstep, 13, 2, barrier)
+            side["roofline"], side["kernel_classes"], side["kernel_classes_standalone"] = \
+                roofline_object(ccl, ccl_iso, cn, args.mode, cdt / 10 * 1e3, probe, "celeba")
         del cmodel, ceng, cstep
         torch.cuda.empty_cache()
 
@@ -560,41 +655,17 @@ def main():
                                        "gradient, issued while the next backward segment computes"}}
         if sustained:
             out["sustained"] = sustained
-        if not args.no_prof:
-            if classes:
-                d = classes[0]
-                ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
-                # split-bf16 issues 3 bf16 MFMA products per algorithmic multiply: its ceiling for ALGORITHMIC flops is
-                # the dense bf16 peak / 3 (833 TF), above the exact-fp32 MFMA peak (157 TF) the f32 mode is bound by
-                peak = FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 3
-                traffic, traffic_source = (None, "not collected for this workload") if celeba else _pmc_traffic(d["kernel"])
-                plim = probe["random_operands_tflops"] if probe else None
-                out["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": peak,
-                                   "unit": "TFLOP/s", "frac": ach / peak, "traffic": traffic, "traffic_source": traffic_source,
-                                   "mfma_flops_per_algorithmic_flop": 1 if args.mode == "f32" else 3,
-                                   "mfma_dense_peak": FP32_MFMA_PEAK_TFLOPS if args.mode == "f32" else BF16_MFMA_PEAK_TFLOPS,
-                                   "mfma_power_limited_peak_measured": plim,
-                                   "mfma_power_limited_peak_source": probe["source"] if probe else None,
-                                   "mfma_constant_operand_peak_measured": probe["constant_operands_tflops"] if probe else None,
-                                   "frac_of_power_limited_peak": ach / (plim / 3) if plim else None,
-                                   "frac_of_fp32_mfma_peak": ach / FP32_MFMA_PEAK_TFLOPS,
-                                   "launches_per_step": d["launches"] / prof_steps, "sampled_steps": prof_steps,
-                                   "avg_launch_us": d["ms"] * 1e3 / d["launches"],
-                                   "gflop_per_launch": d["flops"] / d["launches"] / 1e9,
-                                   "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-                                   "alg_gbs": d["bytes"] / (d["ms"] * 1e-3) / 1e9,
-                                   "share_of_step": d["ms"] / prof_steps / ms}
-                iso = next((c for c in classes_iso if c["kernel"] == d["kernel"]), None)
-                if iso:   # the same kernel class with the side stream off (stand-alone launch durations, untimed steps)
-                    ai = iso["flops"] / (iso["ms"] * 1e-3) / 1e12
-                    out["roofline"]["standalone"] = {"achieved": ai, "frac": ai / peak, "avg_launch_us": iso["ms"] * 1e3 / iso["launches"],
-                                                     "frac_of_power_limited_peak": ai / (plim / 3) if plim else None,
-                                                     "note": "2 extra untimed steps with bd_unet_set_aux_stream(0): no overlap with other kernels"}
-                out["kernel_classes_standalone"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in classes_iso]
-                out["kernel_classes"] = [{k: (round(v, 3) if isinstance(v, float) else v) for k, v in c.items()} for c in classes]
+        if not args.no_prof and classes:
+            out["roofline"], out["kernel_classes"], out["kernel_classes_standalone"] = \
+                roofline_object(classes, classes_iso, prof_steps, args.mode, ms, probe, "celeba" if celeba else "")
+        if dp_probe:
+            out["dp_path_at_world_1"] = dp_probe
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores) ...")
-            out["cpu_baseline"] = cpu_baseline()
+            out["cpu_baseline"] = cpu_baseline(kind="celeba") if celeba else cpu_baseline()
+            if side:
+                log("cpu baseline of the 256x256 step ...")
+                side["cpu_baseline"] = cpu_baseline(seconds_budget=60.0, kind="celeba")
             if sampling:
                 sb = sampling_cpu_baseline()
                 for k in sampling:
@@ -604,7 +675,7 @@ def main():
         if side:
             out["celeba"] = side
         print(json.dumps(out))
-    if world > 1:
+    if dist.is_available() and dist.is_initialized():      # world > 1, or the 1-rank group of the DP probe
         dist.destroy_process_group()
 
 

@@ -1,13 +1,19 @@
 #!/bin/bash
 # HBM traffic of every kernel of the bench step from PMC counters, one counter per pass (guide: FETCH_SIZE and
-# WRITE_SIZE do not fit one pass; kernel-trace only).  usage: pmc_bench.sh <mode> -> gpurun_out/pmc_bench_<mode>.json
+# WRITE_SIZE do not fit one pass; kernel-trace only).  usage: pmc_bench.sh <mode> [cifar|celeba|ddim50] -> gpurun_out/pmc_bench_[<workload>_]<mode>.json
 mode=${1:-bf16x3}
+wl=${2:-cifar}
+case $wl in
+  cifar)  WLARGS="--steps 3 --warmup 1 --no-sampling --no-celeba --no-dp-probe --sustain 0"; tag="" ;;
+  celeba) WLARGS="--workload celeba --steps 3 --warmup 1 --sustain 0"; tag="celeba_" ;;
+  ddim50) WLARGS="--workload ddim50 --batch 512"; tag="ddim50_" ;;
+esac
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
   rm -rf /tmp/pb_$c
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pb_$c -o p -- python $GRAFT_REPO_ROOT/bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-prof --no-sampling --no-celeba --sustain 0 --mode $mode > /tmp/pb_$c.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d /tmp/pb_$c -o p -- python $GRAFT_REPO_ROOT/bench.py $WLARGS --no-cpu-baseline --no-prof --mode $mode > /tmp/pb_$c.log 2>&1
 done
-python3 - $mode <<'PY'
+python3 - $tag$mode <<'PY'
 import csv, sys, glob, json, collections, os
 out = collections.defaultdict(dict)
 for c in ("FETCH_SIZE", "WRITE_SIZE"):

@@ -43,7 +43,7 @@ def test_struct_layouts_match_header_sizes():
              "bd_ddim_step_desc": L.DdimStepDesc, "bd_gn_fwd_desc": L.GnFwdDesc, "bd_gn_bwd_desc": L.GnBwdDesc, "bd_gn_param_item": L.GnParamItem,
              "bd_operand": L.Operand, "bd_igemm_desc": L.IgemmDesc, "bd_conv3x3_fwd_desc": L.ConvFwdDesc,
              "bd_conv3x3_dgrad_desc": L.ConvDgradDesc, "bd_conv3x3_wgrad_desc": L.ConvWgradDesc, "bd_unet_config": L.UnetConfig,
-             "bd_conv3x3_ps_desc": L.ConvPsDesc, "bd_conv3x3_ps_wgrad_desc": L.ConvPsWgradDesc, "bd_attn_fwd_desc": L.AttnFwdDesc,
+             "bd_conv3x3_ps_desc": L.ConvPsDesc, "bd_conv3x3_ps_wgrad_desc": L.ConvPsWgradDesc,
              "bd_upsample_conv_desc": L.UpsampleConvDesc, "bd_conv3x3_s2_dgrad_desc": L.ConvS2DgradDesc}
     prog = '#include <stdio.h>\n#include "bd_hip.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
@@ -83,7 +83,7 @@ def test_round2_entry_points_reject_bad_arguments_without_gpu():
     assert lib.bd_gn_bwd_params(None, 0, 4, None) < 0 and b"bd_gn_bwd_params" in lib.bd_last_error()
     assert lib.bd_gn_bwd_defers(128, 1024, 128, 32) == 1 and lib.bd_gn_bwd_defers(4, 65536, 128, 32) == 0
     assert lib.bd_gn_bwd_defers(4, 64, 130, 32) == 0                      # C not divisible by G
-    assert lib.bd_conv3x3_ps(None, None) < 0 and lib.bd_conv3x3_ps_wgrad(None, None) < 0 and lib.bd_attn_fwd(None, None) < 0
+    assert lib.bd_conv3x3_ps(None, None) < 0 and lib.bd_conv3x3_ps_wgrad(None, None) < 0
     # round 3: phase-decomposed convolutions, deferred join, probe
     assert lib.bd_upsample_conv_fwd(None, None) < 0 and lib.bd_upsample_conv_dgrad(None, None) < 0 and lib.bd_upsample_conv_wgrad(None, None) < 0
     assert lib.bd_conv3x3_s2_dgrad_ps(None, None) < 0 and b"bd_conv3x3_s2_dgrad_ps" in lib.bd_last_error()
@@ -91,4 +91,5 @@ def test_round2_entry_points_reject_bad_arguments_without_gpu():
     d = L.UpsampleConvDesc(B=2, H=8, W=8, Cin=128, Cout=256)
     assert lib.bd_upsample_conv_wgrad_workspace_bytes(ctypes.byref(d)) >= 4 * 256 * 16 * 128       # at least dE itself
     assert lib.bd_unet_set_deferred_join(None, 1) < 0 and lib.bd_unet_stream_wait_aux(None, None) < 0
+    assert lib.bd_unet_set_static_weights(None, 1) < 0
     assert lib.bd_mfma_probe(1, 0, 1, None, None) < 0

@@ -265,10 +265,10 @@ def test_resume_rng_state_is_per_rank(tmp_path):
     config.seed = 3
     config.ckpt_path = str(tmp_path / "ckpt"); config.data_ckpt_path = str(tmp_path / "data.ckpt")
     torch.manual_seed(100)                                        # "rank 0"
-    torch.save({"epoch": 1, "step": 7, "cpu_rng": torch.get_rng_state(), "cuda_rng": None}, config.data_ckpt_path)
+    torch.save({"epoch": 1, "step": 7, "world": 1, "cpu_rng": torch.get_rng_state(), "cuda_rng": None}, config.data_ckpt_path)
     next0 = torch.randn(4)
     torch.manual_seed(101)                                        # "rank 1"
-    cli.save_rank_rng(config, 1)
+    cli.save_rank_rng(config, 1, cli.capture_rank_rng(1, 7))
     next1 = torch.randn(4)
     assert os.path.exists(config.data_ckpt_path + ".rank1") and not torch.equal(next0, next1)
     torch.manual_seed(999)
@@ -278,3 +278,14 @@ def test_resume_rng_state_is_per_rank(tmp_path):
     assert cli.restore_training_state(config, None, rank=2) == (1, 7)     # no file: seed + rank
     want = torch.randn(4, generator=torch.Generator().manual_seed(config.seed + 2))
     assert torch.equal(torch.randn(4), want)
+    # a rank file that belongs to ANOTHER checkpoint (rank 0 crashed before writing data.ckpt, ranks failed at
+    # different steps, a stale file of an earlier run) must not be installed silently
+    torch.manual_seed(555)
+    cli.save_rank_rng(config, 1, cli.capture_rank_rng(2, 14))              # one checkpoint ahead of data.ckpt (1, 7)
+    assert cli.restore_training_state(config, None, rank=1) == (1, 7)
+    want = torch.randn(4, generator=torch.Generator().manual_seed(config.seed + 1))
+    assert torch.equal(torch.randn(4), want)
+    st = cli.capture_rank_rng(1, 7); st["world"] = 4                       # same step, but written by a 4-rank run
+    cli.save_rank_rng(config, 1, st)
+    assert cli.restore_training_state(config, None, rank=1) == (1, 7)
+    assert torch.equal(torch.randn(4), torch.randn(4, generator=torch.Generator().manual_seed(config.seed + 1)))
