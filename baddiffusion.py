@@ -270,9 +270,28 @@ def sampling(config, file_name, pipeline, dsl):
         gen(noise + dsl.trigger.unsqueeze(0), "backdoor_samples")       # raw trigger incl. its -1 background (:417)
 
 
-FID_UNAVAILABLE = ("pytorch_fid's InceptionV3 pool3 weights (pt_inception-2015-12-05) are a third-party asset that is not in the "
-                   "reference repository and cannot be fetched here; activation statistics + Frechet distance are "
-                   "baddiffusion_amd.metrics.fid_from_features(features_a, features_b) once a feature extractor is supplied")
+FID_UNAVAILABLE = ("pytorch_fid's InceptionV3 pool3 weights (pt_inception-2015-12-05-6726825d.pth) are a third-party asset that is not in "
+                   "the reference repository and cannot be fetched here; point BD_FID_WEIGHTS at that file and measure() computes FID with "
+                   "baddiffusion_amd.inception.FIDInceptionV3 (HIP kernels) + metrics.fid_from_features")
+
+
+def _png_dir_u8(path, channel):
+    """every PNG of `path` (numeric file names, in order) as one uint8 [N, H, W, 3] array: what fid_score.py:84-89 feeds the
+    Inception network (PIL -> RGB; a grey image is replicated over the three channels)"""
+    from PIL import Image
+    files = sorted(os.listdir(path), key=lambda n: int(os.path.splitext(n)[0]))
+    return np.stack([np.asarray(Image.open(os.path.join(path, f)).convert("RGB"), dtype=np.uint8) for f in files])
+
+
+def fid_of_dirs(net, real_u8, gen_u8, batch=500):
+    """fid_score.py:233-259 on device-resident uint8 image sets: pool3 features batch by batch -> fp64 statistics on the device
+    -> Frechet distance."""
+    from baddiffusion_amd import metrics
+
+    def feats(arr):
+        for s in range(0, arr.shape[0], batch):
+            yield net(arr[s:s + batch])
+    return metrics.fid_from_features(feats(real_u8), feats(gen_u8))
 
 
 def update_score_file(config, score_file, fid_sc, mse_sc, ssim_sc, fid_reason=None):
@@ -332,10 +351,25 @@ def measure(config, dsl, folder_name, pipeline, rank=0, world=1):
     gen_d, tgt_d = gen.to(dev), tgt.to(dev)
     mse_sc = metrics.mse(gen_d, tgt_d)
     ssim_sc = metrics.ssim(gen_d, tgt_d, data_range=1.0)     # torchmetrics defaults (parity unpinned: torchmetrics absent)
-    # FID needs pool3 features of pytorch_fid's InceptionV3 (weights do not travel); with a feature extractor the rest of
-    # the path is metrics.fid_from_features(...) -> ActivationStats on the device + Frechet distance (pinned by G8)
-    print(f"[{config.sample_ep}] FID: None (pytorch_fid Inception weights unavailable), MSE: {mse_sc}, SSIM: {ssim_sc}")
-    return update_score_file(config, "score.json", None, mse_sc, ssim_sc, fid_reason=FID_UNAVAILABLE)
+    # FID (baddiffusion.py:533: fid(path=[dataset_img_dir, clean_path])): pool3 features of pytorch_fid's InceptionV3 for the first
+    # measure_sample_n images of the seed-shuffled dataset and for the clean samples, on the device (baddiffusion_amd/inception.py),
+    # then fp64 statistics + the Frechet distance (pinned by G8).  The weights file is a third-party asset: without it FID is null
+    # and score.json says why.
+    fid_sc, fid_reason = None, FID_UNAVAILABLE
+    from baddiffusion_amd.inception import load_fid_weights
+    net = load_fid_weights(device=dev) if str(dev) != "cpu" else None
+    if net is not None:
+        n_real = min(config.measure_sample_n, len(dsl))
+        order = torch.randperm(len(dsl), generator=torch.Generator().manual_seed(config.seed))[:n_real]       # ds.shuffle(seed)[:n] (:488, 503)
+        real = dsl.device_images[dsl._rows()[order].to(dsl.device_images.device)]
+        if real.shape[-1] == 1:
+            real = real.expand(-1, -1, -1, 3).contiguous()
+        clean = torch.from_numpy(_png_dir_u8(clean_path, dsl.channel)).to(dev)
+        fid_sc = float(fid_of_dirs(net, real.to(dev), clean))
+        fid_reason = None
+    print(f"[{config.sample_ep}] FID: {fid_sc if fid_sc is not None else 'None (BD_FID_WEIGHTS not set: pytorch_fid Inception weights unavailable)'}, "
+          f"MSE: {mse_sc}, SSIM: {ssim_sc}")
+    return update_score_file(config, "score.json", fid_sc, mse_sc, ssim_sc, fid_reason=fid_reason)
 
 
 def checkpoint(config, engine, pipeline, cur_epoch, cur_step):

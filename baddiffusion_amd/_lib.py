@@ -134,6 +134,11 @@ class AttnSpDesc(C.Structure):
                 ("ldo", i64), ("pt_split", vp), ("do_split", vp), ("lddo", i64), ("dst_split", vp), ("dqkv_split", vp), ("lddqkv", i64)]
 
 
+class Conv2dDesc(C.Structure):
+    _fields_ = [("x", vp), ("ldx", i64), ("w", vp), ("bias", vp), ("y", vp), ("ldy", i64), ("B", i32), ("H", i32), ("W", i32), ("Cin", i32),
+                ("Cout", i32), ("KH", i32), ("KW", i32), ("stride_h", i32), ("stride_w", i32), ("pad_h", i32), ("pad_w", i32), ("relu", i32)]
+
+
 class UnetConfig(C.Structure):
     _fields_ = [("sample_size", i32), ("in_channels", i32), ("out_channels", i32), ("num_blocks", i32),
                 ("block_out_channels", i32 * 8), ("down_attn", i32 * 8), ("up_attn", i32 * 8),
@@ -161,6 +166,10 @@ SIGNATURES = {
     "bd_lincomb": (i32, [i32, C.POINTER(vp), C.POINTER(f32), i64, i32, f32, vp, vp]),
     "bd_ssim_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "bd_ssim": (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp, vp, sz, vp]),
+    "bd_conv2d_nhwc": (i32, [C.POINTER(Conv2dDesc), vp]),
+    "bd_pool2d_nhwc": (i32, [vp, i64, vp, i64, i32, i32, i32, i32, i32, i32, i32, i32, i32, vp]),
+    "bd_resize_bilinear_nhwc": (i32, [vp, i32, vp, i32, i32, i32, i32, i32, i32, f32, f32, vp]),
+    "bd_global_avgpool_nhwc": (i32, [vp, i64, vp, i32, i32, i32, vp]),
     "bd_gn_bwd_defers": (i32, [i32, i32, i32, i32]),
     "bd_gn_bwd_params": (i32, [C.POINTER(GnParamItem), i32, i32, vp]),
     "bd_igemm_workspace_bytes": (sz, [C.POINTER(IgemmDesc)]),

@@ -25,6 +25,7 @@ SOURCES = [  # (file, extra flags)
     ("gemm_sp.hip", []),
     ("attn_sp.hip", ["-DBD_AS_ABLATION"] if os.environ.get("BD_BUILD_ABLATION") == "1" else []),
     ("metrics.hip", ["-ffp-contract=off"]),
+    ("inception.hip", ["-ffp-contract=off"]),
     ("conv.cpp", ["-x", "hip"]),
     ("conv_thin.hip", ["-fno-slp-vectorize"]),   # SLP pairs the fp32 FMAs into v_pk_fma_f32 with splatted coefficients: 2x the registers, spills
     ("unet_plan.cpp", ["-x", "hip"]),

@@ -33,6 +33,7 @@ TRAIN_GFLOP_PER_IMG = 37.324          # SURVEY 8d (fwd+bwd, 2*MAC of conv/GEMM/B
 FP32_MFMA_PEAK_TFLOPS = 157.3         # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0        # dense bf16 MFMA (split-bf16 mode issues 3 MFMA flops per algorithmic flop)
 HBM_PEAK_GBS = 8000.0
+_JSON_OUT = sys.stdout
 
 
 _PMC_OPERANDS = {"conv_fwd": ("ConvKC", ("WgtKC", "WgtKCs")), "conv_dgrad": ("TConvKC", ("WgtRC", "WgtRCs")),
@@ -316,7 +317,7 @@ def bench_sampling(args, world, rank, dev):
         line.update({k: v for k, v in res.items() if k not in line})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = sampling_cpu_baseline()["ddpm1000" if args.workload == "ddpm1000" else "ddim50"]
-        print(json.dumps(line))
+        print(json.dumps(line), file=_JSON_OUT, flush=True)
     return 0
 
 
@@ -483,6 +484,13 @@ def main():
     args = ap.parse_args()
     if args.cpu_baseline_worker:
         return _cpu_baseline_worker(args.cpu_baseline_kind)
+
+    # ONE JSON line on stdout: native libraries print there too (RCCL: "Librccl path : ..."), so file descriptor 1 is pointed
+    # at stderr for the life of the process and the line goes to a private duplicate of the original stdout
+    global _JSON_OUT
+    sys.stdout.flush()
+    _JSON_OUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -674,7 +682,7 @@ def main():
             out["sampling"] = sampling
         if side:
             out["celeba"] = side
-        print(json.dumps(out))
+        print(json.dumps(out), file=_JSON_OUT, flush=True)
     if dist.is_available() and dist.is_initialized():      # world > 1, or the 1-rank group of the DP probe
         dist.destroy_process_group()
 

@@ -361,6 +361,33 @@ int bd_ssim(const float* preds, const float* target, int N, int C, int H, int W,
             int64_t stride_h, int64_t stride_w, float data_range, float* out, void* workspace, size_t workspace_bytes,
             bd_stream_t stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * FID feature extractor (measure path, SURVEY f-3): the layer kernels of pytorch_fid's InceptionV3 up to pool3
+ * (/root/reference/fid_score.py:53 `from pytorch_fid.inception import InceptionV3`, :91-148 get_activations, :255
+ * `InceptionV3([block_idx])`; pytorch-fid==0.2.1 per requirements.txt -- a third-party package absent from the reference tree,
+ * its published graph is restated in baddiffusion_amd/inception.py).  NHWC fp32, exact fp32 products (v_mfma_f32_32x32x2_f32).
+ * ------------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float* x; int64_t ldx;      /* input  [B, H, W, Cin], pixel stride ldx floats (a channel slice of a wider buffer is fine) */
+    const float* w;                   /* weights [KH][KW][Cin][Cout] (BatchNorm scale folded in by the caller)                     */
+    const float* bias;                /* optional [Cout] (folded BatchNorm shift)                                                  */
+    float* y; int64_t ldy;            /* output [B, Ho, Wo, Cout] at pixel stride ldy: Ho = (H + 2 pad_h - KH) / stride_h + 1, ...  */
+    int B, H, W, Cin, Cout, KH, KW, stride_h, stride_w, pad_h, pad_w;
+    int relu;                         /* y = max(y, 0)  (BasicConv2d = conv + bn + relu)                                           */
+} bd_conv2d_desc;
+/* Cout % 4 == 0; x 16-byte aligned with ldx % 4 == 0 when Cin % 4 == 0 (any alignment for the 3-channel stem). */
+int bd_conv2d_nhwc(const bd_conv2d_desc* d, bd_stream_t stream);
+/* F.max_pool2d (mode 0, padding = -inf) / F.avg_pool2d (mode 1, count_include_pad as given) with a square window, C % 4 == 0. */
+int bd_pool2d_nhwc(const float* x, int64_t ldx, float* y, int64_t ldy, int B, int H, int W, int C, int kernel, int stride, int pad,
+                   int mode, int count_include_pad, bd_stream_t stream);
+/* y = scale * F.interpolate(x, size=(Ho, Wo), mode="bilinear", align_corners=False) + shift; x is [B, H, W, C] uint8 (read as
+ * value / 255, i.e. after ToTensor) when x_is_u8, else float32. */
+int bd_resize_bilinear_nhwc(const void* x, int x_is_u8, float* y, int B, int H, int W, int C, int Ho, int Wo, float scale, float shift,
+                            bd_stream_t stream);
+/* AdaptiveAvgPool2d((1, 1)): y[b, c] = mean over the HW pixels of x [B, HW, C] (pixel stride ldx), fixed summation order. */
+int bd_global_avgpool_nhwc(const float* x, int64_t ldx, float* y, int B, int HW, int C, bd_stream_t stream);
+
+
 /* a-8: global-norm clip + Adam over one flat fp32 buffer (baddiffusion.py:320, 611-615).
  * bd_sumsq: sumsq (device double scalar) = sum g^2.  bd_adam_clip reads it:
  *   coef = min(1, max_norm / (sqrt(sumsq) + 1e-6));  g *= coef;  Adam(b1,b2,eps), bias correction from

@@ -44,7 +44,7 @@ def test_struct_layouts_match_header_sizes():
              "bd_operand": L.Operand, "bd_igemm_desc": L.IgemmDesc, "bd_conv3x3_fwd_desc": L.ConvFwdDesc,
              "bd_conv3x3_dgrad_desc": L.ConvDgradDesc, "bd_conv3x3_wgrad_desc": L.ConvWgradDesc, "bd_unet_config": L.UnetConfig,
              "bd_conv3x3_ps_desc": L.ConvPsDesc, "bd_conv3x3_ps_wgrad_desc": L.ConvPsWgradDesc,
-             "bd_upsample_conv_desc": L.UpsampleConvDesc, "bd_conv3x3_s2_dgrad_desc": L.ConvS2DgradDesc}
+             "bd_upsample_conv_desc": L.UpsampleConvDesc, "bd_conv2d_desc": L.Conv2dDesc, "bd_conv3x3_s2_dgrad_desc": L.ConvS2DgradDesc}
     prog = '#include <stdio.h>\n#include "bd_hip.h"\nint main(){' + "".join(
         f'printf("{n} %zu\\n", sizeof({n}));' for n in names) + "return 0;}"
     import tempfile
@@ -92,4 +92,9 @@ def test_round2_entry_points_reject_bad_arguments_without_gpu():
     assert lib.bd_upsample_conv_wgrad_workspace_bytes(ctypes.byref(d)) >= 4 * 256 * 16 * 128       # at least dE itself
     assert lib.bd_unet_set_deferred_join(None, 1) < 0 and lib.bd_unet_stream_wait_aux(None, None) < 0
     assert lib.bd_unet_set_static_weights(None, 1) < 0
+    # round 4: FID feature-extractor kernels
+    assert lib.bd_conv2d_nhwc(None, None) < 0 and b"bd_conv2d_nhwc" in lib.bd_last_error()
+    assert lib.bd_pool2d_nhwc(None, 4, None, 4, 1, 8, 8, 4, 3, 2, 0, 0, 0, None) < 0
+    assert lib.bd_resize_bilinear_nhwc(None, 0, None, 1, 8, 8, 3, 299, 299, 2.0, -1.0, None) < 0
+    assert lib.bd_global_avgpool_nhwc(None, 4, None, 1, 64, 4, None) < 0
     assert lib.bd_mfma_probe(1, 0, 1, None, None) < 0

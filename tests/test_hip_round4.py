@@ -117,3 +117,133 @@ def test_static_weights_sampling_loop(gpu):
     c = pipe(batch_size=4, init=init, num_inference_steps=6, output_type=None).images
     assert not np.array_equal(a, c)
     assert lib.bd_unet_set_static_weights(m._plan, 0) == 0
+
+
+# ------------------------------------------------------------------------------------------------ f-3: FID feature extractor
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad", [
+    (2, 19, 19, 3, 32, (3, 3), 2, (0, 0)),        # the stem: 3 channels (scalar loader), stride 2
+    (3, 17, 17, 80, 192, (3, 3), 1, (0, 0)),      # Cin % 16 != 0 (ragged K chunk)
+    (2, 12, 12, 48, 64, (5, 5), 1, (2, 2)),
+    (2, 17, 17, 160, 160, (1, 7), 1, (0, 3)),
+    (2, 17, 17, 160, 192, (7, 1), 1, (3, 0)),
+    (2, 8, 8, 448, 384, (3, 3), 1, (1, 1)),
+    (5, 9, 9, 96, 96, (3, 3), 2, (0, 0)),         # ragged pixel tiles: M = 5 * 16 = 80
+    (1, 8, 8, 2048, 320, (1, 1), 1, (0, 0)),
+])
+def test_conv2d_nhwc_vs_torch(gpu, B, H, W, Cin, Cout, k, stride, pad):
+    """bd_conv2d_nhwc (BasicConv2d of the FID Inception network with BatchNorm folded: conv + bias + ReLU, output at a channel
+    offset of a wider buffer) against F.conv2d in fp64 on the CPU.  Exact fp32 products: 1e-5 relative."""
+    import ctypes as CT
+    import torch.nn.functional as F
+    from baddiffusion_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, Cin, H, W, generator=g)
+    w = torch.randn(Cout, Cin, *k, generator=g) / (Cin * k[0] * k[1]) ** 0.5
+    b = torch.randn(Cout, generator=g)
+    want = F.relu(F.conv2d(x.double(), w.double(), b.double(), stride, pad)).permute(0, 2, 3, 1)
+    Ho, Wo = want.shape[1:3]
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    wd = w.permute(2, 3, 1, 0).contiguous().to(gpu)
+    bd = b.to(gpu)
+    out = torch.full((B, Ho, Wo, Cout + 8), -7.0, device=gpu)
+    view = out[..., 4:4 + Cout]
+    d = L.Conv2dDesc(x=xd.data_ptr(), ldx=Cin, w=wd.data_ptr(), bias=bd.data_ptr(), y=view.data_ptr(), ldy=Cout + 8, B=B, H=H, W=W, Cin=Cin,
+                     Cout=Cout, KH=k[0], KW=k[1], stride_h=stride, stride_w=stride, pad_h=pad[0], pad_w=pad[1], relu=1)
+    L.check(lib.bd_conv2d_nhwc(CT.byref(d), L.stream()), "bd_conv2d_nhwc")
+    assert relerr(view, want) < 1e-5
+    assert float(out[..., :4].min()) == -7.0 and float(out[..., 4 + Cout:].max()) == -7.0        # neighbours of the slice untouched
+
+
+def test_inception_pools_and_resize_vs_torch(gpu):
+    """bd_pool2d_nhwc (max 3/2/0 and 3/1/1, average 3/1/1 with count_include_pad False and True), bd_global_avgpool_nhwc and
+    bd_resize_bilinear_nhwc (uint8 and float sources, up- and down-scaling, then 2v - 1) against torch.nn.functional on the CPU."""
+    import torch.nn.functional as F
+    from baddiffusion_amd import _lib as L
+    lib = L.load()
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(3, 24, 17, 15, generator=g)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(gpu)
+    for (k, s, p, mode, cip), want in (((3, 2, 0, 0, 0), F.max_pool2d(x, 3, 2)), ((3, 1, 1, 0, 0), F.max_pool2d(x, 3, 1, 1)),
+                                       ((3, 1, 1, 1, 0), F.avg_pool2d(x, 3, 1, 1, count_include_pad=False)),
+                                       ((3, 1, 1, 1, 1), F.avg_pool2d(x, 3, 1, 1, count_include_pad=True))):
+        Ho, Wo = want.shape[2:]
+        y = torch.empty(3, Ho, Wo, 24, device=gpu)
+        L.check(lib.bd_pool2d_nhwc(xd.data_ptr(), 24, y.data_ptr(), 24, 3, 17, 15, 24, k, s, p, mode, cip, L.stream()), "bd_pool2d_nhwc")
+        assert float((y.cpu() - want.permute(0, 2, 3, 1)).abs().max()) < 1e-6, (k, s, p, mode, cip)
+    y = torch.empty(3, 24, device=gpu)
+    L.check(lib.bd_global_avgpool_nhwc(xd.data_ptr(), 24, y.data_ptr(), 3, 17 * 15, 24, L.stream()), "bd_global_avgpool_nhwc")
+    assert float((y.cpu() - F.adaptive_avg_pool2d(x, (1, 1)).flatten(1)).abs().max()) < 1e-6
+    for H, W in ((32, 32), (256, 256), (299, 299), (400, 301)):
+        u8 = torch.randint(0, 256, (2, H, W, 3), generator=g, dtype=torch.uint8)
+        want = 2 * F.interpolate((u8.float() / 255).permute(0, 3, 1, 2), size=(299, 299), mode="bilinear", align_corners=False) - 1
+        for src, is_u8 in ((u8.to(gpu), 1), ((u8.float() / 255).to(gpu), 0)):
+            y = torch.empty(2, 299, 299, 3, device=gpu)
+            L.check(lib.bd_resize_bilinear_nhwc(src.data_ptr(), is_u8, y.data_ptr(), 2, H, W, 3, 299, 299, 2.0, -1.0, L.stream()), "resize")
+            assert float((y.cpu() - want.permute(0, 2, 3, 1)).abs().max()) < 2e-6, (H, W, is_u8)
+
+
+def test_fid_inception_pool3_vs_oracle(gpu):
+    """f-3: FIDInceptionV3 (94 bd_conv2d_nhwc launches with folded BatchNorm, pools, resize) against the CPU restatement of
+    pytorch_fid's network (oracle/inception_ref.py) on seeded random weights: pool3 features of 32 x 32 uint8 images (the CIFAR
+    measure path) and of float 64 x 48 images, 1e-4 relative (fp32 both sides; 1e-3 is north_star's bar).  PARITY UNPINNED against
+    pytorch_fid itself (package and weights absent)."""
+    from baddiffusion_amd.inception import FIDInceptionV3
+    from oracle import inception_ref as I
+    P = I.gen_params(11)
+    net = FIDInceptionV3(P, device=gpu, batch_size=3)
+    g = torch.Generator().manual_seed(0)
+    u8 = torch.randint(0, 256, (5, 32, 32, 3), generator=g, dtype=torch.uint8)
+    got = net(u8.to(gpu))
+    want = I.pool3_features(P, (u8.float() / 255).permute(0, 3, 1, 2))
+    assert got.shape == (5, 2048) and relerr(got, want) < 1e-4, relerr(got, want)
+    fl = torch.rand(2, 3, 64, 48, generator=g)
+    assert relerr(net(fl.to(gpu)), I.pool3_features(P, fl)) < 1e-4
+    with pytest.raises(RuntimeError, match="device tensors"):
+        net(fl)
+    bad = dict(P); bad["Mixed_5b.branch1x1.conv.weight"] = torch.zeros(64, 192, 3, 3)
+    with pytest.raises(RuntimeError, match="size mismatch"):
+        FIDInceptionV3(bad, device=gpu)
+
+
+def test_measure_writes_fid_when_weights_are_mounted(gpu, tmp_path, monkeypatch):
+    """baddiffusion.py measure() (reference :477-551, FID at :533): with BD_FID_WEIGHTS pointing at a state-dict file score.json
+    carries a finite FID and no FID_reason; the features of both image sets (seed-shuffled dataset subset, written clean PNGs)
+    match the ORACLE network, and the statistics + Frechet distance (pinned by G8) over them reproduce the number.  (The distance
+    itself is not compared across networks: with n = 16 rows the 2048 x 2048 covariance product is rank-deficient and its matrix
+    square root is ill-conditioned.)"""
+    import dataclasses
+    import baddiffusion as cli
+    from baddiffusion_amd.dataset import DatasetLoader
+    from baddiffusion_amd.pipelines import DDIMPipeline
+    from baddiffusion_amd.schedulers import DDIMScheduler
+    from baddiffusion_amd.unet import unet_from_config
+    from oracle import inception_ref as I
+    cfg_net = dataclasses.replace(C.SMALL_CFGS["small"], sample_size=32)
+    model = unet_from_config(cfg_net).cuda()
+    model.load_state_dict(U.gen_params(cfg_net, 7))
+    dsl = DatasetLoader(root=None, name=DatasetLoader.CIFAR10, batch_size=8, seed=0, device=gpu, num_images=24)
+    dsl.set_poison(trigger_type="BOX_14", target_type="CORNER", clean_rate=1.0, poison_rate=0.25).prepare_dataset(mode="FIXED")
+    P = I.gen_params(5)
+    wfile = str(tmp_path / "pt_inception.pth")
+    torch.save(P, wfile)
+    monkeypatch.setenv("BD_FID_WEIGHTS", wfile)
+    config = cli.TrainingConfig()
+    config.output_dir = str(tmp_path / "out"); config.seed = 0; config.clip = False; config.sample_ep = None
+    config.measure_sample_n = 16; config.eval_max_batch = 16
+    os.makedirs(config.output_dir, exist_ok=True)
+    pipe = DDIMPipeline(model, DDIMScheduler(num_train_timesteps=1000, clip_sample=False))
+    score = cli.measure(config, dsl, "measure", pipe, rank=0, world=1)
+    assert "FID_reason_noclip" not in score and np.isfinite(score["FID_noclip"])
+    # the same two image sets through the oracle network
+    order = torch.randperm(len(dsl), generator=torch.Generator().manual_seed(config.seed))[:16]
+    real = dsl.device_images[dsl._rows()[order].to(gpu)].cpu()
+    clean = torch.from_numpy(cli._png_dir_u8(os.path.join(config.output_dir, "measure", "clean_noclip"), 3))
+    from baddiffusion_amd.inception import load_fid_weights
+    net = load_fid_weights(device=gpu)
+    fa, fb = net(real.to(gpu)), net(clean.to(gpu))
+    assert relerr(fa, I.pool3_features(P, (real.float() / 255).permute(0, 3, 1, 2))) < 1e-4
+    assert relerr(fb, I.pool3_features(P, (clean.float() / 255).permute(0, 3, 1, 2))) < 1e-4
+    # statistics + Frechet distance (pinned by G8) over exactly these features give the number in score.json
+    again = cli.fid_of_dirs(net, real.to(gpu), clean.to(gpu))
+    assert abs(again - score["FID_noclip"]) <= 1e-6 * max(1.0, abs(again)), (again, score["FID_noclip"])

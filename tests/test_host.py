@@ -289,3 +289,21 @@ def test_resume_rng_state_is_per_rank(tmp_path):
     cli.save_rank_rng(config, 1, st)
     assert cli.restore_training_state(config, None, rank=1) == (1, 7)
     assert torch.equal(torch.randn(4), torch.randn(4, generator=torch.Generator().manual_seed(config.seed + 1)))
+
+
+def test_fid_inception_manifest():
+    """f-3: the FID feature extractor's state-dict manifest (baddiffusion_amd/inception.py) names what pytorch_fid's
+    pt_inception-2015-12-05 checkpoint holds -- 94 BasicConv2d (conv.weight + 4 BatchNorm tensors each) + the unused 1008-way
+    fc head = 472 tensors, 23 885 392 parameters -- and agrees with the oracle's independent statement key for key.  A state dict
+    with a wrong shape, a missing or an unknown key is refused (no GPU needed: the check precedes any device work)."""
+    import pytest
+    from baddiffusion_amd import inception as P
+    from oracle import inception_ref as I
+    a, b = P.state_dict_manifest(), I.manifest()
+    assert list(a.items()) == list(b.items()) and len(a) == 472
+    assert sum(int(np.prod(s)) for s in a.values()) == 23_885_392
+    assert a["Conv2d_1a_3x3.conv.weight"] == (32, 3, 3, 3) and a["Mixed_6c.branch7x7dbl_4.conv.weight"] == (160, 160, 7, 1)
+    assert a["Mixed_7c.branch3x3dbl_1.conv.weight"] == (448, 2048, 1, 1) and a["fc.weight"] == (1008, 2048)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        P.FIDInceptionV3(device="cpu")
+    assert P.load_fid_weights("/nonexistent/pt_inception.pth") is None

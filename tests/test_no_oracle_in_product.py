@@ -23,7 +23,8 @@ def test_product_never_imports_oracle_or_reference():
 def test_no_torch_compute_fallback_for_network_ops():
     """No aten conv / group_norm / attention in the product: those ops exist only as HIP kernels."""
     banned = ("F.conv2d", "nn.Conv2d", "F.group_norm", "nn.GroupNorm", "scaled_dot_product_attention", "F.linear(", "nn.Linear(",
-              "torch.bmm", "torch.softmax", "F.silu")
+              "torch.bmm", "torch.softmax", "F.silu", "F.avg_pool2d", "F.max_pool2d", "F.interpolate", "F.batch_norm", "nn.BatchNorm2d",
+              "adaptive_avg_pool2d")
     for f in _py_files():
         src = open(f).read()
         code = re.sub(r'""".*?"""', "", src, flags=re.S)
