@@ -29,26 +29,42 @@ def cosine_schedule_with_warmup(step, num_warmup_steps, num_training_steps, num_
 
 
 class DPReducer:
-    """Sum-all-reduce of finished ranges of one flat gradient buffer, issued asynchronously as backward
-    produces them (RCCL over xGMI on the GPUs; gloo on CPU tensors in the tests).  The loss gradient is
-    pre-scaled by 1/world, so the sum is the global-batch mean gradient."""
+    """Sum-all-reduce of finished ranges of one flat gradient buffer, issued asynchronously as backward produces them.  The
+    loss gradient is pre-scaled by 1/world, so the sum is the global-batch mean gradient.  Two transports:
+      * `rccl` (an rccl.RcclComm; the product path on GPUs): ncclAllReduce enqueued directly on the caller's communication
+        stream -- ordering is plain HIP stream order, nothing else runs per collective;
+      * torch.distributed (c10d) on the current stream: gloo in the CPU / shared-GPU tests, or BD_DP_TRANSPORT=c10d for A/B."""
 
-    def __init__(self, flat, process_group=None, force=False, shadow=None):
+    def __init__(self, flat, process_group=None, force=False, shadow=None, rccl=None, stream=None):
         self.flat, self.pg = flat, process_group
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
-        self.active = self.world > 1 or (force and dist.is_available() and dist.is_initialized())
+        self.rccl, self.stream = rccl, stream
+        self.active = self.world > 1 or (force and (rccl is not None or (dist.is_available() and dist.is_initialized())))
         self.shadow = shadow          # ordering check (TrainEngine(dp_check=True)): what the collective's stream saw, see there
         self.works = []
         self.bytes = 0
 
-    def reduce_range(self, lo, hi):
-        if self.active and hi > lo:
-            self.works.append(dist.all_reduce(self.flat[lo:hi], group=self.pg, async_op=True))
-            self.bytes += 4 * (hi - lo)
-            if self.shadow is not None:
-                # snapshot the range on the stream that ISSUED the collective, right behind it: it reads the gradient at the
-                # point in time the collective's kernels may read it
+    def reduce_ranges(self, ranges):
+        """all ranges a backward segment has finalised; call with the communication stream current (its waits already issued)"""
+        if not self.active:
+            return
+        ranges = [(lo, hi) for lo, hi in ranges if hi > lo]
+        if self.rccl == "none":      # BD_DP_TRANSPORT=none (measurement only): the whole path without the collective call itself
+            self.bytes += sum(hi - lo for lo, hi in ranges) * 4
+        elif self.rccl is not None:
+            self.bytes += self.rccl.all_reduce_ranges_(self.flat, ranges, self.stream or torch.cuda.current_stream())
+        else:
+            for lo, hi in ranges:
+                self.works.append(dist.all_reduce(self.flat[lo:hi], group=self.pg, async_op=True))
+                self.bytes += 4 * (hi - lo)
+        if self.shadow is not None:
+            # snapshot the ranges on the stream that ISSUED the collective, right behind it: it reads the gradient at the
+            # point in time the collective's kernels may read it
+            for lo, hi in ranges:
                 self.shadow[lo:hi].copy_(self.flat[lo:hi])
+
+    def reduce_range(self, lo, hi):
+        self.reduce_ranges([(lo, hi)])
 
     def finish(self):
         for w in self.works:
@@ -74,6 +90,32 @@ def ensure_single_rank_group(backend=None):
 def plan_segments(model):
     """[(lo, hi)] main ranges of the flat gradient in the order backward finalises them."""
     return [r[0] for r in plan_segment_ranges(model)]
+
+
+def merge_ranges(ranges):
+    """union of [lo, hi) ranges as a sorted list of disjoint ranges (adjacent / overlapping ones fused): consecutive backward
+    segments own adjacent stretches of the flat gradient -- alignment pads between tensors are zero and ride along"""
+    out = []
+    for lo, hi in sorted(r for r in ranges if r[1] > r[0]):
+        if out and lo <= out[-1][1] + 64:       # (tensors start on 32-float boundaries: gaps are alignment pads)
+            out[-1] = (out[-1][0], max(out[-1][1], hi))
+        else:
+            out.append((lo, hi))
+    return out
+
+
+def plan_buckets(seg_ranges, bucket_bytes):
+    """Group the backward segments (in the order they finish) into communication buckets: a bucket closes with the first segment
+    that brings it to `bucket_bytes` (the last one takes the rest).  Returns [(last segment index, [merged ranges])].
+    bucket_bytes <= 0: one bucket per segment."""
+    buckets, cur, size = [], [], 0
+    for s, rs in enumerate(seg_ranges):
+        cur += rs
+        size += sum(hi - lo for lo, hi in rs) * 4
+        if bucket_bytes <= 0 or size >= bucket_bytes or s == len(seg_ranges) - 1:
+            buckets.append((s, merge_ranges(cur)))
+            cur, size = [], 0
+    return buckets
 
 
 def plan_segment_ranges(model):
@@ -111,8 +153,8 @@ class TrainEngine:
         if force_dp is None:
             force_dp = os.environ.get("BD_FORCE_DP", "0") == "1"
         self.force_dp = bool(force_dp)
-        if self.force_dp:
-            ensure_single_rank_group()
+        if self.force_dp and os.environ.get("BD_DP_TRANSPORT", "rccl") == "c10d":
+            ensure_single_rank_group()      # c10d needs a process group even for one rank; the direct RCCL transport does not
         self.world = dist.get_world_size(process_group) if (dist.is_available() and dist.is_initialized()) else 1
         self.dp = self.world > 1 or self.force_dp
         self.accum = int(grad_accum_steps)
@@ -129,6 +171,11 @@ class TrainEngine:
         self._lib = L.load()
         self._nseg = self._lib.bd_unet_num_segments(model._plan)
         self._seg_ranges = plan_segment_ranges(model)
+        # communication buckets: every collective has a fixed cost beside the backward kernels, xGMI rings
+        # are per-link bound and want large messages -- segments are fused until a bucket holds BD_DP_BUCKET_MB (default 32 MB:
+        # 5 buckets / 8 collectives for the CIFAR UNet's 143 MB instead of 12 / 30)
+        self._buckets = plan_buckets(self._seg_ranges, int(float(os.environ.get("BD_DP_BUCKET_MB", "32")) * 2 ** 20))
+        self._bucket_at = {s: rs for s, rs in self._buckets}
         # hipGraph replay of the whole step (fused q_sample -> forward -> loss -> backward -> clip + Adam): one launch per
         # step from the host instead of ~700.  Single-process, no gradient accumulation; BD_TRAIN_GRAPH=0/1 overrides.
         if use_graph is None:
@@ -138,8 +185,20 @@ class TrainEngine:
         # deferred join of the weight-gradient side stream (include/bd_hip.h: bd_unet_set_deferred_join); BD_DEFER_JOIN=0 = A/B
         self._defer = os.environ.get("BD_DEFER_JOIN", "1") != "0"
         L.check(self._lib.bd_unet_set_deferred_join(model._plan, 1 if self._defer else 0), "bd_unet_set_deferred_join")
-        self._comm = torch.cuda.Stream(device=dev) if (self.dp and self._defer) else None
+        # transport of the gradient exchange: RCCL called directly on our own stream (rccl.py) whenever the ranks own one GPU each
+        # (default group backend nccl, or the forced 1-rank path); c10d otherwise (gloo: CPU tests / ranks sharing a GPU)
+        self._rccl = None
+        if self.dp and self.world == 1 and os.environ.get("BD_DP_TRANSPORT", "rccl") == "none":
+            self._rccl = "none"
+        if self.dp and os.environ.get("BD_DP_TRANSPORT", "rccl") == "rccl":
+            be = dist.get_backend(process_group) if (dist.is_available() and dist.is_initialized()) else "none"
+            if process_group is None and (be == "nccl" or self.world == 1):
+                from .rccl import RcclComm
+                self._rccl = RcclComm(dev)
+        self._comm = torch.cuda.Stream(device=dev) if (self.dp and (self._defer or self._rccl is not None)) else None
         self._dp_shadow = torch.zeros(n, device=dev) if (dp_check and self.dp) else None
+        if dp_check and self.accum != 1:
+            raise ValueError("dp_check needs grad_accum_steps == 1")
         self.collective_bytes = 0
         self.alphas, self.alphas_cumprod = noise_sched.device_tables(dev)
         self.sync_state()
@@ -150,7 +209,10 @@ class TrainEngine:
         points and drift apart).  Call again after loading optimizer state on a resume."""
         if self.world > 1:
             for t in (self.model.flat.data, self.m, self.v):
-                dist.broadcast(t, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
+                if self._rccl is not None and self._rccl != "none":
+                    self._rccl.broadcast_(t, 0, torch.cuda.current_stream())
+                else:
+                    dist.broadcast(t, src=dist.get_global_rank(self.pg, 0) if self.pg is not None else 0, group=self.pg)
 
     # ---- LR schedule (host scalar; baddiffusion.py:327-331) ------------------------------------------
     def current_lr(self):
@@ -170,7 +232,7 @@ class TrainEngine:
             self.grads.fill_(float("nan"))
             for plo, phi in model._pads:
                 self.grads[plo:phi].zero_()
-        red = DPReducer(self.grads, self.pg, force=self.force_dp, shadow=self._dp_shadow)
+        red = DPReducer(self.grads, self.pg, force=self.force_dp, shadow=self._dp_shadow, rccl=self._rccl, stream=self._comm)
         lo, hi = ctypes.c_int64(), ctypes.c_int64()
         main = torch.cuda.current_stream()
         for s in range(self._nseg):
@@ -178,22 +240,22 @@ class TrainEngine:
                 model._plan, s, B, flat.data_ptr(), xn.data_ptr(), xn.shape[-1], dpred.data_ptr(), dpred.shape[-1],
                 self.grads.data_ptr(), ws.data_ptr(), ws.numel(), L.stream(), ctypes.byref(lo), ctypes.byref(hi)),
                 "bd_unet_backward_segment")
-            if not self.dp:
+            if not self.dp or s not in self._bucket_at:
                 continue
+            ranges = self._bucket_at[s]
             # The segment's weight gradients may still be running on the plan's side stream (deferred join): the collective
             # is issued from a third stream that waits for (a) the main stream's position -- GroupNorm parameter fold, bias
             # rows -- and (b) the side stream's position, so the NEXT segment's kernels on the main stream are not held back.
             # RCCL orders itself after the issuing stream, then overlaps with the next segments; 143 MB per step for the
             # CIFAR UNet.
-            if self._defer:
+            if self._comm is not None:
                 self._comm.wait_stream(main)
-                L.check(self._lib.bd_unet_stream_wait_aux(model._plan, self._comm.cuda_stream), "bd_unet_stream_wait_aux")
+                if self._defer:     # (without the deferred join the segment call has already ordered `main` behind the side stream)
+                    L.check(self._lib.bd_unet_stream_wait_aux(model._plan, self._comm.cuda_stream), "bd_unet_stream_wait_aux")
                 with torch.cuda.stream(self._comm):
-                    for (rlo, rhi) in self._seg_ranges[s]:
-                        red.reduce_range(rlo, rhi)
+                    red.reduce_ranges(ranges)
             else:
-                for (rlo, rhi) in self._seg_ranges[s]:
-                    red.reduce_range(rlo, rhi)
+                red.reduce_ranges(ranges)
         red.finish()          # the main stream waits for every collective (work.wait() orders the CURRENT stream)
         if self._comm is not None:
             main.wait_stream(self._comm)      # ... and for whatever else the issuing stream did behind them (dp_check snapshots)

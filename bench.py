@@ -560,24 +560,45 @@ def main():
     dp_probe = None
     if world == 1 and not celeba and not args.no_dp_probe:
         # the data-parallel communication path at N = 1 (task 3): a second engine over the same model with
-        # force_dp -- comm stream, side-stream event wait, one async RCCL all_reduce per finished gradient range on a 1-rank group
+        # force_dp -- comm stream, side-stream event wait, one grouped ncclAllReduce per bucket on a 1-rank communicator.  Measured
+        # twice: with the RCCL call, and with everything but that call (BD_DP_TRANSPORT=none) -- RCCL's 1-rank path performs a
+        # host-synchronous operation per call, which stalls the host's run-ahead (host_enqueue_ms); its multi-rank path launches a
+        # kernel instead.
         try:
             from baddiffusion_amd.trainer import TrainEngine
             from baddiffusion_amd.schedulers import DDPMScheduler
-            eng2 = TrainEngine(model, DDPMScheduler(num_train_timesteps=1000), lr=2e-4, lr_warmup_steps=500, num_training_steps=469 * 50,
-                               force_dp=True)
-            def step2(i, _e=eng2):
-                return _e.train_step(*step.inputs(i))
-            for i in range(3):
-                step2(i)
-            ddt, _, dper = timed_steps(step2, 3, 10, barrier, dev, world)
-            pdt, _, _ = timed_steps(step, 3, 10, barrier, dev, world)      # the ordinary step again, back to back on the same clocks
-            dp_probe = {"ms_per_step": ddt / 10 * 1e3, "ms_per_step_plain_back_to_back": pdt / 10 * 1e3,
-                        "overhead_ms": (ddt - pdt) / 10 * 1e3, "backend": dist.get_backend(), "world": dist.get_world_size(),
-                        "collectives_per_step": sum(len(rs) for rs in eng2._seg_ranges), "bytes_per_step": int(eng2.collective_bytes),
+
+            def host_and_gpu(fn, n=10):
+                for i in range(3):
+                    fn(i)
+                barrier()
+                t0 = time.perf_counter()
+                for i in range(n):
+                    fn(3 + i)
+                th = time.perf_counter() - t0
+                barrier()
+                return (time.perf_counter() - t0) / n * 1e3, th / n * 1e3
+
+            res = {}
+            for transport in ("rccl", "none"):
+                os.environ["BD_DP_TRANSPORT"] = transport
+                e2 = TrainEngine(model, DDPMScheduler(num_train_timesteps=1000), lr=2e-4, lr_warmup_steps=500, num_training_steps=469 * 50,
+                                 force_dp=True)
+                ms_, host_ = host_and_gpu(lambda i, _e=e2: _e.train_step(*step.inputs(i)))
+                res[transport] = (ms_, host_, e2)
+            os.environ.pop("BD_DP_TRANSPORT", None)
+            pms, phost = host_and_gpu(step)      # the ordinary step again, back to back on the same clocks
+            e2 = res["rccl"][2]
+            dp_probe = {"ms_per_step": res["rccl"][0], "host_enqueue_ms": res["rccl"][1],
+                        "ms_per_step_without_the_rccl_call": res["none"][0], "host_enqueue_ms_without_the_rccl_call": res["none"][1],
+                        "ms_per_step_plain_back_to_back": pms, "host_enqueue_ms_plain": phost,
+                        "overhead_ms": res["rccl"][0] - pms, "overhead_ms_without_the_rccl_call": res["none"][0] - pms,
+                        "transport": "RCCL called directly (baddiffusion_amd/rccl.py), 1-rank communicator", "world": e2.world,
+                        "collectives_per_step": sum(len(rs) for _, rs in e2._buckets), "buckets": len(e2._buckets),
+                        "bytes_per_step": int(e2.collective_bytes),
                         "note": "TrainEngine(force_dp=True): trainer.py's DP branch on one GPU; tests/test_hip_round4.py checks its stream ordering"}
-            log(f"dp path at world 1: {ddt / 10 * 1e3:.2f} ms/step (plain {pdt / 10 * 1e3:.2f})")
-            del eng2
+            log(f"dp path at world 1: {res['rccl'][0]:.2f} ms/step, without the RCCL call {res['none'][0]:.2f} (plain {pms:.2f})")
+            del e2, res
         except Exception as e:      # a box without a working RCCL init must not lose the headline line
             dp_probe = {"error": f"{type(e).__name__}: {e}"}
 
@@ -642,7 +663,7 @@ def main():
                         f"BOX_14 trigger, {target_name} target" + ("" if target_name == "HAT" else " (HAT stand-in)") + ", clip 1.0 + Adam, fp32 storage")
         srt = sorted(per_step)
         nseg = len(eng._seg_ranges)
-        coll = [sum(hi - lo for lo, hi in rs) * 4 for rs in eng._seg_ranges]
+        coll = [sum(hi - lo for lo, hi in rs) * 4 for _, rs in eng._buckets]
         out = {"metric": metric,
                "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
@@ -657,10 +678,13 @@ def main():
                "step_frac_of_fp32_mfma_peak": gflop_img * B / (ms * 1e-3) / 1e3 / FP32_MFMA_PEAK_TFLOPS,
                "step_frac_of_hbm_roofline": hbm_floor_ms / ms,
                "distributed": {"world": world, "backend": backend if world > 1 else "none (single process)",
-                               "collectives_per_step": sum(len(rs) for rs in eng._seg_ranges) if world > 1 else 0,
-                               "segments": nseg, "bytes_per_segment": coll, "bytes_per_step": sum(coll),
-                               "note": "one async all_reduce (sum; loss gradient pre-scaled by 1/world) per finished range of the flat fp32 "
-                                       "gradient, issued while the next backward segment computes"}}
+                               "gradient_transport": ("RCCL called directly on the engine's communication stream (baddiffusion_amd/rccl.py)"
+                                                      if eng._rccl is not None else ("torch.distributed (c10d)" if world > 1 else "none")),
+                               "collectives_per_step": sum(len(rs) for _, rs in eng._buckets) if world > 1 else 0,
+                               "segments": nseg, "buckets": len(eng._buckets), "bytes_per_bucket": coll, "bytes_per_step": sum(coll),
+                               "note": "backward segments are fused into buckets of >= BD_DP_BUCKET_MB (32); when a bucket's last segment has run, "
+                                       "its ranges of the flat fp32 gradient are all-reduced (sum; loss gradient pre-scaled by 1/world) from the "
+                                       "communication stream while the next segments compute"}}
         if sustained:
             out["sustained"] = sustained
         if not args.no_prof and classes:

@@ -3,9 +3,10 @@
 Two engines over identical weights take 3 CIFAR-topology train steps at B = 128 on the same inputs:
   A: the ordinary single-GPU step;
   B: TrainEngine(force_dp=True, dp_check=True) -- the data-parallel path of trainer.py (comm stream, bd_unet_stream_wait_aux,
-     one async all_reduce per finished gradient range, backend nccl = RCCL on a 1-rank group), with the gradient buffer
-     NaN-filled before every backward and the optimizer fed from snapshots taken on the collective's stream.
-Prints one JSON line: {equal, max_abs_diff, finite, backend, collective_bytes, ms_plain, ms_dp}."""
+     one all-reduce per finished gradient range: RCCL called directly on a 1-rank communicator, or with BD_DP_TRANSPORT=c10d
+     torch.distributed's nccl backend on a 1-rank group), with the gradient buffer NaN-filled before every backward and the
+     optimizer fed from snapshots taken on the collective's stream.
+Prints one JSON line: {equal, max_abs_diff, finite, transport, collective_bytes, ms_plain, ms_dp}."""
 import json
 import os
 import sys
@@ -40,7 +41,7 @@ def main():
     ea = TrainEngine(ma, DDPMScheduler(), lr=2e-4, force_dp=False)
     eb = TrainEngine(mb, DDPMScheduler(), lr=2e-4, force_dp=True, dp_check=True)
     assert eb.dp and eb._comm is not None and eb._dp_shadow is not None
-    out = {"backend": dist.get_backend(), "world": dist.get_world_size()}
+    out = {"transport": "rccl-direct" if eb._rccl is not None else "c10d:" + dist.get_backend(), "world": eb.world}
     for e, key in ((ea, "ms_plain"), (eb, "ms_dp")):
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -53,7 +54,8 @@ def main():
                finite=bool(torch.isfinite(mb.flat.data).all()), collective_bytes=int(eb.collective_bytes),
                moments_equal=bool(torch.equal(ea.m, eb.m) and torch.equal(ea.v, eb.v)))
     print(json.dumps(out), flush=True)
-    dist.destroy_process_group()
+    if dist.is_initialized():
+        dist.destroy_process_group()
 
 
 if __name__ == "__main__":
