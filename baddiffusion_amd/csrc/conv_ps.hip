@@ -47,7 +47,22 @@ struct PsParams {
     int accumulate;
     unsigned short* y_split; long long ldys;   // optional second output: y in split planes (same row count, ld)
     int ablate;            // -DBD_PS_ABLATION builds only (BD_PS_ABLATE): 1 = no steady-state DMA, 2 = no MFMA, 4 = no fragment reads
+    int lvw;               // conv_ps3_kernel: log2 of the VIRTUAL image width min(W, 32), see ps_v2r
 };
+
+// Round 4: VIRTUAL pixel order.  The vertical-tap-sharing kernels (conv_ps3_kernel, conv_ps_wgrad3_kernel) want the rows one image row
+// apart to sit a SMALL constant number of pixels apart in the order they walk the image (a 256 + 2W row LDS window, an X ring of 2W + 32
+// pixels): fine for W <= 32, impossible for the 64 .. 256 wide layers of the 256 x 256 network.  Those are walked strip by strip instead:
+// an image is cut into W/32 vertical strips of 32 columns and virtual pixel v = strip * (H * 32) + y * 32 + xs, so that one image row down is
+// always v + 32 -- to the kernels every image looks 32 pixels wide and H * W / 32 rows tall, and only the address of a pixel (this
+// function) and the "is the row above / below inside the image" test (y = (v >> 5) & (H - 1)) know about the real layout.  A 256-pixel tile is
+// then an 8 x 32 pixel block, a 32-pixel chunk one strip row.  W <= 32: identity.
+__device__ __forceinline__ int ps_v2r(int v, int lw, int lh, int lvw) {
+    if (lw == lvw) return v;
+    const int lhw = lw + lh;
+    const int r = v & ((1 << lhw) - 1);
+    return (v - r) + (((r >> lvw) & ((1 << lh) - 1)) << lw) + ((r >> (lh + lvw)) << lvw) + (r & ((1 << lvw) - 1));
+}
 
 // bank swizzle of the 16-byte slots of a 128-byte LDS row (row stride 128 B = half a 256-byte bank row): rows r and
 // r^1 share a bank row, f spreads 16 consecutive rows over the 8 slots x 2 halves -> every ds_read_b128 lane group
@@ -77,15 +92,17 @@ __device__ __forceinline__ void ps_sync() {
 // (wave-uniform: every row of the sub-tile is < M) removes the per-element predicate: behind an exec-masked branch per
 // element hipcc reuses one address register pair and waits vmcnt(0) for the previous store before every store -- a chain
 // of ~64 serialised memory round trips per wave that used to be a large part of the per-tile overhead.
+// mb[i] = the output row of the first of the 32 consecutive rows of the wave's i-th 32 x 32 tile (consecutive in memory: a virtual-order
+// tile of conv_ps3_kernel is 8 image-row pieces of 32 pixels, see ps_v2r)
 template <int EPI, int TM, bool FULL>
-__device__ __forceinline__ void ps_epilogue(const PsParams& p, floatx16 (&acc)[TM][2], int mw, int nw, int li, int h) {
+__device__ __forceinline__ void ps_epilogue(const PsParams& p, floatx16 (&acc)[TM][2], const int (&mb)[TM], int nw, int li, int h) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int q = 0; q < 2; ++q) {
             const int n = nw + q * 32 + li;
             const float bn = p.bias ? p.bias[n] : 0.f;
-            const int m_base = mw + i * 32 + 4 * h;
+            const int m_base = mb[i] + 4 * h;
             float ad[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) ad[r] = 0.f;
@@ -277,8 +294,9 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps_kernel(PsParams p) {
 
     // ---- epilogue: lane holds column n = li of rows (r&3) + 8*(r>>2) + 4*h of every 32x32 tile
     const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-    if (mw + 64 <= p.M) ps_epilogue<EPI, 2, true>(p, acc, mw, nw, li, h);    // wave-uniform: whole sub-tile inside M
-    else ps_epilogue<EPI, 2, false>(p, acc, mw, nw, li, h);
+    const int mb[2] = {mw, mw + 32};
+    if (mw + 64 <= p.M) ps_epilogue<EPI, 2, true>(p, acc, mb, nw, li, h);    // wave-uniform: whole sub-tile inside M
+    else ps_epilogue<EPI, 2, false>(p, acc, mb, nw, li, h);
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -311,20 +329,22 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps3_kernel(PsParams p) {
     const int m0 = tm * PS_BM, n0 = tn * PS_BN;
 
     // ---- A window: wave w moves row groups (8 rows = one 1-KiB DMA) w, w+8, .., w+32 of the 320-row window; window row wr is
-    // pixel m0 - W + wr.  Per row: validity of the image row, and of the three column shifts.
+    // (virtual) pixel m0 - VW + wr.  Per row: validity of the image row, and of the three column shifts.
     const int dr = lane >> 3, ps = lane & 7;
     const char* ap[5];
     int vm[5];
+    // (m0 and the window rows are VIRTUAL pixels, ps_v2r: VW = min(W, 32) wide rows; a tile = 256 / VW rows of one strip of one image)
+    const int VW = 1 << p.lvw, lh = p.lhw - p.lw;
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
         const int wr = (wave + 8 * j) * 8 + dr;
-        const int m = m0 - p.W + wr;                         // may be < 0 or past the image: masked below
+        const int m = ps_v2r(m0 - VW + wr, p.lw, lh, p.lvw);  // may be < 0 or past the image: masked below
         const int x = m & (p.W - 1);
-        const int yrel = (wr >> p.lw) - 1;                   // image row relative to the tile's first row
-        const int y0 = (m0 >> p.lw) & (p.H - 1);
+        const int yrel = (wr >> p.lvw) - 1;                  // image row relative to the tile's first row
+        const int y0 = (m0 >> p.lvw) & (p.H - 1);
         const int yy = y0 + yrel;
         int mask = 0;
-        if ((unsigned)yy < (unsigned)p.H && wr < PS_BM + 2 * p.W) {      // (tiles never straddle images: H*W % 256 == 0, host-checked)
+        if ((unsigned)yy < (unsigned)p.H && wr < PS_BM + 2 * VW) {       // (tiles never straddle strips / images: H * VW % 256 == 0, host-checked)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx)
                 if ((unsigned)(x + p.sign * (kx - 1)) < (unsigned)p.W) mask |= 1 << kx;
@@ -367,8 +387,8 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps3_kernel(PsParams p) {
 #pragma unroll
         for (int pl = 0; pl < 2; ++pl) foff[s][pl] = li * 128 + (((pl * 4 + s * 2 + h) ^ ps_swz(li)) << 4);
     const int abase = wm * 64 * 128, bbase = wn * 64 * 128;
-    // vertical tap ky of the forward gather reads window rows r + ky*W; the data-gradient gather (sign -1) mirrors it
-    const int wrow_bytes = p.W * 128;
+    // vertical tap ky of the forward gather reads window rows r + ky*VW; the data-gradient gather (sign -1) mirrors it
+    const int wrow_bytes = VW * 128;
 
     floatx16 acc[2][2];
 #pragma unroll
@@ -438,9 +458,10 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps3_kernel(PsParams p) {
     }
     (void)nchunks;
 
-    const int mw = m0 + wm * 64, nw = n0 + wn * 64;
-    if (mw + 64 <= p.M) ps_epilogue<EPI, 2, true>(p, acc, mw, nw, li, h);
-    else ps_epilogue<EPI, 2, false>(p, acc, mw, nw, li, h);
+    // output rows: the wave's two 32-pixel blocks, virtual -> real (32 consecutive virtual pixels are consecutive in memory)
+    const int nw = n0 + wn * 64;
+    const int mb[2] = {ps_v2r(m0 + wm * 64, p.lw, lh, p.lvw), ps_v2r(m0 + wm * 64 + 32, p.lw, lh, p.lvw)};
+    ps_epilogue<EPI, 2, true>(p, acc, mb, nw, li, h);        // (M % 256 == 0: every tile is whole, host-checked)
 }
 
 // ---------------------------------------------------------------------------------------------------------------------
@@ -582,8 +603,9 @@ __global__ __launch_bounds__(512, 4) void conv_ps128_kernel(PsSmallParams pp) {
         return;
     }
     floatx16 a2[1][2] = {{acc[0], acc[1]}};
-    if (full) ps_epilogue<EPI, 1, true>(p, a2, mw, nw, li, h);
-    else ps_epilogue<EPI, 1, false>(p, a2, mw, nw, li, h);
+    const int mb[1] = {mw};
+    if (full) ps_epilogue<EPI, 1, true>(p, a2, mb, nw, li, h);
+    else ps_epilogue<EPI, 1, false>(p, a2, mb, nw, li, h);
 }
 
 // second pass of the K split: fixed-order sum of the slabs + the epilogue, float4 per thread (N % 4 == 0)
@@ -648,6 +670,7 @@ struct PsWgParams {
     int want_db;
     int ablate;                        // -DBD_PS_ABLATION builds only, as in PsParams
     int ntaps;                         // taps per output row: 9, or 16 in the PHASE form (conv_ph.hip: upsample convolution)
+    int lh, lvw;                       // conv_ps_wgrad3_kernel: log2(H), log2 of the virtual image width min(W, 32) (ps_v2r)
 };
 
 typedef short ps_short4 __attribute__((ext_vector_type(4)));
@@ -1004,20 +1027,22 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
         char* stage = smem + (c & 1) * WG_OP_BYTES;
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const long long pp = (long long)c * 32 + kpix[j];
+            const long long pp = ps_v2r(c * 32 + kpix[j], p.lw, p.lh, p.lvw);       // chunk c = 32 VIRTUAL pixels (one strip row when W > 32)
             ps_dma16(abase_g[j] + pp * p.lddy * 4, stage + (wave + 8 * j) * 1024);
         }
     };
-    // X pixels [32 v + W, 32 v + 32 + W) of (possibly virtual, v < c_begin) chunk v: the rows the LAST vertical tap of chunk v needs
+    const int VW = 1 << p.lvw;
+    // X pixels [32 v + VW, 32 v + 32 + VW) (virtual order) of chunk v (v < c_begin: the halo): the rows the LAST vertical tap of chunk v needs
     auto issue_x = [&](int v) {
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-            const int s0 = v * 32 + p.W + 2 * (wave + 8 * j);            // first pixel of the pair (wave-uniform)
+            const int s0 = v * 32 + VW + 2 * (wave + 8 * j);             // first (virtual) pixel of the pair (wave-uniform)
             const int s = s0 + (lane >> 5);
-            const int x = s & (p.W - 1);
+            const int sr = ps_v2r(s, p.lw, p.lh, p.lvw);                 // its place in memory
+            const int x = sr & (p.W - 1);
             const bool ok = s >= 0 && s < p.P && (unsigned)(x + dxt) < (unsigned)p.W;
             const int unit = ((s0 + 4096) >> 4) & (WG3_RING_UNITS - 1);
-            ps_dma16(ok ? bbase_g[j] + (long long)(s + dxt) * p.ldx * 4 : reinterpret_cast<const char*>(kPsZero),
+            ps_dma16(ok ? bbase_g[j] + (long long)(sr + dxt) * p.ldx * 4 : reinterpret_cast<const char*>(kPsZero),
                      ring + unit * WG3_UNIT_BYTES + (s0 & 15) * 512);
         }
     };
@@ -1088,7 +1113,7 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
         for (int q = 0; q < 2; ++q) a[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[q], a[q], 0, 0, 0);
     };
 
-    const int wu = p.W >> 4;       // units per image row
+    const int wu = VW >> 4;        // units per (virtual) image row
     // six (16-pixel step, tap) stages per chunk, statically scheduled: the fragments of stage i+1 are read while the MFMAs of stage i
     // run.  A tap whose X row is outside the image skips its MFMAs (wave-uniform); its reads hit a live ring slot and are dropped.
     auto compute = [&](int c) {
@@ -1099,7 +1124,7 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
             const int S = i / 3, ky = i - 3 * S;
-            const int y = ((p0 + 16 * S) >> p.lw) & (p.H - 1);
+            const int y = ((p0 + 16 * S) >> p.lvw) & (p.H - 1);
             ok[i] = (unsigned)(y + ky - 1) < (unsigned)p.H;
             xb[i] = ring_addr + (unsigned)(((u0 + S + (ky - 1) * wu) & (WG3_RING_UNITS - 1)) * WG3_UNIT_BYTES);
         }
@@ -1129,7 +1154,7 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
     };
 
     if (c_begin < c_end) {
-        for (int v = c_begin - (p.W >> 4); v < c_begin; ++v) issue_x(v);     // halo: X rows [32 c_begin - W, 32 c_begin + W)
+        for (int v = c_begin - (VW >> 4); v < c_begin; ++v) issue_x(v);      // halo: X rows [32 c_begin - VW, 32 c_begin + VW)
         issue_dy(c_begin); issue_x(c_begin);
         for (int c = c_begin; c < c_end; ++c) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -1385,7 +1410,11 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
 #endif
         // vertical-tap sharing variant (conv_ps3_kernel): image rows of 16 or 32 pixels, whole images per tile row block
         static const bool v3_off = getenv("BD_PS_V3") && atoi(getenv("BD_PS_V3")) == 0;
-        const bool v3 = !v3_off && (d.W == 16 || d.W == 32) && ((long long)d.H * d.W) % PS_BM == 0 && M % PS_BM == 0;
+        // round 4: any W >= 16 -- images wider than 32 pixels are walked strip by strip (virtual pixel order, ps_v2r)
+        static const int v3_maxw = getenv("BD_PS_V3_MAXW") ? atoi(getenv("BD_PS_V3_MAXW")) : (1 << 30);     // (A/B knob: 32 = round 3's gate)
+        const int vw = d.W < 32 ? d.W : 32;
+        const bool v3 = !v3_off && d.W >= 16 && d.W <= v3_maxw && ((long long)d.H * vw) % PS_BM == 0 && M % PS_BM == 0;
+        p.lvw = ilog2x(vw);
 #define PS_LAUNCH(E) do { if (v3) hipLaunchKernelGGL((conv_ps3_kernel<E>), grid, block, 0, st, p); \
                           else hipLaunchKernelGGL((conv_ps_kernel<E>), grid, block, 0, st, p); } while (0)
         switch (epi) {          // every combination has its own instantiation: the epilogue's addends are compile-time
@@ -1438,7 +1467,9 @@ bool conv3x3_ps_wgrad_supported(int B, int H, int W, int Cin, int Cout) {
 // vertical-tap sharing form (conv_ps_wgrad3_kernel): image rows of 16 or 32 pixels, whole 32-pixel chunks
 static bool ps_wgrad_v3(const bd_conv3x3_ps_wgrad_desc& d) {
     static const bool off = getenv("BD_PS_WG3") && atoi(getenv("BD_PS_WG3")) == 0;
-    return !off && (d.W == 16 || d.W == 32) && ((long long)d.B * d.H * d.W) % 32 == 0;
+    static const int maxw = getenv("BD_PS_WG3_MAXW") ? atoi(getenv("BD_PS_WG3_MAXW")) : (1 << 30);        // (A/B knob: 32 = round 3's gate)
+    // round 4: any W >= 16 -- wider images are walked strip by strip (virtual pixel order, ps_v2r): a chunk = one 32-pixel strip row
+    return !off && d.W >= 16 && d.W <= maxw && ((long long)d.B * d.H * d.W) % 32 == 0;
 }
 static void ps_wgrad_split(const bd_conv3x3_ps_wgrad_desc& d, int& ksplit, int& cps) {
     const bool v3 = ps_wgrad_v3(d);
@@ -1472,6 +1503,7 @@ int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
     PsWgParams p = {};
     p.dy = reinterpret_cast<const char*>(d.dy_split); p.x = reinterpret_cast<const char*>(d.x_split);
     p.lddy = d.lddy; p.ldx = d.ldx; p.Cin = d.Cin; p.Cout = d.Cout; p.H = d.H; p.W = d.W; p.lw = ilog2x(d.W);
+    p.lh = ilog2x(d.H); p.lvw = ilog2x(d.W < 32 ? d.W : 32);
     p.P = d.B * d.H * d.W;
     const bool v3 = ps_wgrad_v3(d);
     p.tiles_m = d.Cout / WG_BM; p.tiles_n = (v3 ? 3 : 9) * d.Cin / WG_BN; p.ntaps = 9;

@@ -249,3 +249,34 @@ def test_measure_writes_fid_when_weights_are_mounted(gpu, tmp_path, monkeypatch)
     # statistics + Frechet distance (pinned by G8) over exactly these features give the number in score.json
     again = cli.fid_of_dirs(net, real.to(gpu), clean.to(gpu))
     assert abs(again - score["FID_noclip"]) <= 1e-6 * max(1.0, abs(again)), (again, score["FID_noclip"])
+
+
+# ------------------------------------------------------------------------------------------------ 256 x 256 network: wide layers
+@pytest.mark.parametrize("B,H,W,Cin,Cout", [(1, 256, 256, 128, 128), (3, 128, 64, 128, 128), (3, 64, 128, 256, 128), (4, 64, 64, 128, 256),
+                                             (1, 8, 64, 128, 128)])
+def test_conv_ps_wide_images_virtual_pixel_order(gpu, B, H, W, Cin, Cout):
+    """Round 4: the vertical-tap-sharing kernels (conv_ps3_kernel forward / data gradient, conv_ps_wgrad3_kernel) on images WIDER than 32
+    pixels -- walked strip by strip in virtual pixel order (conv_ps.hip: ps_v2r) -- against the exact-fp32 igemm path (1e-4) and the
+    split-bf16 igemm path (same products, another summation order: 2e-6), square and non-square grids, every epilogue form.
+    Reference ops: resnet.py:493,514 (the 3x3 convolutions of ResnetBlock2D at the 64 .. 256 pixel levels of DDPM-CELEBA-HQ-256)."""
+    from baddiffusion_amd import ops
+    g = torch.Generator().manual_seed(B * 1000 + H + W)
+    x = torch.randn(B, H, W, Cin, generator=g).cuda(); dy = torch.randn(B, H, W, Cout, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).cuda(); bias = torch.randn(Cout, generator=g).cuda()
+    rb = torch.randn(B, Cout, generator=g).cuda(); res = torch.randn(B, H, W, Cout, generator=g).cuda()
+    ws, xs, dys, wts = ops.split_bf16(w), ops.split_rows(x), ops.split_rows(dy), ops.split_wT(w)
+    for kw in (dict(), dict(rowbias=rb), dict(residual=res, out_scale=0.7)):
+        new = ops.conv3x3_ps(xs, ws, B, H, W, Cin, Cout, 1, bias=bias, **kw)
+        assert relerr(new, ops.conv3x3_fwd(x, w, bias, mode=0, **kw)) < 1e-4, sorted(kw)
+        assert relerr(new, ops.conv3x3_fwd(x, w, bias, mode=1, **kw)) < 2e-6, sorted(kw)
+    newd = ops.conv3x3_ps(dys, wts, B, H, W, Cout, Cin, -1)
+    assert relerr(newd, ops.conv3x3_dgrad(dy, w, (B, H, W, Cin), mode=0)) < 1e-4
+    acc = ops.conv3x3_ps(dys, wts, B, H, W, Cout, Cin, -1, out=newd.clone(), accumulate=True)
+    assert relerr(acc, 2 * newd) < 1e-6
+    dw, db = ops.conv3x3_ps_wgrad(xs, dys, B, H, W, Cin, Cout, with_db=True)
+    dw_ref, db_ref = ops.conv3x3_wgrad(x, dy, mode=0, with_db=True)
+    assert relerr(dw, dw_ref) < 1e-4 and relerr(db, db_ref) < 1e-4
+    assert torch.equal(dw, ops.conv3x3_ps_wgrad(xs, dys, B, H, W, Cin, Cout))          # fixed-order K split: run-to-run identical
+    # per-tap check of the weight gradient (a wrong vertical neighbour would hide in a relative norm less well than here)
+    for t in range(9):
+        assert relerr(dw[:, t // 3, t % 3], dw_ref[:, t // 3, t % 3]) < 2e-4, t
