@@ -159,7 +159,10 @@ __global__ __launch_bounds__(256) void gn_fwd_finalize_kernel(const double* __re
 }
 
 // ---- forward apply: y = silu?((x - mean) * rstd * gamma + beta); grid = (pixel ranges, B), block = (C/4) x r threads:
-// a thread keeps its four channels' constants in registers and walks its pixel rows four at a time
+// a thread keeps its four channels' constants in registers and walks its pixel rows four at a time.
+// (Round 4, measured and dropped: folding the finalize launch into this kernel -- every thread deriving its group's statistics from the S
+// partials -- costs +1.1 ms per 256 x 256 step: a few hundred dependent L2 reads in front of every ~5 us block; visiting the blocks in
+// reverse order to meet the Infinity Cache's most recent lines: neutral.)
 __global__ void gn_apply_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y, long long ldy, int HW, int C,
                                 int G, int r, int per, const float* __restrict__ gamma, const float* __restrict__ beta,
                                 const float* __restrict__ mean, const float* __restrict__ rstd, int silu,
@@ -333,7 +336,8 @@ __global__ __launch_bounds__(1024) void gn_bwd_param_batched_kernel(GnParamTable
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, int HW, int C, int G, int S,
                                                             const float* __restrict__ gamma, const float* __restrict__ rstd,
                                                             float inv_n, float* __restrict__ ds /* [B][G][2] */,
-                                                            float* __restrict__ dx_colsum, long long ld_colsum) {
+                                                            float* __restrict__ dx_colsum, long long ld_colsum,
+                                                            float* __restrict__ ppart /* optional [B][2][C]: per-sample dgamma / dbeta partials */) {
     __shared__ float sg[8][2];
     const int b = blockIdx.x, g0 = blockIdx.y * 8;
     const int cpg = C / G;
@@ -353,6 +357,25 @@ __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __res
         ds[((long long)b * G + g) * 2 + 1] = (float)e;
     }
     __syncthreads();
+    if (ppart) {
+        // per-sample weight / bias gradient partials of this block's channels (fp64 over the S splits, fixed order): the batch
+        // sum is left to ONE bd_gn_bwd_params launch per backward segment instead of a launch per layer (round 4: large-image path too)
+        int ng = G - g0;
+        if (ng > 8) ng = 8;
+        const int nch = ng * cpg, items = 2 * nch;
+        int tpc = 1;                      // threads per (plane, channel): a power of two of contiguous lanes, splits strided, butterfly fold
+        while (tpc < 32 && tpc * 2 * items <= 256) tpc *= 2;
+        const int sub = threadIdx.x % tpc;
+        for (int base = 0; base < items; base += 256 / tpc) {      // block-uniform trip count: every lane reaches the shuffles
+            const int i = base + threadIdx.x / tpc;
+            const int plane = i < nch ? 0 : 1, c = g0 * cpg + (i < nch ? i : i - nch);
+            double s = 0.0;
+            if (i < items)
+                for (int sp = sub; sp < S; sp += tpc) s += (double)part[((long long)b * S + sp) * 3 * C + plane * C + c];
+            for (int off = 1; off < tpc; off <<= 1) s += __shfl_xor(s, off);
+            if (i < items && sub == 0) ppart[((long long)b * 2 + plane) * C + c] = (float)s;
+        }
+    }
     if (dx_colsum) {
         // channels of this block's groups; tpc threads per channel (a power of two, contiguous lanes), splits strided
         int ng = G - g0;
@@ -861,8 +884,10 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
 }
 
 extern "C" int bd_gn_bwd_defers(int B, int HW, int C, int G) {
+    // round 4: both the resident and the large-image path leave per-sample partials to the caller
+    static const bool split_too = !(getenv("BD_GN_DEFER_SPLIT") && atoi(getenv("BD_GN_DEFER_SPLIT")) == 0);      // (A/B knob)
     GnRes rp;
-    return B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && (C & 3) == 0 && gn_resident_plan(B, HW, C, G, rp, true) ? 1 : 0;
+    return B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && (C & 3) == 0 && (split_too || gn_resident_plan(B, HW, C, G, rp, true)) ? 1 : 0;
 }
 
 extern "C" int bd_gn_bwd_params(const bd_gn_param_item* items, int n, int B, bd_stream_t stream) {
@@ -931,14 +956,16 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
                        (long long)d->ldx, d->dy, (long long)d->lddy, d->HW, d->C, d->G, r, S_, d->gamma, d->beta, d->mean,
                        d->rstd, d->silu, part);
     BD_LAUNCH_CHECK("gn_bwd_stats");
-    hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(1024), 0, S(stream), part, d->B * S_, 3 * d->C,
-                       d->C, d->dgamma, d->dbeta);
-    BD_LAUNCH_CHECK("gn_bwd_param");
+    if (!d->param_partials) {
+        hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(1024), 0, S(stream), part, d->B * S_, 3 * d->C,
+                           d->C, d->dgamma, d->dbeta);
+        BD_LAUNCH_CHECK("gn_bwd_param");
+    }
     {
         const int per = gn_apply_rows(d->HW, r);
         const float inv_n = 1.0f / ((float)d->HW * (d->C / d->G));
         hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(d->B, (unsigned)cdiv(d->G, 8)), dim3(256), 0, S(stream), part, d->HW, d->C, d->G,
-                           S_, d->gamma, d->rstd, inv_n, ds, d->dx_colsum, (long long)d->ld_colsum);
+                           S_, d->gamma, d->rstd, inv_n, ds, d->dx_colsum, (long long)d->ld_colsum, d->param_partials);
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)cdiv(d->HW, per), d->B), dim3(threads), 0, S(stream), d->x,
                            (long long)d->ldx, d->dy, (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, r, per, ds,
                            d->gamma, d->beta, d->mean, d->rstd, inv_n, d->silu, d->accumulate_dx, d->dx_split,

@@ -170,7 +170,8 @@ typedef struct {
                                                launch (51 GroupNorms per CIFAR backward, one launch per segment)      */
 } bd_gn_bwd_desc;
 int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream);
-/* 1 if this shape takes the single-pass kernel that can leave its parameter partials to the caller, else 0 */
+/* 1 if this shape can leave its parameter partials to the caller (round 4: every valid shape -- the single-pass kernels write them
+ * directly, the large-image path from its group-finalize launch), else 0 */
 int bd_gn_bwd_defers(int B, int HW, int C, int G);
 typedef struct {
     const float* partials;                  /* [B][2][C] as written through bd_gn_bwd_desc.param_partials */

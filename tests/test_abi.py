@@ -81,7 +81,7 @@ def test_round2_entry_points_reject_bad_arguments_without_gpu():
     assert lib.bd_ssim(None, None, 1, 3, 32, 32, 0, 0, 0, 0, 1.0, None, None, 0, None) < 0 and b"bd_ssim" in lib.bd_last_error()
     assert lib.bd_ssim_workspace_bytes(2, 3, 32, 32) == 2 * 3 * 8 and lib.bd_ssim_workspace_bytes(2, 3, 75, 44) == 2 * 3 * 3 * 2 * 8
     assert lib.bd_gn_bwd_params(None, 0, 4, None) < 0 and b"bd_gn_bwd_params" in lib.bd_last_error()
-    assert lib.bd_gn_bwd_defers(128, 1024, 128, 32) == 1 and lib.bd_gn_bwd_defers(4, 65536, 128, 32) == 0
+    assert lib.bd_gn_bwd_defers(128, 1024, 128, 32) == 1 and lib.bd_gn_bwd_defers(4, 65536, 128, 32) == 1
     assert lib.bd_gn_bwd_defers(4, 64, 130, 32) == 0                      # C not divisible by G
     assert lib.bd_conv3x3_ps(None, None) < 0 and lib.bd_conv3x3_ps_wgrad(None, None) < 0
     # round 3: phase-decomposed convolutions, deferred join, probe

@@ -557,7 +557,7 @@ def test_gn_bwd_deferred_param_fold_equals_per_layer(gpu):
     torch.cuda.synchronize()
     for dg0, db0, dg1, db1 in want:
         assert torch.equal(dg0, dg1) and torch.equal(db0, db1)
-    assert lib.bd_gn_bwd_defers(4, 65536, 128, 32) == 0                  # large images take the split path: no deferral
+    assert lib.bd_gn_bwd_defers(4, 65536, 128, 32) == 1                  # round 4: the large-image (split) path defers too
 
 
 def test_gn_bwd_dx_add_equals_separate_add(gpu):

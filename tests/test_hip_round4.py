@@ -280,3 +280,47 @@ def test_conv_ps_wide_images_virtual_pixel_order(gpu, B, H, W, Cin, Cout):
     # per-tap check of the weight gradient (a wrong vertical neighbour would hide in a relative norm less well than here)
     for t in range(9):
         assert relerr(dw[:, t // 3, t % 3], dw_ref[:, t // 3, t % 3]) < 2e-4, t
+
+
+def test_groupnorm_large_image_path_round4(gpu):
+    """Round 4, the GroupNorm kernels of the 256 x 256 network (grids that do not fit the single-pass form): the backward can leave
+    per-sample (dgamma, dbeta) partials -- written by its group-finalize launch -- to ONE bd_gn_bwd_params launch per backward segment
+    (1e-6 against the per-layer reduction, dx bit-identical).  Forward, statistics and dx against fp64 torch group_norm + silu
+    (resnet.py:559,591): 1e-5."""
+    import ctypes as CT
+    import torch.nn.functional as F
+    from baddiffusion_amd import _lib as L, ops
+    lib = L.load()
+    torch.manual_seed(9)
+    G = 32
+    for (B, HW, Cc) in [(2, 16384, 128), (1, 65536, 64), (3, 4096, 256)]:
+        x = torch.randn(B, HW, Cc, device=gpu) * 2 + 0.5; dy = torch.randn(B, HW, Cc, device=gpu)
+        ga = torch.randn(Cc, device=gpu); be = torch.randn(Cc, device=gpu)
+        st = torch.empty(2, B, G, device=gpu)
+        ws = ops.workspace(lib.bd_gn_workspace_bytes(B, Cc), x.device)
+        y = torch.empty_like(x)
+        f = L.GnFwdDesc(B=B, HW=HW, C=Cc, G=G, eps=1e-6, silu=1, x=L.ptr(x), ldx=Cc, gamma=L.ptr(ga), beta=L.ptr(be), y=L.ptr(y), ldy=Cc,
+                        mean=L.ptr(st[0]), rstd=L.ptr(st[1]), workspace=L.ptr(ws), workspace_bytes=ws.numel())
+        L.check(lib.bd_gn_fwd(CT.byref(f), L.stream()))
+        x64 = x.double().cpu().permute(0, 2, 1).reshape(B, Cc, HW, 1).requires_grad_(True)
+        y64 = F.silu(F.group_norm(x64, G, ga.double().cpu(), be.double().cpu(), 1e-6))
+        assert relerr(y, y64.reshape(B, Cc, HW).permute(0, 2, 1)) < 1e-5
+        xg = x64.detach().reshape(B, G, -1)
+        assert relerr(st[0], xg.mean(-1)) < 1e-5 and relerr(st[1], 1 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-6)) < 1e-5
+        y64.backward(dy.double().cpu().permute(0, 2, 1).reshape(B, Cc, HW, 1))
+        outs = []
+        for deferred in (False, True):
+            dx = torch.empty_like(x); dg = torch.full((Cc,), float("nan"), device=gpu); db = torch.full((Cc,), float("nan"), device=gpu)
+            part = torch.empty(B, 2, Cc, device=gpu)
+            d = L.GnBwdDesc(B=B, HW=HW, C=Cc, G=G, silu=1, x=L.ptr(x), ldx=Cc, gamma=L.ptr(ga), beta=L.ptr(be), mean=L.ptr(st[0]),
+                            rstd=L.ptr(st[1]), dy=L.ptr(dy), lddy=Cc, dx=L.ptr(dx), lddx=Cc, accumulate_dx=0, dgamma=L.ptr(dg),
+                            dbeta=L.ptr(db), workspace=L.ptr(ws), workspace_bytes=ws.numel(), param_partials=L.ptr(part) if deferred else None)
+            L.check(lib.bd_gn_bwd(CT.byref(d), L.stream()))
+            outs.append((dx, dg, db, part))
+        (dx0, dg0, db0, _), (dx1, dg1, db1, part1) = outs
+        assert torch.equal(dx0, dx1) and relerr(dx0, x64.grad.reshape(B, Cc, HW).permute(0, 2, 1)) < 1e-5
+        assert torch.isnan(dg1).all() and torch.isnan(db1).all()
+        items = (L.GnParamItem * 1)()
+        items[0].partials = L.ptr(part1); items[0].C = Cc; items[0].dgamma = L.ptr(dg1); items[0].dbeta = L.ptr(db1)
+        L.check(lib.bd_gn_bwd_params(items, 1, B, L.stream()))
+        assert relerr(dg1, dg0) < 1e-6 and relerr(db1, db0) < 1e-6
