@@ -142,6 +142,13 @@ def celeba_full_inputs():
     return x, torch.tensor([417]), dout
 
 
+def celeba_b4_inputs():
+    """(x, t, dout) for the real 256x256 network at BASELINE configs[3]'s per-GPU batch of 4 (distinct timesteps per sample)"""
+    x = torch.randn(4, 3, 256, 256, generator=torch.Generator().manual_seed(13))
+    dout = torch.randn(4, 3, 256, 256, generator=torch.Generator().manual_seed(14)) / 4
+    return x, torch.tensor([417, 12, 988, 500]), dout
+
+
 def pipeline_init(cfg, n=2):
     return torch.randn(n, 3, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(0))
 

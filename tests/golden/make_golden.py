@@ -20,6 +20,8 @@ Fixtures:
                     full-size GPU tests compare with the reference and not with the product's other arithmetic mode
   attn_planes.npz G11 AttentionBlock forward + backward at 16 x 16 (256 tokens, head dim 256; one and two heads): the shapes the
                     split-plane attention path takes (modules.npz has 8 x 8 / 4 x 4 blocks, which stay on the unfused path)
+  full_size_b4.npz G12 the same 256x256 network at B = 4, the per-GPU batch of BASELINE configs[3] (four timesteps, per-sample output
+                    slices + checksums, every gradient tensor's norm + leading elements)
   pndm.npz      G9  PNDMScheduler timesteps + full chains with a stand-in model, the scheduler every `--sched` other than
                     DDPM / DDIM ends up as (pipeline_pndm.py:46 converts whatever it is given), PNDMPipeline images
 """
@@ -374,7 +376,29 @@ def g10():
     save("full_size.npz", **out)
 
 
+# ---- G12: the 256 x 256 network at the per-GPU batch of BASELINE configs[3] (B = 4) -------------------------------------------------
+def g12():
+    import time
+    from tests.golden.cases import celeba_b4_inputs
+    t0 = time.time()
+    cfg = U.CELEBA_HQ_256
+    m = ref_unet(cfg, U.gen_params(cfg, 5)); m.train()
+    x, t, dout = celeba_b4_inputs()
+    y = m(x, t, return_dict=False)[0]
+    y.backward(dout)
+    out = {}
+    out["celeba256b4_out_slices"] = y.detach()[:, :, ::16, ::16]
+    out["celeba256b4_out_sum"] = y.detach().double().sum(dim=(1, 2, 3))
+    out["celeba256b4_out_sumsq"] = (y.detach().double() ** 2).sum(dim=(1, 2, 3))
+    out["celeba256b4_names"] = np.array([k for k, _ in m.named_parameters()])
+    out["celeba256b4_gradnorms"] = torch.stack([p.grad.double().norm().float() for _, p in m.named_parameters()])
+    out["celeba256b4_grad8"] = torch.stack([torch.nn.functional.pad(p.grad.flatten()[:8], (0, max(0, 8 - p.numel())))
+                                            for _, p in m.named_parameters()])
+    print(f"celeba256 B=4 {time.time() - t0:.1f}s")
+    save("full_size_b4.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
     for w in which:
         globals()[w]()

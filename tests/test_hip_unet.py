@@ -222,6 +222,28 @@ def test_celeba_full_resolution_vs_reference(bd, golden, mode):
     _golden_grad_check(m, g, tag)
 
 
+@pytest.mark.parametrize("mode", ["f32", "bf16x3"])
+def test_celeba_batch4_vs_reference(bd, golden, mode):
+    """BASELINE configs[3]'s per-GPU share at its real size: the 256x256 DDPM-CELEBA-HQ-256 network at B = 4 (four different
+    timesteps), forward + backward against what the imported reference computed for this batch (G12, make_golden.py g12 ->
+    full_size_b4.npz; unet_2d.py:229-326): per-sample output slices + checksums, every gradient tensor's norm + leading elements.
+    At this batch the wide layers take the strip-order kernels (conv_ps3 / wgrad3 at W = 64 .. 256) and the large-image GroupNorm path."""
+    unet, ops = bd
+    g = golden("full_size_b4"); tag = "celeba256b4"
+    cfg = U.CELEBA_HQ_256
+    m = make_model(unet, cfg, 5).set_compute_mode(mode)
+    x, t, dout = C.celeba_b4_inputs()
+    out = m(x.cuda(), t.cuda(), return_dict=False)[0]
+    od = out.detach()
+    assert relerr(od[:, :, ::16, ::16], g[f"{tag}_out_slices"]) < 1e-4
+    for i in range(4):
+        sq = float(g[f"{tag}_out_sumsq"][i])
+        assert abs(float((od[i].double() ** 2).sum()) - sq) < 1e-4 * sq, i
+        assert abs(float(od[i].double().sum()) - float(g[f"{tag}_out_sum"][i])) < 1e-3 * float(np.sqrt(sq * od[i].numel())), i
+    out.backward(dout.cuda())
+    _golden_grad_check(m, g, tag)
+
+
 def test_cifar_full_batch_modes_and_schedules_agree(bd):
     """BASELINE configs[1] at its full size (DDPM-CIFAR10-32, batch 128): the oracle would need a minute, so the check
     is self-consistency across the independent code paths -- split-bf16 vs exact-fp32 contraction, two-stream vs

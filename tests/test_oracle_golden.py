@@ -354,6 +354,14 @@ def test_oracle_matches_full_size_reference_vectors(golden):
     ref = torch.from_numpy(g["celeba256_out_slices"])
     assert float((out[0, :, ::16, ::16] - ref).norm() / ref.norm()) < 1e-5
     assert abs(float((out.double() ** 2).sum()) - float(g["celeba256_out_sumsq"])) < 1e-5 * float(g["celeba256_out_sumsq"])
+    # G12: one sample of the B = 4 batch (samples are independent through the network)
+    g4 = golden("full_size_b4")
+    x4, t4, _ = C.celeba_b4_inputs()
+    with torch.no_grad():
+        out = U.unet_forward(cfg, U.gen_params(cfg, 5), x4[2:3], t4[2:3])
+    ref = torch.from_numpy(g4["celeba256b4_out_slices"][2])
+    assert float((out[0, :, ::16, ::16] - ref).norm() / ref.norm()) < 1e-5
+    assert abs(float((out.double() ** 2).sum()) - float(g4["celeba256b4_out_sumsq"][2])) < 1e-5 * float(g4["celeba256b4_out_sumsq"][2])
 
 
 def test_pndm_oracle_matches_reference_chains(golden):
