@@ -104,18 +104,34 @@ def merge_ranges(ranges):
     return out
 
 
-def plan_buckets(seg_ranges, bucket_bytes):
+def plan_buckets(seg_ranges, bucket_bytes, tail_bytes=8 << 20):
     """Group the backward segments (in the order they finish) into communication buckets: a bucket closes with the first segment
-    that brings it to `bucket_bytes` (the last one takes the rest).  Returns [(last segment index, [merged ranges])].
-    bucket_bytes <= 0: one bucket per segment."""
-    buckets, cur, size = [], [], 0
-    for s, rs in enumerate(seg_ranges):
-        cur += rs
-        size += sum(hi - lo for lo, hi in rs) * 4
-        if bucket_bytes <= 0 or size >= bucket_bytes or s == len(seg_ranges) - 1:
-            buckets.append((s, merge_ranges(cur)))
+    that brings it to `bucket_bytes`.  The LAST bucket is the only collective nothing can hide (it is issued behind the last
+    data-gradient kernel), so it holds just the trailing segments that fit `tail_bytes`; a short remainder in front of it joins the
+    bucket before.  Returns [(last segment index, [merged ranges])].  bucket_bytes <= 0: one bucket per segment."""
+    sizes = [sum(hi - lo for lo, hi in rs) * 4 for rs in seg_ranges]
+    n = len(seg_ranges)
+    if bucket_bytes <= 0:
+        return [(s, merge_ranges(rs)) for s, rs in enumerate(seg_ranges)]
+    tail, acc = n, 0
+    while tail > 1 and acc + sizes[tail - 1] <= tail_bytes:
+        tail -= 1
+        acc += sizes[tail]
+    groups, cur, size = [], [], 0
+    for s in range(tail):
+        cur.append(s)
+        size += sizes[s]
+        if size >= bucket_bytes:
+            groups.append(cur)
             cur, size = [], 0
-    return buckets
+    if cur:
+        if groups and size < bucket_bytes // 2:
+            groups[-1] += cur
+        else:
+            groups.append(cur)
+    if tail < n:
+        groups.append(list(range(tail, n)))
+    return [(g[-1], merge_ranges([r for s in g for r in seg_ranges[s]])) for g in groups]
 
 
 def plan_segment_ranges(model):

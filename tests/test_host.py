@@ -307,3 +307,30 @@ def test_fid_inception_manifest():
     with pytest.raises(RuntimeError, match="GPU only"):
         P.FIDInceptionV3(device="cpu")
     assert P.load_fid_weights("/nonexistent/pt_inception.pth") is None
+
+
+def test_dp_communication_buckets_cover_every_gradient_range():
+    """trainer.plan_buckets: backward segments fused into communication buckets.  Every range a segment finalises lies inside a range of
+    the bucket that closes at or after that segment (never before: the collective must not precede its producer), bucket ranges are
+    disjoint, the fused gaps are alignment pads only, and the last bucket -- the one collective nothing overlaps -- is small."""
+    from baddiffusion_amd.model import KNOWN_TOPOLOGIES
+    from baddiffusion_amd.trainer import merge_ranges, plan_buckets, plan_segment_ranges
+    from baddiffusion_amd.unet import UNet2DModel
+    assert merge_ranges([(10, 20), (0, 10), (30, 40), (38, 50), (200, 300)]) == [(0, 50), (200, 300)]
+    for name in ("google/ddpm-cifar10-32", "google/ddpm-ema-celebahq-256"):
+        m = UNet2DModel(**KNOWN_TOPOLOGIES[name])
+        sr = plan_segment_ranges(m)
+        seg_elems = sum(hi - lo for rs in sr for lo, hi in rs)
+        for mb in (0, 16, 32, 1e6):
+            b = plan_buckets(sr, int(mb * 2 ** 20))
+            closes = [s for s, _ in b]
+            assert closes == sorted(closes) and closes[-1] == len(sr) - 1
+            flat = sorted(r for _, rs in b for r in rs)
+            assert all(a[1] <= c[0] for a, c in zip(flat, flat[1:]))                       # disjoint
+            assert 0 <= sum(hi - lo for lo, hi in flat) - seg_elems < 64 * len(flat) * 4     # fused gaps = pads
+            for s, rs in enumerate(sr):
+                owner = next(i for i, c in enumerate(closes) if c >= s)
+                for lo, hi in rs:
+                    assert any(blo <= lo and hi <= bhi for blo, bhi in b[owner][1]), (name, mb, s, lo, hi)
+            if mb == 32:
+                assert sum(hi - lo for lo, hi in b[-1][1]) * 4 <= 8 << 20 and len(b) <= 8
