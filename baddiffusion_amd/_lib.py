@@ -53,7 +53,7 @@ class GnBwdDesc(C.Structure):
                 ("dy", vp), ("lddy", i64), ("dx", vp), ("lddx", i64), ("accumulate_dx", i32),
                 ("dgamma", vp), ("dbeta", vp), ("workspace", vp), ("workspace_bytes", sz),
                 ("dx_colsum", vp), ("ld_colsum", i64), ("dx_split", vp), ("lddxs", i64),
-                ("dx_add", vp), ("ld_add", i64), ("param_partials", vp)]
+                ("dx_add", vp), ("ld_add", i64), ("param_partials", vp), ("dx_split_c0", i32), ("dx_split_c1", i32)]
 
 
 class GnParamItem(C.Structure):

@@ -410,7 +410,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, long long ldx, 
                                     const float* __restrict__ beta, const float* __restrict__ mean,
                                     const float* __restrict__ rstd, float inv_n, int silu, int acc,
                                     unsigned short* __restrict__ dxs, long long lddxs, const float* __restrict__ addp,
-                                    long long ldadd) {
+                                    long long ldadd, int dxs_c0, int dxs_c1) {
     const int q = C / 4, cpg = C / G;
     const int t = threadIdx.x;
     const int cq = t % q, prow = t / q;
@@ -460,9 +460,9 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, long long ldx, 
             const int pu = p + u * r;
             if (pu < p1) {
                 if (dx) *reinterpret_cast<float4*>(ob + (long long)pu * lddx) = v[u];
-                if (dxs) {
+                if (dxs && cq * 4 >= dxs_c0 && cq * 4 < dxs_c1) {
                     const float o[4] = {v[u].x, v[u].y, v[u].z, v[u].w};
-                    gn_store_split4(dxs + 2 * ((long long)b * HW + pu) * lddxs, cq * 4, o);
+                    gn_store_split4(dxs + 2 * ((long long)b * HW + pu) * lddxs, cq * 4 - dxs_c0, o);
                 }
             }
         }
@@ -658,7 +658,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_res_kernel(const float* __restrict_
                                                        int silu, int acc, float* __restrict__ part,
                                                        float* __restrict__ dx_colsum, long long ld_colsum,
                                                        unsigned short* __restrict__ dxs, long long lddxs,
-                                                       const float* __restrict__ addp, long long ldadd) {
+                                                       const float* __restrict__ addp, long long ldadd, int dxs_c0, int dxs_c1) {
     __shared__ float sh[3 * 4 * NT];   // [R][cb][3]: sum dz, sum dz*xhat, sum xhat
     __shared__ float ch[3 * 4 * NT];   // [cb][3] channel totals (cb <= 4*NT)
     __shared__ float sg[2 * 256];    // per group: s1, s2
@@ -809,9 +809,9 @@ __global__ __launch_bounds__(NT) void gn_bwd_res_kernel(const float* __restrict_
         const int p = prow + R * i;
         if (i < E && p < HW) {
             if (dx) *reinterpret_cast<float4*>(ob + (long long)p * lddx) = dz[i];
-            if (dxs) {
+            if (dxs && c0 + cq * 4 >= dxs_c0 && c0 + cq * 4 < dxs_c1) {      // planes of the FINAL value, channels [dxs_c0, dxs_c1) only
                 const float o[4] = {dz[i].x, dz[i].y, dz[i].z, dz[i].w};
-                gn_store_split4(dxs + 2 * ((long long)b * HW + p) * lddxs, c0 + cq * 4, o);
+                gn_store_split4(dxs + 2 * ((long long)b * HW + p) * lddxs, c0 + cq * 4 - dxs_c0, o);
             }
         }
     }
@@ -916,6 +916,9 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
              BD_ERR_INVALID, "bd_gn_bwd: null pointer");
     BD_CHECK(!d->dx_split || (d->C % 32 == 0 && d->lddxs % 32 == 0 && ((uintptr_t)d->dx_split & 127) == 0), BD_ERR_UNSUPPORTED,
              "bd_gn_bwd: dx_split needs C %% 32 == 0, lddxs %% 32 == 0 and a 128-byte aligned base");
+    const int xs0 = d->dx_split_c1 > d->dx_split_c0 ? d->dx_split_c0 : 0, xs1 = d->dx_split_c1 > d->dx_split_c0 ? d->dx_split_c1 : d->C;
+    BD_CHECK(!d->dx_split || (xs0 >= 0 && xs1 <= d->C && xs0 % 32 == 0 && xs1 % 32 == 0 && d->lddxs >= xs1 - xs0), BD_ERR_INVALID,
+             "bd_gn_bwd: dx_split channel range [%d, %d) must be whole 32-channel blocks inside C = %d with lddxs >= its width", xs0, xs1, d->C);
     BD_CHECK(d->dx || !d->accumulate_dx, BD_ERR_INVALID, "bd_gn_bwd: accumulate_dx needs dx");
     BD_CHECK((d->lddy & 3) == 0 && (d->lddx & 3) == 0 && aligned16(d->dy) && aligned16(d->dx) && aligned16(d->gamma) &&
                  aligned16(d->beta), BD_ERR_UNSUPPORTED, "bd_gn_bwd: pointers must be 16B aligned, ld multiples of 4");
@@ -931,7 +934,7 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
     hipLaunchKernelGGL((gn_bwd_res_kernel<EM, NT>), grid, dim3(NT), 0, S(stream), d->x, (long long)d->ldx, d->dy,            \
                        (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->gamma,     \
                        d->beta, d->mean, d->rstd, d->silu, d->accumulate_dx, part_r, d->dx_colsum, (long long)d->ld_colsum, \
-                       d->dx_split, (long long)d->lddxs, d->dx_add, (long long)d->ld_add)
+                       d->dx_split, (long long)d->lddxs, d->dx_add, (long long)d->ld_add, xs0, xs1)
         if (rp.nt == 512 && rp.E <= 8) BD_GN_BWD_RES(8, 512);
         else if (rp.nt == 512) BD_GN_BWD_RES(GN_RES_EMAX, 512);
         else if (rp.E <= 4) BD_GN_BWD_RES(4, 256);
@@ -969,7 +972,7 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)cdiv(d->HW, per), d->B), dim3(threads), 0, S(stream), d->x,
                            (long long)d->ldx, d->dy, (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, r, per, ds,
                            d->gamma, d->beta, d->mean, d->rstd, inv_n, d->silu, d->accumulate_dx, d->dx_split,
-                           (long long)d->lddxs, d->dx_add, (long long)d->ld_add);
+                           (long long)d->lddxs, d->dx_add, (long long)d->ld_add, xs0, xs1);
     }
     BD_LAUNCH_CHECK("gn_bwd_apply");
     return BD_OK;

@@ -147,6 +147,39 @@ struct bd_unet {
     int64_t p_tw = 0, p_tb = 0;  // offsets of the batched time_emb_proj weight / bias
     int b_tproj = -1, b_dtproj = -1, b_embs = -1;
     std::vector<long long> wt_off; std::vector<int> wt_cin, wt_cout;   // 3x3 conv weights with a transposed split copy
+    // Round 4: a tensor's gradient handed over READY-SPLIT.  The producer of tensor T (a resnet / attention / down- / upsample node whose
+    // backward starts by turning dL/dT into split planes) registers T; the FIRST node that consumes T in forward order is the LAST one to add
+    // to dL/dT in backward, and if that node ends with a GroupNorm backward (resnet norm1, attention group_norm, conv_norm_out) the kernel
+    // writes the planes of the final value next to the fp32 store (bd_gn_bwd_desc.dx_split + channel range): the producer's bd_split_rows
+    // launch and its 4 B / element read disappear.  Consumers that end otherwise (down- / upsample data gradients) leave the fallback.
+    struct GSplit { int buf, coff, C, H, W; int b_pl; std::function<bool(const Ctx&)> want; bool claimed = false, emitted = false; };
+    std::vector<GSplit> gsplits;
+    int reg_gsplit(const View& y, std::function<bool(const Ctx&)> want) {
+        static const bool off = getenv("BD_GSPLIT") && atoi(getenv("BD_GSPLIT")) == 0;      // (A/B knob)
+        if (off || y.buf < 0 || y.C % 32 != 0) return -1;
+        GSplit e; e.buf = y.buf; e.coff = y.coff; e.C = y.C; e.H = y.H; e.W = y.W; e.want = std::move(want);
+        const int keep = cur_group;
+        e.b_pl = new_buf((int64_t)y.H * y.W * y.C, 0, R_GRAD);
+        cur_group = keep;
+        gsplits.push_back(std::move(e));
+        const int idx = (int)gsplits.size() - 1;
+        bufs[gsplits[idx].b_pl].live = [this, idx](int B, int training) {
+            Ctx q; q.dry = true; q.B = q.LB = B;
+            return training && gsplits[idx].emitted && gsplits[idx].want(q);
+        };
+        return idx;
+    }
+    // called by every node for its input view, in forward order: the first consumer of a registered tensor; `emits`: it can write the planes
+    int claim_gsplit(const View& x, bool emits) {
+        int got = -1;
+        for (int i = 0; i < (int)gsplits.size(); ++i) {
+            GSplit& e = gsplits[i];
+            if (e.claimed || e.buf != x.buf || e.coff < x.coff || e.coff + e.C > x.coff + x.C) continue;
+            e.claimed = true;
+            if (emits && got < 0) { e.emitted = true; got = i; }      // (one range per consumer launch)
+        }
+        return got;
+    }
     struct UpsW { int64_t pw; int C, H, W; int b_e, b_et; };           // upsample convolutions on the phase path: E (/ E^T when training) planes
     // weight preprocessing (split copy, E planes) is skipped while the caller promises constant weights (bd_unet_set_static_weights):
     // a sampling loop runs 50-1000 forwards over the same parameters
@@ -319,9 +352,13 @@ struct bd_unet {
         return bd_gn_fwd(&d, (bd_stream_t)c.st);
     }
     int gn_bwd(Ctx& c, const View& x, int64_t pg, int64_t pb, int stats_buf, const float* dy, int64_t lddy, int silu,
-               const float* dx_add = nullptr, int64_t ld_add = 0) {
+               const float* dx_add = nullptr, int64_t ld_add = 0, int gs = -1) {
         bd_gn_bwd_desc d = {};
         d.dx_add = dx_add; d.ld_add = ld_add;
+        if (gs >= 0 && gsplits[gs].want(c)) {      // this launch makes dL/dx final: hand its producer the planes of its channel range
+            const GSplit& e = gsplits[gs];
+            d.dx_split = U16(BP(c, e.b_pl)); d.lddxs = e.C; d.dx_split_c0 = e.coff - x.coff; d.dx_split_c1 = d.dx_split_c0 + e.C;
+        }
         d.B = c.B; d.HW = x.H * x.W; d.C = x.C; d.G = cfg.norm_num_groups; d.silu = silu;
         d.x = VP(c, x); d.ldx = x.ld; d.gamma = c.params + pg; d.beta = c.params + pb;
         d.mean = MEANP(c, stats_buf, d.G); d.rstd = RSTDP(c, stats_buf, d.G);
@@ -528,6 +565,10 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
     const int b_dyS = scratch((int64_t)HW * Cout), b_dh1S = scratch((int64_t)HW * Cout);
     const float inv = 1.f / scale;
     const int sumC_ = sumC;
+    // dL/dx becomes final in this node's norm1 backward (first consumer of x in forward order); dL/dy arrives ready-split when y's first
+    // consumer can do the same for us (GSplit)
+    const int gs_in = claim_gsplit(x, true);
+    const int gs_out = b_dys < 0 ? reg_gsplit(y, [this, H, W, Cout](const Ctx& c) { return ps_ok(c, H, W, Cout, Cout); }) : -1;
 
     F([=](Ctx& c) {
         const bool ps1 = ps_ok(c, H, W, Cin, Cout), ps2 = ps_ok(c, H, W, Cout, Cout);
@@ -596,15 +637,17 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
         }
         const bool ps1 = ps_ok(c, H, W, Cin, Cout), ps2 = ps_ok(c, H, W, Cout, Cout);
         if (ps2) {
-            BD_TRY(split_rows(c, dy, lddy, M, Cout, BP(c, b_dyS)));
+            const bool ready = gs_out >= 0 && gsplits[gs_out].emitted;      // y's consumer left the planes of dL/dy (run-time: set after this node was built)
+            float* dyS = ready ? BP(c, gsplits[gs_out].b_pl) : BP(c, b_dyS);
+            if (!ready) BD_TRY(split_rows(c, dy, lddy, M, Cout, dyS));
             bd_conv3x3_ps_wgrad_desc w2 = {};
             w2.B = c.B; w2.H = H; w2.W = W; w2.Cin = Cout; w2.Cout = Cout;
-            w2.x_split = U16(BP(c, b_a2s)); w2.ldx = Cout; w2.dy_split = U16(BP(c, b_dyS)); w2.lddy = Cout;
+            w2.x_split = U16(BP(c, b_a2s)); w2.ldx = Cout; w2.dy_split = U16(dyS); w2.lddy = Cout;
             w2.dw = c.grads + pc2w; w2.db = c.grads + pc2b;
             BD_TRY(conv_pw(c, w2));
             bd_conv3x3_ps_desc g2 = {};
             g2.B = c.B; g2.H = H; g2.W = W; g2.K = Cout; g2.N = Cout; g2.direction = -1;
-            g2.x_split = U16(BP(c, b_dyS)); g2.ldx = Cout; g2.w_split = c.wT_split + 2 * pc2w; g2.out_scale = 1.f;
+            g2.x_split = U16(dyS); g2.ldx = Cout; g2.w_split = c.wT_split + 2 * pc2w; g2.out_scale = 1.f;
             g2.y = BP(c, b_da2); g2.ldy = Cout;
             BD_TRY(conv_p(c, g2));
         } else {
@@ -655,13 +698,15 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             g1.dy = BP(c, b_dh1); g1.lddy = Cout; g1.w = c.params + pc1w; g1.dx = BP(c, b_da1); g1.lddx = Cin;
             BD_TRY(conv_d(c, g1));
         }
-        // norm1 backward; the identity shortcut's gradient (dy itself) is added in the same store
-        BD_TRY(gn_bwd(c, x, pn1w, pn1b, b_st1, BP(c, b_da1), Cin, 1, shortcut ? nullptr : dy, lddy));
-        if (shortcut) {   // 1x1 shortcut convolution
+        if (shortcut) {   // 1x1 shortcut convolution: its data gradient goes in FIRST, so that the norm1 backward below is the store that makes
+            // dL/dx final (and can hand x's producer the split planes of it)
             BD_TRY(linear_wgrad(c, dy, lddy, VP(c, x), x.ld, c.grads + psw, M, Cout, Cin, c.grads + psb));
-            BD_TRY(linear_dgrad(c, dy, lddy, c.params + psw, GP(c, x), x.ld, M, Cout, Cin, 1));
+            const int acc = c.ginit[x.buf];
+            c.ginit[x.buf] = 1;
+            BD_TRY(linear_dgrad(c, dy, lddy, c.params + psw, GP(c, x), x.ld, M, Cout, Cin, acc));
         }
-        return (int)BD_OK;
+        // norm1 backward; the identity shortcut's gradient (dy itself) is added in the same store
+        return gn_bwd(c, x, pn1w, pn1b, b_st1, BP(c, b_da1), Cin, 1, shortcut ? nullptr : dy, lddy, gs_in);
     });
 }
 
@@ -700,6 +745,8 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
         return cfg.compute_mode == BD_MODE_BF16X3 && (c.dry || c.w_split) && attn_sp_supported(N, dh) &&
                gemm_sp_supported((int)((int64_t)(c.LB > 0 ? c.LB : c.B) * N), C, C) && gemm_sp_supported(3 * C, C, 32);
     };
+    const int gs_in = claim_gsplit(x, true);
+    const int gs_out = b_dys < 0 ? reg_gsplit(y, [use_sp](const Ctx& c) { return use_sp(c); }) : -1;
     F([=](Ctx& c) {
         const int M = (int)rows(c, x);
         if (use_sp(c)) {
@@ -766,15 +813,17 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
             dy = BP(c, b_dys); lddy = C;
         }
         if (use_sp(c)) {
-            BD_TRY(split_rows(c, dy, lddy, M, C, BP(c, b_dyS)));
+            const bool ready = gs_out >= 0 && gsplits[gs_out].emitted;
+            float* dyS = ready ? BP(c, gsplits[gs_out].b_pl) : BP(c, b_dyS);
+            if (!ready) BD_TRY(split_rows(c, dy, lddy, M, C, dyS));
             bd_gemm_sp_desc w = {};      // dWp = dy^T o, dbp = column sums of dy  (side stream)
             w.M = C; w.N = C; w.K = M; w.batch = 1;
-            w.a = U16(BP(c, b_dyS)); w.lda = C; w.a_kmajor = 1; w.b = U16(BP(c, b_o)); w.ldb = C; w.b_kmajor = 1;
+            w.a = U16(dyS); w.lda = C; w.a_kmajor = 1; w.b = U16(BP(c, b_o)); w.ldb = C; w.b_kmajor = 1;
             w.c = c.grads + ppw; w.ldc = C; w.a_colsum = c.grads + ppb; w.alpha = 1.f; w.out_scale = 1.f;
             BD_TRY(gemm_s(c, w, true));
             bd_gemm_sp_desc g = {};      // dO = dy Wp -> planes
             g.M = M; g.N = C; g.K = C; g.batch = 1;
-            g.a = U16(BP(c, b_dyS)); g.lda = C; g.b = c.w_split + 2 * ppw; g.ldb = C; g.b_kmajor = 1;
+            g.a = U16(dyS); g.lda = C; g.b = c.w_split + 2 * ppw; g.ldb = C; g.b_kmajor = 1;
             g.c_split = U16(BP(c, b_do)); g.ldcs = C; g.alpha = 1.f; g.out_scale = 1.f;
             BD_TRY(gemm_s(c, g));
             if (!c.dry) {
@@ -794,7 +843,7 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
             dn.a = U16(BP(c, b_dqkv)); dn.lda = 3 * C; dn.b = c.w_split + 2 * pqw; dn.ldb = C; dn.b_kmajor = 1;
             dn.c = BP(c, b_dn); dn.ldc = C; dn.alpha = 1.f; dn.out_scale = 1.f;
             BD_TRY(gemm_s(c, dn));
-            return gn_bwd(c, x, pgw, pgb, b_st, BP(c, b_dn), C, 0, dy, lddy);
+            return gn_bwd(c, x, pgw, pgb, b_st, BP(c, b_dn), C, 0, dy, lddy, gs_in);
         }
         float* qkv = BP(c, b_qkv); float* dqkv = BP(c, b_dqkv); float* P = BP(c, b_p); float* dP = BP(c, b_dp);
         float* dO = BP(c, b_do);
@@ -840,7 +889,7 @@ void bd_unet::node_attention(const std::string& pre, const View& x, const View& 
         BD_TRY(linear_wgrad(c, dqkv, 3 * C, BP(c, b_n), C, c.grads + pqw, M, 3 * C, C, c.grads + pqb));
         BD_TRY(linear_dgrad(c, dqkv, 3 * C, c.params + pqw, BP(c, b_dn), C, M, 3 * C, C, 0));
         // group-norm backward; the residual connection's gradient (dy itself) is added in the same store
-        return gn_bwd(c, x, pgw, pgb, b_st, BP(c, b_dn), C, 0, dy, lddy);
+        return gn_bwd(c, x, pgw, pgb, b_st, BP(c, b_dn), C, 0, dy, lddy, gs_in);
     });
 }
 
@@ -850,6 +899,8 @@ void bd_unet::node_downsample(const std::string& pre, const View& x, const View&
     const int64_t pw = add_param(pre + "conv.weight", {C, C, 3, 3}, 1), pb = add_param(pre + "conv.bias", {C});
     if (C % 32 == 0) { wt_off.push_back(pw); wt_cin.push_back(C); wt_cout.push_back(C); }   // transposed planes for the phase data gradient
     const int b_bs = scratch(C), b_dyS = scratch((int64_t)Ho * Wo * C);
+    claim_gsplit(x, false);        // (this node's data gradient is a convolution: it cannot leave dL/dx as planes)
+    const int gs_out = reg_gsplit(y, [this, H, W, Ho, Wo, C](const Ctx& c) { return H == 2 * Ho && W == 2 * Wo && phase_ok(c, Ho, Wo, C, C); });
     F([=](Ctx& c) {
         bd_conv3x3_fwd_desc d = {};
         d.B = c.B; d.Hs = H; d.Ws = W; d.Cin = C; d.Cout = C; d.stride = 2; d.pad_t = pad; d.pad_l = pad; d.Ho = Ho; d.Wo = Wo;
@@ -867,11 +918,13 @@ void bd_unet::node_downsample(const std::string& pre, const View& x, const View&
         c.ginit[x.buf] = 1;
         if (H == 2 * Ho && W == 2 * Wo && phase_ok(c, Ho, Wo, C, C)) {
             // by the parity of the input pixel only 4 / 2 / 2 / 1 of the nine taps contribute: four classes on the output grid
-            BD_TRY(split_rows(c, dy, y.ld, (int64_t)c.B * Ho * Wo, C, BP(c, b_dyS)));
+            const bool ready = gs_out >= 0 && gsplits[gs_out].emitted;
+            float* dyS = ready ? BP(c, gsplits[gs_out].b_pl) : BP(c, b_dyS);
+            if (!ready) BD_TRY(split_rows(c, dy, y.ld, (int64_t)c.B * Ho * Wo, C, dyS));
             if (c.dry) return (int)BD_OK;
             bd_conv3x3_s2_dgrad_desc g = {};
             g.B = c.B; g.Ho = Ho; g.Wo = Wo; g.Cin = C; g.Cout = C; g.pad = pad;
-            g.dy_split = U16(BP(c, b_dyS)); g.lddy = C; g.wT_split = c.wT_split + 2 * pw;
+            g.dy_split = U16(dyS); g.lddy = C; g.wT_split = c.wT_split + 2 * pw;
             g.dx = GP(c, x); g.lddx = x.ld; g.accumulate = acc;
             return conv3x3_s2_dgrad_ps(g, c.st);
         }
@@ -895,6 +948,8 @@ void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y
     const int b_xS = new_buf((int64_t)H * W * C, 0, R_VALUE);
     const int b_e = new_buf(0, (int64_t)16 * C * C, R_VALUE), b_et = new_buf(0, (int64_t)16 * C * C, R_VALUE);
     if (C % 128 == 0) upsw.push_back({pw, C, H, W, b_e, b_et});
+    claim_gsplit(x, false);
+    const int gs_out = reg_gsplit(y, [this, H, W, C](const Ctx& c) { return phase_ok(c, H, W, C, C) || ps_ok(c, 2 * H, 2 * W, C, C); });
     {   // which of the two operand sets exists is the plan's path choice for the batch the workspace is laid out for
         auto phase_at = [=](int B) { Ctx q; q.dry = true; q.B = q.LB = B; return phase_ok(q, H, W, C, C); };
         auto ps_at = [=](int B) { Ctx q; q.dry = true; q.B = q.LB = B; return ps_ok(q, 2 * H, 2 * W, C, C); };
@@ -931,11 +986,13 @@ void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y
         const float* dy = GP(c, y);
         const int acc = c.ginit[x.buf];
         c.ginit[x.buf] = 1;
+        const bool ready = gs_out >= 0 && gsplits[gs_out].emitted;
+        float* dyS = ready ? BP(c, gsplits[gs_out].b_pl) : BP(c, b_dyS);
         if (phase_ok(c, H, W, C, C)) {
-            BD_TRY(split_rows(c, dy, y.ld, (int64_t)c.B * 4 * H * W, C, BP(c, b_dyS)));
+            if (!ready) BD_TRY(split_rows(c, dy, y.ld, (int64_t)c.B * 4 * H * W, C, dyS));
             bd_upsample_conv_desc d = {};
             d.B = c.B; d.H = H; d.W = W; d.Cin = C; d.Cout = C;
-            d.x_split = U16(BP(c, b_xS)); d.ldx = C; d.dy_split = U16(BP(c, b_dyS)); d.lddy = C;
+            d.x_split = U16(BP(c, b_xS)); d.ldx = C; d.dy_split = U16(dyS); d.lddy = C;
             d.et_split = U16(BP(c, b_et)); d.dx = GP(c, x); d.lddx = x.ld; d.accumulate = acc;
             d.dw = c.grads + pw; d.db = c.grads + pb;
             // ONE class of 16 taps: >= 128 tiles of its own, or (taps dealt to four workgroups per tile) >= 32
@@ -956,21 +1013,21 @@ void bd_unet::node_upsample(const std::string& pre, const View& x, const View& y
             }
             bd_conv3x3_ps_desc g = {};                           // literal data gradient on the fine grid + 2x2 sums
             g.B = c.B; g.H = 2 * H; g.W = 2 * W; g.K = C; g.N = C; g.direction = -1;
-            g.x_split = U16(BP(c, b_dyS)); g.ldx = C; g.w_split = c.wT_split + 2 * pw; g.out_scale = 1.f;
+            g.x_split = U16(dyS); g.ldx = C; g.w_split = c.wT_split + 2 * pw; g.out_scale = 1.f;
             g.y = BP(c, b_du); g.ldy = C;
             BD_TRY(conv_p(c, g));
             return bd_sum2x2(BP(c, b_du), C, GP(c, x), x.ld, c.B, H, W, C, acc, (bd_stream_t)c.st);
         }
         if (ps_ok(c, 2 * H, 2 * W, C, C)) {
-            BD_TRY(split_rows(c, dy, y.ld, (int64_t)c.B * 4 * H * W, C, BP(c, b_dyS)));
+            if (!ready) BD_TRY(split_rows(c, dy, y.ld, (int64_t)c.B * 4 * H * W, C, dyS));
             bd_conv3x3_ps_wgrad_desc w = {};
             w.B = c.B; w.H = 2 * H; w.W = 2 * W; w.Cin = C; w.Cout = C;
-            w.x_split = U16(BP(c, b_xuS)); w.ldx = C; w.dy_split = U16(BP(c, b_dyS)); w.lddy = C;
+            w.x_split = U16(BP(c, b_xuS)); w.ldx = C; w.dy_split = U16(dyS); w.lddy = C;
             w.dw = c.grads + pw; w.db = c.grads + pb;
             BD_TRY(conv_pw(c, w));
             bd_conv3x3_ps_desc g = {};
             g.B = c.B; g.H = 2 * H; g.W = 2 * W; g.K = C; g.N = C; g.direction = -1;
-            g.x_split = U16(BP(c, b_dyS)); g.ldx = C; g.w_split = c.wT_split + 2 * pw; g.out_scale = 1.f;
+            g.x_split = U16(dyS); g.ldx = C; g.w_split = c.wT_split + 2 * pw; g.out_scale = 1.f;
             g.y = BP(c, b_du); g.ldy = C;
             BD_TRY(conv_p(c, g));
         } else {
@@ -995,6 +1052,7 @@ void bd_unet::node_conv_out(const View& x) {
     const int G = cfg.norm_num_groups;
     const int b_a = new_buf((int64_t)H * W * C, 0, R_VALUE), b_st = new_buf(2 * G, 0, R_VALUE);
     const int b_bs = scratch(Co), b_da = scratch((int64_t)H * W * C);
+    const int gs_in = claim_gsplit(x, true);
     F([=](Ctx& c) {
         BD_TRY(gn_fwd(c, x, pnw, pnb, BP(c, b_a), C, b_st, 1));
         bd_conv3x3_fwd_desc d = {};
@@ -1014,7 +1072,7 @@ void bd_unet::node_conv_out(const View& x) {
         g.B = c.B; g.Hs = H; g.Ws = W; g.Cin = C; g.Cout = Co; g.stride = 1; g.pad_t = 1; g.pad_l = 1; g.Ho = H; g.Wo = W;
         g.dy = c.dout; g.lddy = c.lddo; g.w = c.params + pw; g.dx = BP(c, b_da); g.lddx = C;
         BD_TRY(conv_d(c, g));
-        return gn_bwd(c, x, pnw, pnb, b_st, BP(c, b_da), C, 1);
+        return gn_bwd(c, x, pnw, pnb, b_st, BP(c, b_da), C, 1, nullptr, 0, gs_in);
     });
 }
 
@@ -1172,7 +1230,7 @@ void bd_unet::layout(int B, int training) {
     int64_t v = 0, g = 0;
     for (auto& b : bufs) if (b.region == R_VALUE) { b.off = v; if (!b.live || b.live(B, training)) v += al(b.per_sample * B + b.fixed); }
     value_floats = v;
-    for (auto& b : bufs) if (b.region == R_GRAD) { b.off = v + g; g += al(b.per_sample * B + b.fixed); }
+    for (auto& b : bufs) if (b.region == R_GRAD) { b.off = v + g; if (!b.live || b.live(B, training)) g += al(b.per_sample * B + b.fixed); }
     grad_floats = training ? g : 0;
     const int64_t base = value_floats + grad_floats;
     int64_t smax = 0;
@@ -1354,7 +1412,10 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
                                 (int)u->wt_off.size(), st);
     };
     static const int fwd_pipes = getenv("BD_FWD_PIPES") ? atoi(getenv("BD_FWD_PIPES")) : 2;   // 1 = forward on one stream (A/B)
-    if (!u->aux_enabled || B < 32 || fwd_pipes < 2) {
+    // two pipelines need enough work per half to pay for twice the host enqueue: >= 32 K input pixels in the batch (B = 32 at 32 x 32 as
+    // before; round 4: B = 4 at 256 x 256 qualifies too -- 29.05 -> 28.13 ms per 256 x 256 train step, small layers fill the chip in pairs)
+    static const long long pipes_min_px = getenv("BD_FWD_PIPES_MINPX") ? atoll(getenv("BD_FWD_PIPES_MINPX")) : 32768;      // (A/B knob)
+    if (!u->aux_enabled || B < 2 || (long long)B * u->cfg.sample_size * u->cfg.sample_size < pipes_min_px || fwd_pipes < 2) {
         BD_TRY(transpose_weights(c.st));
         for (auto& f : u->fwd) BD_TRY(f(c));
         return BD_OK;

@@ -160,14 +160,17 @@ typedef struct {
     float* dx_colsum; int64_t ld_colsum;    /* optional [B, C] (row stride ld_colsum): per-sample sum
                                                over pixels of the written dx (needs accumulate_dx=0);
                                                the time-embedding gradient of resnet.py:571            */
-    uint16_t* dx_split; int64_t lddxs;      /* optional: this launch's dx term also / only (dx == NULL) as split
-                                               planes (not accumulated)                                            */
+    uint16_t* dx_split; int64_t lddxs;      /* optional: the value stored to dx -- this launch's term (+ the existing dx when
+                                               accumulate_dx) (+ dx_add) -- also / only (dx == NULL) as split planes         */
     const float* dx_add; int64_t ld_add;    /* optional: dx = (term (+ dx)) + dx_add, a second gradient of the same tensor
                                                folded into the store (the identity shortcut of resnet.py:596-600)     */
     float* param_partials;                  /* optional [B][2][C], caller storage: if set and bd_gn_bwd_defers(B, HW, C, G),
                                                the per-sample partial sums of (dgamma, dbeta) are left here and dgamma /
                                                dbeta are NOT written -- fold many layers later with ONE bd_gn_bwd_params
                                                launch (51 GroupNorms per CIFAR backward, one launch per segment)      */
+    int dx_split_c0, dx_split_c1;           /* optional (round 4): only channels [c0, c1) of x go to dx_split, at plane column c - c0
+                                               (whole 32-channel blocks; 0, 0 = all C).  The consumer that makes a tensor's gradient
+                                               final hands the producer of that tensor its dY operand ready-split.            */
 } bd_gn_bwd_desc;
 int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream);
 /* 1 if this shape can leave its parameter partials to the caller (round 4: every valid shape -- the single-pass kernels write them
