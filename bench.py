@@ -49,7 +49,7 @@ _PMC_PS = {"conv_ps_wgrad": (r"conv_ps_wgrad3?_kernel", r"conv_ps_wgrad_reduce")
            "gemm_sp_nt": (r"gemm_sp_kernel<false, false>",), "gemm_sp_nn": (r"gemm_sp_kernel<false, true>",),
            "gemm_sp_tn": (r"gemm_sp_kernel<true, true>", r"gemm_sp_reduce")}
 PMC_ROUNDS = ("r04", "r03", "r02")                     # this round's file first; an older one is used only when it is absent, and flagged
-PMC_FILE = "profiles/{rnd}_pmc_bench_{wl}{mode}.json"   # wl = "" (CIFAR train step), "celeba_" (256x256 train step), "ddim50_" (sampling)
+PMC_FILE = "profiles/{rnd}_pmc_bench_{wl}{mode}.json"   # wl = "" (CIFAR train step), "celeba_" (256x256 train step), "ddim50_" / "ddpm1000_" (sampling)
 
 
 def _pmc_traffic(cls, workload=""):
@@ -74,7 +74,8 @@ def _pmc_traffic(cls, workload=""):
     kernels = json.load(open(path))["kernels"]
     by = lambda v: (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
     if cls in _PMC_PS:
-        main_pat = re.compile(_PMC_PS[cls][0])
+        # (inference runs no data gradient: every conv_ps3 / conv_ps instantiation of a sampling loop is a forward launch)
+        main_pat = re.compile(r"conv_ps3?_kernel<" if (workload in ("ddim50", "ddpm1000") and cls == "conv_ps_fwd") else _PMC_PS[cls][0])
         tot = n = 0.0
         for name, v in kernels.items():
             if main_pat.search(name):
@@ -271,7 +272,7 @@ def run_sampling(model, kind, n, mode, world, rank, dev, lib, want_roofline=True
             d = cl[0]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             peak = FP32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 3
-            traffic, tsrc = _pmc_traffic(d["kernel"], "ddim50")     # same kernels, same chunk shapes in both sampling loops
+            traffic, tsrc = _pmc_traffic(d["kernel"], "ddpm1000" if kind == "ddpm1000" else "ddim50")     # PMC run of the same chunk shape
             res["roofline"] = {"bound": "mfma", "kernel": d["kernel"], "achieved": ach, "peak": peak, "unit": "TFLOP/s",
                                "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
                                "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],

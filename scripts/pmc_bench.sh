@@ -1,12 +1,13 @@
 #!/bin/bash
 # HBM traffic of every kernel of the bench step from PMC counters, one counter per pass (guide: FETCH_SIZE and
-# WRITE_SIZE do not fit one pass; kernel-trace only).  usage: pmc_bench.sh <mode> [cifar|celeba|ddim50] -> gpurun_out/pmc_bench_[<workload>_]<mode>.json
+# WRITE_SIZE do not fit one pass; kernel-trace only).  usage: pmc_bench.sh <mode> [cifar|celeba|ddim50|ddpm1000] -> gpurun_out/pmc_bench_[<workload>_]<mode>.json
 mode=${1:-bf16x3}
 wl=${2:-cifar}
 case $wl in
   cifar)  WLARGS="--steps 3 --warmup 1 --no-sampling --no-celeba --no-dp-probe --sustain 0"; tag="" ;;
   celeba) WLARGS="--workload celeba --steps 3 --warmup 1 --sustain 0"; tag="celeba_" ;;
-  ddim50) WLARGS="--workload ddim50 --batch 512"; tag="ddim50_" ;;
+  ddim50) WLARGS="--workload ddim50 --batch 2048"; tag="ddim50_" ;;       # the chunk shape of the default line's DDIM-50 x 2048 loop
+  ddpm1000) WLARGS="--workload ddim50 --batch 256"; tag="ddpm1000_" ;;    # same kernels and batch as the DDPM-1000 x 256 loop, 50 evaluations
 esac
 cd /tmp && export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do

@@ -20,6 +20,8 @@ $GRAFT_REPO_ROOT/scripts/pmc_bench.sh bf16x3 > /dev/null 2>&1
 cp $out/pmc_bench_bf16x3.json $out/${tag}_pmc_bench_bf16x3.json
 $GRAFT_REPO_ROOT/scripts/pmc_bench.sh bf16x3 ddim50 > /dev/null 2>&1
 cp $out/pmc_bench_ddim50_bf16x3.json $out/${tag}_pmc_bench_ddim50_bf16x3.json
+$GRAFT_REPO_ROOT/scripts/pmc_bench.sh bf16x3 ddpm1000 > /dev/null 2>&1
+cp $out/pmc_bench_ddpm1000_bf16x3.json $out/${tag}_pmc_bench_ddpm1000_bf16x3.json
 # 4. stand-alone kernel durations (side stream off) for the kernel table in DESIGN.md
 cd /tmp && rm -rf /tmp/rp2 && BD_AUX_STREAM=0 rocprofv3 --kernel-trace --stats -d /tmp/rp2 -o r -- python $GRAFT_REPO_ROOT/bench.py --steps 8 --warmup 2 --no-prof $TRAIN > /tmp/rp2.log 2>&1
 python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/rp2 -name "*.db" | head -1) 10 > $out/${tag}_train_step_b128_single_stream_kernel_stats.txt
