@@ -209,8 +209,15 @@ class TrainEngine:
         if self.dp and os.environ.get("BD_DP_TRANSPORT", "rccl") == "rccl":
             be = dist.get_backend(process_group) if (dist.is_available() and dist.is_initialized()) else "none"
             if process_group is None and (be == "nccl" or self.world == 1):
-                from .rccl import RcclComm
-                self._rccl = RcclComm(dev)
+                try:
+                    from .rccl import RcclComm
+                    self._rccl = RcclComm(dev)
+                except (RuntimeError, OSError) as e:       # no librccl.so / communicator init refused: the c10d transport still works
+                    import warnings
+                    warnings.warn(f"direct RCCL transport unavailable ({e}); gradients go through torch.distributed.all_reduce")
+                    if self.world == 1:
+                        ensure_single_rank_group()
+                    self._rccl = None
         self._comm = torch.cuda.Stream(device=dev) if (self.dp and (self._defer or self._rccl is not None)) else None
         self._dp_shadow = torch.zeros(n, device=dev) if (dp_check and self.dp) else None
         if dp_check and self.accum != 1:
