@@ -334,3 +334,16 @@ def test_dp_communication_buckets_cover_every_gradient_range():
                     assert any(blo <= lo and hi <= bhi for blo, bhi in b[owner][1]), (name, mb, s, lo, hi)
             if mb == 32:
                 assert sum(hi - lo for lo, hi in b[-1][1]) * 4 <= 8 << 20 and len(b) <= 8
+
+
+def test_rccl_binding_loads_and_exports_the_calls_used():
+    """baddiffusion_amd/rccl.py binds the librccl.so that ships with PyTorch-ROCm through ctypes: the library loads without a GPU and
+    exports every entry point the gradient exchange uses (no communicator is created here -- that needs a device)."""
+    from baddiffusion_amd import rccl
+    lib = rccl._load()
+    for name in ("ncclGetUniqueId", "ncclCommInitRank", "ncclAllReduce", "ncclBroadcast", "ncclCommDestroy", "ncclGroupStart", "ncclGroupEnd",
+                 "ncclGetErrorString"):
+        assert hasattr(lib, name), name
+    import ctypes
+    assert ctypes.sizeof(rccl._UniqueId) == 128
+    assert b"" != lib.ncclGetErrorString(0)
