@@ -258,6 +258,108 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const float* __restric
     }
 }
 
+// Round 4: the expand direction on the matrix pipe (BD_MODE_BF16X3 only).  thin_expand_kernel is bound by plain v_fma_f32 issue (3 456 FMAs per pixel
+// for 128 output channels: 92 us for a 27 us stream of bytes at 256 x 256).  As a GEMM the layer is [pixels x 27] x [27 x C]: K = 27 pads to 32 = two
+// v_mfma_f32_32x32x16_bf16 steps, and the im2col operand needs no LDS: a lane of the A fragment IS one pixel and one octet of K, so it loads its
+// own 16 tap values (the 3-channel tensor is tiny: every read hits L1 / L2), splits them into bf16 hi | lo in registers (the same truncate / RNE
+// split as everywhere else) and multiplies against weight fragments built once per wave.  24 MFMAs (3 passes x 4 channel tiles x 2 K steps) + 16
+// loads + 64 coalesced 128-byte stores per 32 pixels and 128 channels: the kernel writes at the rate of its output.
+typedef __bf16 thin_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float thin_f32x16 __attribute__((ext_vector_type(16)));
+__device__ __forceinline__ void thin_split8(const float (&v)[8], thin_bf16x8& hi, thin_bf16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const unsigned u = __builtin_bit_cast(unsigned, v[j]) & 0xFFFF0000u;
+        const float h = __builtin_bit_cast(float, u);
+        hi[j] = __builtin_bit_cast(__bf16, (unsigned short)(u >> 16));
+        lo[j] = (__bf16)(v[j] - h);
+    }
+}
+
+template <int J>
+__global__ __launch_bounds__(256) void thin_expand_mfma_kernel(const float* __restrict__ in, long long ldi, const float* __restrict__ w, ThinCoef cm,
+                                                             const float* __restrict__ bias, float* __restrict__ out, long long ldo, int H,
+                                                             int W, long long runs, int iters, float out_scale) {
+    static_assert(9 * J <= 32, "K = 9 J must fit two 16-deep MFMA steps");
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int n0 = blockIdx.y * 128;
+    // k = s*16 + h*8 + j  ->  tap t = k / J, channel k % J (k >= 9 J: padding)
+    int ktap[16], kch[16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int k = (i >> 3) * 16 + h * 8 + (i & 7);
+        ktap[i] = k < 9 * J ? k / J : -1;
+        kch[i] = k < 9 * J ? k % J : 0;
+    }
+    // weight fragments: lane = output channel li of tile q, its 16 k values, hi | lo
+    thin_bf16x8 bh[4][2], bl[4][2];
+    float bn[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const int n = n0 + q * 32 + li;
+        bn[q] = bias ? bias[n] : 0.f;
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            float c[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = s * 8 + j;
+                const float v = w[cm.base + (long long)n * cm.sn + (ktap[i] < 0 ? 0 : ktap[i]) * cm.st + kch[i] * cm.sj];
+                c[j] = ktap[i] < 0 ? 0.f : v;
+            }
+            thin_split8(c, bh[q][s], bl[q][s]);
+        }
+    }
+    const int HW = H * W;
+    for (int it = 0; it < iters; ++it) {
+        const long long run = ((long long)blockIdx.x * 4 + wave) * iters + it;      // wave-uniform
+        if (run >= runs) break;
+        const long long p0 = run * 32;                 // W % 32 == 0: a run is 32 pixels of one image row
+        const int b = (int)(p0 / HW), r = (int)(p0 - (long long)b * HW);
+        const int y = r / W, x = r - y * W + li;       // this lane's pixel
+        // its 16 tap values: out-of-image taps read a clamped pixel of the same neighbourhood and are multiplied by 0 (no select around the load)
+        float a[16];
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int t = ktap[i] < 0 ? 4 : ktap[i];
+            const int ys = y - 1 + t / 3, xs = x - 1 + t % 3;
+            const float m = (ktap[i] >= 0 && (unsigned)ys < (unsigned)H && (unsigned)xs < (unsigned)W) ? 1.f : 0.f;
+            const int yc = min(max(ys, 0), H - 1), xc = min(max(xs, 0), W - 1);
+            a[i] = in[((long long)b * HW + (long long)yc * W + xc) * ldi + kch[i]] * m;
+        }
+        thin_bf16x8 ah[2], al[2];
+        {
+            float lo8[8], hi8[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { lo8[j] = a[j]; hi8[j] = a[8 + j]; }
+            thin_split8(lo8, ah[0], al[0]);
+            thin_split8(hi8, ah[1], al[1]);
+        }
+        thin_f32x16 acc[4];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[q][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[s], bh[q][s], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bl[q][s], acc[q], 0, 0, 0);
+#pragma unroll
+            for (int s = 0; s < 2; ++s) acc[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[s], bh[q][s], acc[q], 0, 0, 0);
+        }
+        // lane holds output channel li of pixels (e & 3) + 8 (e >> 2) + 4 h of the run: 128 contiguous bytes per half-wave and store
+        float* ob = out + p0 * ldo + n0 + li;
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * h;
+                ob[(long long)m * ldo + q * 32] = (acc[q][e] + bn[q]) * out_scale;
+            }
+    }
+}
+
 // halving butterfly: on entry every lane holds NV partial values ("slots", NV a power of two <= 32); on exit lane l holds the
 // sum over all 64 lanes of slot l / (64 / NV).  NV - 1 + log2(64 / NV) shuffles for NV values instead of 6 per value.
 template <int NV>
@@ -444,9 +546,19 @@ static bool thin_same_grid(int stride, int ups, int pad_t, int pad_l, int Hs, in
 }
 
 static int thin_expand_launch(int J, const float* in, long long ldi, const float* w, ThinCoef cm, const float* bias, float* out, long long ldo,
-                              int N, int B, int H, int W, float out_scale, hipStream_t st) {
+                              int N, int B, int H, int W, float out_scale, hipStream_t st, int mode) {
     const long long pixels = (long long)B * H * W;
     const long long runs = cdiv(pixels, 32);
+    static const bool mfma_off = getenv("BD_THIN_MFMA") && atoi(getenv("BD_THIN_MFMA")) == 0;      // (A/B knob)
+    if (!mfma_off && mode == BD_MODE_BF16X3 && J == 3 && W % 32 == 0 && pixels % 32 == 0) {
+        // split-bf16 products like every other convolution of this mode; the exact-fp32 mode keeps the FMA kernel below
+        int iters = 8;
+        while (iters > 1 && runs / (4 * iters) < 512) iters >>= 1;        // >= 512 workgroups where the layer has them
+        const dim3 grid((unsigned)cdiv(runs, 4 * iters), (unsigned)(N / 128)), block(256);
+        hipLaunchKernelGGL(thin_expand_mfma_kernel<3>, grid, block, 0, st, in, ldi, w, cm, bias, out, ldo, H, W, runs, iters, out_scale);
+        BD_LAUNCH_CHECK("conv3x3 thin expand (mfma)");
+        return 1;
+    }
     const int iters = (int)(runs >= 4096 ? 4 : 1);      // >= 1024 workgroups per 128-channel block at the UNet's sizes
     const dim3 grid((unsigned)cdiv(runs, iters), (unsigned)(N / 128)), block(256);
     if (J == 3) hipLaunchKernelGGL(thin_expand_kernel<3>, grid, block, 0, st, in, ldi, w, cm, bias, out, ldo, H, W, pixels, iters, out_scale);
@@ -464,7 +576,7 @@ int conv3x3_fwd_thin(const bd_conv3x3_fwd_desc& d, hipStream_t st) {
     if ((d.Cin == 3 || d.Cin == 1) && d.Cout % 128 == 0 && d.Ws % 4 == 0 && d.ldy % 4 == 0 && aligned16(d.y) && (!d.bias || aligned16(d.bias))) {
         const int rec = prof_on() ? prof_begin("conv_thin_fwd", flops, bytes, st) : -1;
         const ThinCoef cm = {0, 9ll * d.Cin, d.Cin, 1};
-        const int r = thin_expand_launch(d.Cin, d.x, d.ldx, d.w, cm, d.bias, d.y, d.ldy, d.Cout, d.B, d.Hs, d.Ws, os, st);
+        const int r = thin_expand_launch(d.Cin, d.x, d.ldx, d.w, cm, d.bias, d.y, d.ldy, d.Cout, d.B, d.Hs, d.Ws, os, st, d.mode);
         prof_end(rec, st);
         return r;
     }
@@ -488,7 +600,7 @@ int conv3x3_dgrad_thin(const bd_conv3x3_dgrad_desc& d, hipStream_t st) {
     const int rec = prof_on() ? prof_begin("conv_thin_dgrad", 2.0 * d.B * d.Hs * d.Ws * 9.0 * d.Cin * d.Cout, 4.0 * d.B * d.Hs * d.Ws * (d.Cin + d.Cout), st) : -1;
     // dx[p][c] = sum_{t', o} dy[p + d(t')][o] * w[o][8 - t'][c]   (w = [Cout][3][3][Cin])
     const ThinCoef cm = {8ll * d.Cin, 1, -(long long)d.Cin, 9ll * d.Cin};
-    const int r = thin_expand_launch(d.Cout, d.dy, d.lddy, d.w, cm, nullptr, d.dx, d.lddx, d.Cin, d.B, d.Hs, d.Ws, 1.f, st);
+    const int r = thin_expand_launch(d.Cout, d.dy, d.lddy, d.w, cm, nullptr, d.dx, d.lddx, d.Cin, d.B, d.Hs, d.Ws, 1.f, st, d.mode);
     prof_end(rec, st);
     return r;
 }
@@ -501,6 +613,85 @@ bool conv3x3_wgrad_is_thin(const bd_conv3x3_wgrad_desc& d) {
 }
 
 // returns 1 when it handled the call, 0 when the shape belongs to the igemm path, < 0 on error
+// Round 4: the two weight gradients on the matrix pipe (BD_MODE_BF16X3, W % 32 == 0).  Both are out[c][k] = sum_p wide[p][c] * col[p][k] with a
+// 128-channel-wide tensor and a <= 32-column im2col of the 3-channel one (k = tap * 3 + channel; conv_in: col[p][k] = x[p + d(t)][j] and column 27 = 1
+// carries the bias gradient; conv_out: col[q][k] = dy[q - d(t)][o]).  The contraction runs over pixels, so the MFMA A operand is wide^T: lane = channel,
+// 8 consecutive pixels per K octet -- each of the 8 loads of a step is a coalesced 128-byte row piece per half-wave -- and the B operand is the lane's
+// own im2col column for the same 8 pixels (L1 / L2 hits).  A wave owns 32 channels for the whole pixel slab of its workgroup (no cross-wave fold), a
+// workgroup leaves one partial row in the layout thin_reduce_kernel sums (fixed order, deterministic).  wgrad_thin_row_kernel needs 27 float2
+// accumulators and 27 x 2 FMAs per lane and pixel: 100 - 146 us against ~35 for the bytes at 256 x 256.
+template <bool WIDE_IS_DY>
+__global__ __launch_bounds__(256) void wgrad_thin_mfma_kernel(const float* __restrict__ wide, long long ldw, const float* __restrict__ nar, long long ldn,
+                                                            int Cw, int H, int W, long long nsteps, int steps_per_wg, long long n_row, long long n_w,
+                                                            float* __restrict__ partial) {
+    const int lane = threadIdx.x & 63, li = lane & 31, h = lane >> 5;
+    const int q = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);       // this wave's 32-channel tile
+    const int c0 = blockIdx.y * 128 + q * 32;
+    const int t = li < 27 ? li / 3 : 4, ch = li < 27 ? li % 3 : 0;
+    const int sgn = WIDE_IS_DY ? 1 : -1;
+    const int dyl = sgn * (t / 3 - 1), dxl = sgn * (t % 3 - 1);
+    const int HW = H * W;
+    thin_f32x16 acc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+    float csum = 0.f;
+    const long long s_begin = (long long)blockIdx.x * steps_per_wg;
+    long long s_end = s_begin + steps_per_wg;
+    if (s_end > nsteps) s_end = nsteps;
+    for (long long s = s_begin; s < s_end; ++s) {
+        const long long p0 = s * 16;                         // 16 pixels of one image row (W % 32 == 0)
+        const int b = (int)(p0 / HW), r = (int)(p0 - (long long)b * HW);
+        const int y = r / W, x0 = r - y * W + h * 8;
+        float av[8], bv[8];
+        const float* wp = wide + (p0 + h * 8) * ldw + c0 + li;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) av[j] = wp[(long long)j * ldw];
+        const int ys = y + dyl;
+        const float rm = (li < 27 && (unsigned)ys < (unsigned)H) ? 1.f : 0.f;
+        const int yc = min(max(ys, 0), H - 1);
+        const float* np_ = nar + ((long long)b * HW + (long long)yc * W) * ldn + ch;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int xs = x0 + j + dxl;
+            const float m = (unsigned)xs < (unsigned)W ? rm : 0.f;
+            const int xc = min(max(xs, 0), W - 1);
+            bv[j] = np_[(long long)xc * ldn] * m;
+        }
+        if (WIDE_IS_DY && li == 27) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bv[j] = 1.f;       // bias gradient: sum_p dy[p][c]
+        }
+        if (!WIDE_IS_DY) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) csum += bv[j];     // centre-tap columns: sum_p dy[p][o] = the bias gradient of conv_out
+        }
+        thin_bf16x8 ah, al, bh, bl;
+        thin_split8(av, ah, al);
+        thin_split8(bv, bh, bl);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+    // lane: column k = li, channels c0 + (e & 3) + 8 (e >> 2) + 4 h
+    float* row = partial + (long long)blockIdx.x * n_row;
+    if (WIDE_IS_DY) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = c0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (li < 27) row[(long long)c * 27 + li] = acc[e];          // dW[co][t][j]
+            else if (li == 27) row[n_w + c] = acc[e];                  // db[co]
+        }
+    } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            const int c = c0 + (e & 3) + 8 * (e >> 2) + 4 * h;
+            if (li < 27) row[((long long)ch * 9 + t) * Cw + c] = acc[e]; // dW[o][t][c]
+        }
+        csum += __shfl_xor(csum, 32, 64);
+        if (blockIdx.y == 0 && q == 0 && h == 0 && li >= 12 && li < 15) row[n_w + (li - 12)] = csum;   // db[o]
+    }
+}
+
 int conv3x3_wgrad_thin(const bd_conv3x3_wgrad_desc& d, hipStream_t st) {
     if (!conv3x3_wgrad_is_thin(d)) return 0;
     const bool thin_in = thin_in_shape(d);
@@ -517,6 +708,23 @@ int conv3x3_wgrad_thin(const bd_conv3x3_wgrad_desc& d, hipStream_t st) {
     BD_CHECK(d.workspace && d.workspace_bytes >= need, BD_ERR_WORKSPACE, "conv3x3_wgrad (thin): workspace %zu < %zu", d.workspace_bytes,
              need);
     float* part = reinterpret_cast<float*>(d.workspace);
+    static const bool mfma_off = getenv("BD_THIN_MFMA") && atoi(getenv("BD_THIN_MFMA")) == 0;      // (A/B knob)
+    if (!mfma_off && d.mode == BD_MODE_BF16X3 && d.Ws % 32 == 0 && d.pad_t == 1 && d.pad_l == 1 && (thin_in ? d.Cin == 3 : d.Cout == 3)) {
+        const long long nsteps = g.pixels / 16;
+        const int spw = (int)cdiv(nsteps, 512);                  // <= 512 partial rows (7 MB for the second pass to fold)
+        const int rows = (int)cdiv(nsteps, spw);
+        const int Cw = thin_in ? d.Cout : d.Cin;
+        BD_CHECK(d.workspace_bytes >= (size_t)rows * n * sizeof(float), BD_ERR_WORKSPACE, "conv3x3_wgrad (thin mfma): workspace too small");
+        const dim3 grid((unsigned)rows, (unsigned)(Cw / 128));
+        if (thin_in) hipLaunchKernelGGL(wgrad_thin_mfma_kernel<true>, grid, dim3(256), 0, st, d.dy, (long long)d.lddy, d.x, (long long)d.ldx, Cw, d.Hs, d.Ws,
+                                        nsteps, spw, n, n_w, part);
+        else hipLaunchKernelGGL(wgrad_thin_mfma_kernel<false>, grid, dim3(256), 0, st, d.x, (long long)d.ldx, d.dy, (long long)d.lddy, Cw, d.Hs, d.Ws,
+                                nsteps, spw, n, n_w, part);
+        BD_LAUNCH_CHECK("conv3x3_wgrad_thin_mfma");
+        hipLaunchKernelGGL(thin_reduce_kernel, dim3((unsigned)cdiv(n, 64)), dim3(1024), 0, st, part, rows, n, n_w, d.dw, d.db);
+        BD_LAUNCH_CHECK("conv3x3_wgrad_thin_reduce");
+        return 1;
+    }
     static const bool row_off = getenv("BD_THIN_DIRECT") && atoi(getenv("BD_THIN_DIRECT")) == 0;
     if (!row_off && d.Ws % 32 == 0 && d.pad_t == 1 && d.pad_l == 1 && (d.Cin == 3 || d.Cout == 3) &&
         (thin_in ? d.lddy : d.ldx) % 2 == 0 && ((uintptr_t)(thin_in ? d.dy : d.x) & 7) == 0) {   // float2 loads of the wide tensor

@@ -808,8 +808,9 @@ def test_cli_sampling_and_measure_end_to_end(gpu, tmp_path):
 def test_thin_convs_direct_kernels(gpu, B, H, W, C):
     """conv_in (3 -> C) and conv_out (C -> 3) forward / data gradient / weight gradient (unet_2d.py:124,217): the direct fp32
     streaming kernels of round 3 (conv_thin.hip: W % 4 == 0 expand, W % 32 == 0 and C == 128 contract / row weight gradients; other
-    shapes take the implicit-GEMM path, same checks) against fp64 F.conv2d + autograd on the CPU.  Exact fp32 products in both
-    compute modes, so 1e-5 relative; run-to-run bit identity of the K-split weight gradients."""
+    shapes take the implicit-GEMM path, same checks) against fp64 F.conv2d + autograd on the CPU.  Exact fp32 products (1e-5 relative)
+    except the expand direction and the weight gradients in split-bf16 mode, which round 4 moved to the matrix pipe (2e-5); run-to-run bit
+    identity of the K-split weight gradients."""
     import torch.nn.functional as F
     from baddiffusion_amd import ops
     g = torch.Generator().manual_seed(B * 100 + W)
@@ -828,9 +829,9 @@ def test_thin_convs_direct_kernels(gpu, B, H, W, C):
         # conv_in
         y, _, dw, db = ref(x3, w_in, b_in, dy_c)
         got = ops.conv3x3_fwd(x3.cuda(), w_in.cuda(), b_in.cuda(), mode=mode, out_scale=0.5)
-        assert relerr(got, 0.5 * y) < 1e-5
+        assert relerr(got, 0.5 * y) < (1e-5 if mode == 0 else 2e-5)        # (round 4: split-bf16 MFMA form of the expand direction in mode 1, W % 32 == 0)
         gw, gb = ops.conv3x3_wgrad(x3.cuda(), dy_c.cuda(), mode=mode, with_db=True)
-        assert relerr(gw, dw) < 1e-5 and relerr(gb, db) < 1e-5
+        assert relerr(gw, dw) < (1e-5 if mode == 0 else 2e-5) and relerr(gb, db) < (1e-5 if mode == 0 else 2e-5)
         gw2, gb2 = ops.conv3x3_wgrad(x3.cuda(), dy_c.cuda(), mode=mode, with_db=True)
         assert torch.equal(gw, gw2) and torch.equal(gb, gb2)
         # conv_out
@@ -840,7 +841,7 @@ def test_thin_convs_direct_kernels(gpu, B, H, W, C):
         gx = ops.conv3x3_dgrad(dy_3.cuda(), w_out.cuda(), (B, H, W, C), mode=mode)
         assert relerr(gx, dx) < (1e-5 if mode == 0 else 2e-5)
         gw, gb = ops.conv3x3_wgrad(xc.cuda(), dy_3.cuda(), mode=mode, with_db=True)
-        assert relerr(gw, dw) < 1e-5 and relerr(gb, db) < 1e-5
+        assert relerr(gw, dw) < (1e-5 if mode == 0 else 2e-5) and relerr(gb, db) < 1e-5
         gw2, _ = ops.conv3x3_wgrad(xc.cuda(), dy_3.cuda(), mode=mode, with_db=True)
         assert torch.equal(gw, gw2)
 
