@@ -51,6 +51,19 @@ __device__ __forceinline__ float silu_grad_dev(float z) {
     const float s = 1.0f / (1.0f + expf(-z));
     return s * (1.0f + z * (1.0f - s));
 }
+// Round 4: the LARGE-IMAGE kernels (gn_apply / gn_bwd_stats / gn_bwd_apply) take the sigmoid from the hardware transcendentals -- v_exp_f32 (2^x,
+// 1 ulp) of -z * log2(e) and v_rcp_f32 (1 ulp): 4 VALU instructions instead of the ~25 of expf() + an IEEE division, <= 3 ulp of fp32 (tests: 1e-5
+// against fp64 torch).  They stream 134 MB tensors beside MFMA kernels that are bound by issue slots and board power: 27.87 -> 27.41 ms per 256 x 256
+// step (A/B of two builds alternating on one box).  The resident kernels keep expf(): the same change there measured +0.22 ms on the CIFAR step
+// (17.92 -> 18.15, three alternations) -- their time is the LDS / shuffle reduction, and the shorter arithmetic changed nothing but the schedule.
+__device__ __forceinline__ float gn_sigmoid_fast(float z) {
+    return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__fmul_rn(z, -1.44269504088896341f)));
+}
+__device__ __forceinline__ float silu_fast(float z) { return z * gn_sigmoid_fast(z); }
+__device__ __forceinline__ float silu_grad_fast(float z) {
+    const float s = gn_sigmoid_fast(z);
+    return s * (1.0f + z * (1.0f - s));
+}
 
 // ---- split-plane output (bd_hip.h "split planes"): 4 consecutive channels c..c+3 of one row -> 8 B of bf16 hi and 8 B of
 // bf16 lo (hi = truncation, lo = RNE of the remainder: bit-identical to the on-the-fly split of the bf16x3 engine)
@@ -194,7 +207,7 @@ __global__ void gn_apply_kernel(const float* __restrict__ x, long long ldx, floa
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const float z = (in[j] - mu[j]) * rs[j] * gg[j] + bb[j];
-                o[j] = silu ? silu_dev(z) : z;
+                o[j] = silu ? silu_fast(z) : z;
             }
             v[u] = make_float4(o[0], o[1], o[2], o[3]);
         }
@@ -255,7 +268,7 @@ __global__ void gn_bwd_stats_kernel(const float* __restrict__ x, long long ldx, 
             for (int j = 0; j < 4; ++j) {
                 const float xh = ok ? (in[j] - mu[j]) * rs[j] : 0.f;
                 float dz = dd[j];
-                if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
+                if (silu) dz *= silu_grad_fast(xh * gg[j] + bb[j]);
                 s0[j] += dz;
                 s1[j] += dz * xh;
                 s2[j] += xh;
@@ -450,7 +463,7 @@ __global__ void gn_bwd_apply_kernel(const float* __restrict__ x, long long ldx, 
             for (int j = 0; j < 4; ++j) {
                 const float xh = (in[j] - mu[j]) * rs[j];
                 float dz = dd[j];
-                if (silu) dz *= silu_grad_dev(xh * gg[j] + bb[j]);
+                if (silu) dz *= silu_grad_fast(xh * gg[j] + bb[j]);
                 o[j] = (rs[j] * (dz * gg[j] - (g1[j] + xh * g2[j]) * inv_n) + ee[j]) + aa[j];
             }
             v[u] = make_float4(o[0], o[1], o[2], o[3]);
