@@ -703,7 +703,20 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             BD_TRY(linear_wgrad(c, dy, lddy, VP(c, x), x.ld, c.grads + psw, M, Cout, Cin, c.grads + psb));
             const int acc = c.ginit[x.buf];
             c.ginit[x.buf] = 1;
-            BD_TRY(linear_dgrad(c, dy, lddy, c.params + psw, GP(c, x), x.ld, M, Cout, Cin, acc));
+            // dL/dy exists as split planes whenever conv2 took the plane kernels: the shortcut's data gradient then runs DMA-fed on them
+            // (bd_gemm_sp, the weight's per-step plane copy taken K-major) instead of splitting both fp32 operands in the igemm loaders
+            static const bool sc_sp = !(getenv("BD_SHORTCUT_SP") && atoi(getenv("BD_SHORTCUT_SP")) == 0);      // (A/B knob)
+            if (sc_sp && ps2 && gemm_sp_supported(M, Cin, Cout) && x.ld % 4 == 0) {
+                const bool ready = gs_out >= 0 && gsplits[gs_out].emitted;
+                bd_gemm_sp_desc g = {};
+                g.M = M; g.N = Cin; g.K = Cout; g.batch = 1;
+                g.a = U16(ready ? BP(c, gsplits[gs_out].b_pl) : BP(c, b_dyS)); g.lda = Cout;
+                g.b = c.w_split + 2 * psw; g.ldb = Cin; g.b_kmajor = 1;
+                g.c = GP(c, x); g.ldc = x.ld; g.accumulate = acc; g.alpha = 1.f; g.out_scale = 1.f;
+                BD_TRY(gemm_s(c, g));
+            } else {
+                BD_TRY(linear_dgrad(c, dy, lddy, c.params + psw, GP(c, x), x.ld, M, Cout, Cin, acc));
+            }
         }
         // norm1 backward; the identity shortcut's gradient (dy itself) is added in the same store
         return gn_bwd(c, x, pn1w, pn1b, b_st1, BP(c, b_da1), Cin, 1, shortcut ? nullptr : dy, lddy, gs_in);
