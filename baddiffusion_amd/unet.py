@@ -283,8 +283,8 @@ class UNet2DModel(nn.Module):
         pooled workspace of that size counts as free: it is reused).  Halves until it fits; never below 1."""
         chunk = max(1, min(int(B), self.max_chunk))
         dev = self.flat.device
-        if dev.type != "cuda":
-            return chunk
+        if dev.type != "cuda" or self._ws_pool.get((chunk, False, str(dev))):
+            return chunk        # (a pooled workspace of this size exists: nothing to allocate, no driver query on the sampling loop's path)
         free, _ = torch.cuda.mem_get_info(dev)
         free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # the caching allocator's idle blocks
         while chunk > 1:

@@ -707,9 +707,14 @@ def main():
             out["sampling"] = sampling
         if side:
             out["celeba"] = side
-        print(json.dumps(out), file=_JSON_OUT, flush=True)
-    if dist.is_available() and dist.is_initialized():      # world > 1, or the 1-rank group of the DP probe
+        final_line = json.dumps(out)
+    else:
+        final_line = None
+    del eng, model
+    if dist.is_available() and dist.is_initialized():      # world > 1 (or a c10d 1-rank group of an A/B run)
         dist.destroy_process_group()
+    if final_line is not None:      # the LAST thing this process writes: nothing a library prints at teardown can follow it
+        print(final_line, file=_JSON_OUT, flush=True)
 
 
 if __name__ == "__main__":
