@@ -496,6 +496,7 @@ def train_loop(config, model, noise_sched, get_pipeline, dsl, device, world, ran
                 save_rank_rng(config, rank, capture_rank_rng(epoch, cur_step))
         if log is not None:
             log.close()
+        engine.close()
     return get_pipeline(unet=model, scheduler=noise_sched)
 
 

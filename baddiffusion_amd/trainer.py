@@ -226,6 +226,13 @@ class TrainEngine:
         self.alphas, self.alphas_cumprod = noise_sched.device_tables(dev)
         self.sync_state()
 
+    def close(self):
+        """Tear the gradient communicator down explicitly (while the HIP runtime is still up; otherwise it goes with the object)."""
+        c, self._rccl = self._rccl, None
+        if c not in (None, "none"):
+            torch.cuda.synchronize()
+            c.destroy()
+
     def sync_state(self):
         """Make every rank start from rank 0's parameters and Adam moments (replicas only ever exchange gradients:
         without this, ranks that initialised or resumed differently would apply the averaged gradient at different

@@ -599,6 +599,11 @@ def main():
                         "bytes_per_step": int(e2.collective_bytes),
                         "note": "TrainEngine(force_dp=True): trainer.py's DP branch on one GPU; tests/test_hip_round4.py checks its stream ordering"}
             log(f"dp path at world 1: {res['rccl'][0]:.2f} ms/step, without the RCCL call {res['none'][0]:.2f} (plain {pms:.2f})")
+            torch.cuda.synchronize()
+            for _t in ("rccl", "none"):
+                _c = getattr(res[_t][2], "_rccl", None)
+                if _c not in (None, "none"):
+                    _c.destroy()
             del e2, res
         except Exception as e:      # a box without a working RCCL init must not lose the headline line
             dp_probe = {"error": f"{type(e).__name__}: {e}"}
@@ -645,6 +650,9 @@ def main():
             ccl, ccl_iso, cn = profile_steps(lib, cmodel, cstep, 13, 2, barrier)
             side["roofline"], side["kernel_classes"], side["kernel_classes_standalone"] = \
                 roofline_object(ccl, ccl_iso, cn, args.mode, cdt / 10 * 1e3, probe, "celeba")
+        if getattr(ceng, "_rccl", None) not in (None, "none"):
+            torch.cuda.synchronize()
+            ceng._rccl.destroy()
         del cmodel, ceng, cstep
         torch.cuda.empty_cache()
 
@@ -710,7 +718,9 @@ def main():
         final_line = json.dumps(out)
     else:
         final_line = None
-    del eng, model
+    if getattr(eng, "_rccl", None) not in (None, "none"):      # tear the gradient communicator down while the HIP runtime is still up
+        torch.cuda.synchronize()
+        eng._rccl.destroy()
     if dist.is_available() and dist.is_initialized():      # world > 1 (or a c10d 1-rank group of an A/B run)
         dist.destroy_process_group()
     if final_line is not None:      # the LAST thing this process writes: nothing a library prints at teardown can follow it
