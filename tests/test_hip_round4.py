@@ -324,3 +324,24 @@ def test_groupnorm_large_image_path_round4(gpu):
         items[0].partials = L.ptr(part1); items[0].C = Cc; items[0].dgamma = L.ptr(dg1); items[0].dbeta = L.ptr(db1)
         L.check(lib.bd_gn_bwd_params(items, 1, B, L.stream()))
         assert relerr(dg1, dg0) < 1e-6 and relerr(db1, db0) < 1e-6
+
+
+@pytest.mark.parametrize("topology,batch", [("google/ddpm-cifar10-32", 40), ("google/ddpm-ema-celebahq-256", 1)])
+def test_round4_paths_equal_their_fallbacks(gpu, tmp_path, topology, batch):
+    """Every plan / kernel path added in round 4 against the path it replaces, on whole networks (each knob is read once per process, hence
+    the child processes): ready-split gradients (BD_GSPLIT), the shortcut data gradient on planes (BD_SHORTCUT_SP), the 3-channel convolutions on
+    the matrix pipe (BD_THIN_MFMA), strip-order convolutions on wide images (BD_PS_V3_MAXW / BD_PS_WG3_MAXW = 32) and -- B = 40 holds >= 32 K
+    pixels -- the two forward pipelines (BD_FWD_PIPES_MINPX).  Output and the full flat gradient agree to rounding (2e-5 / 1e-4 relative; the paths
+    differ in summation order and, for the thin convolutions, in exact-fp32 vs split-bf16 products)."""
+    base = dict(os.environ, BD_T_TOPOLOGY=topology, BD_T_BATCH=str(batch))
+    off = dict(base, BD_GSPLIT="0", BD_SHORTCUT_SP="0", BD_THIN_MFMA="0", BD_PS_V3_MAXW="32", BD_PS_WG3_MAXW="32", BD_FWD_PIPES_MINPX=str(1 << 40))
+    res = {}
+    for tag, env in (("new", base), ("old", off)):
+        f = str(tmp_path / f"{tag}.pt")
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_knob_worker.py"), f], capture_output=True, text=True, timeout=600,
+                           cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[tag] = torch.load(f)
+    assert relerr(res["new"]["out"], res["old"]["out"]) < 2e-5
+    assert relerr(res["new"]["grad"], res["old"]["grad"]) < 1e-4
+    assert torch.isfinite(res["new"]["grad"]).all()
