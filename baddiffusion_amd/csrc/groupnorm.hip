@@ -51,11 +51,13 @@ __device__ __forceinline__ float silu_grad_dev(float z) {
     const float s = 1.0f / (1.0f + expf(-z));
     return s * (1.0f + z * (1.0f - s));
 }
-// Round 4: the LARGE-IMAGE kernels (gn_apply / gn_bwd_stats / gn_bwd_apply) take the sigmoid from the hardware transcendentals -- v_exp_f32 (2^x,
-// 1 ulp) of -z * log2(e) and v_rcp_f32 (1 ulp): 4 VALU instructions instead of the ~25 of expf() + an IEEE division, <= 3 ulp of fp32 (tests: 1e-5
-// against fp64 torch).  They stream 134 MB tensors beside MFMA kernels that are bound by issue slots and board power: 27.87 -> 27.41 ms per 256 x 256
-// step (A/B of two builds alternating on one box).  The resident kernels keep expf(): the same change there measured +0.22 ms on the CIFAR step
-// (17.92 -> 18.15, three alternations) -- their time is the LDS / shuffle reduction, and the shorter arithmetic changed nothing but the schedule.
+// Round 4: the sigmoid from the hardware transcendentals -- v_exp_f32 (2^x, 1 ulp) of -z * log2(e) and v_rcp_f32 (1 ulp): 4 VALU instructions instead of
+// the ~25 of expf() + an IEEE division, <= 3 ulp of fp32 (tests: 1e-5 against fp64 torch).  An instruction census of the CIFAR step
+// (scripts/valu_census.sh, SQ_INSTS_VALU per kernel) puts a THIRD of all VALU wave-instructions in the GroupNorm kernels, which share the chip with
+// MFMA kernels bound by issue slots and board power.  Used by the large-image kernels (gn_apply / gn_bwd_stats / gn_bwd_apply: 28.10 -> 27.54 ms per
+// 256 x 256 step) and by the resident BACKWARD kernel (17.64 -> 17.54 ms per CIFAR step; same 124 VGPRs).  The resident FORWARD kernel keeps expf():
+// with the short form hipcc's schedule of gn_fwd_res_kernel<16, 256> spills 66 VGPRs (260 B of scratch per lane under the 128-VGPR budget of four
+// workgroups per CU; a sched_barrier per row piece does not cure it) and the step gets 0.22 ms SLOWER.
 __device__ __forceinline__ float gn_sigmoid_fast(float z) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__fmul_rn(z, -1.44269504088896341f)));
 }
@@ -709,7 +711,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_res_kernel(const float* __restrict_
         for (int j = 0; j < 4; ++j) {
             const float h = ok ? (in[j] - mu[j]) * rs[j] : 0.f;
             float d = dd[j];
-            if (silu) d *= silu_grad_dev(h * gg[j] + bb[j]);
+            if (silu) d *= silu_grad_fast(h * gg[j] + bb[j]);
             in[j] = h; dd[j] = d;
             s0[j] += d; s1[j] += d * h; s2[j] += h;
         }
