@@ -55,13 +55,24 @@ __device__ __forceinline__ float silu_grad_dev(float z) {
 // the ~25 of expf() + an IEEE division, <= 3 ulp of fp32 (tests: 1e-5 against fp64 torch).  An instruction census of the CIFAR step
 // (scripts/valu_census.sh, SQ_INSTS_VALU per kernel) puts a THIRD of all VALU wave-instructions in the GroupNorm kernels, which share the chip with
 // MFMA kernels bound by issue slots and board power.  Used by the large-image kernels (gn_apply / gn_bwd_stats / gn_bwd_apply: 28.10 -> 27.54 ms per
-// 256 x 256 step) and by the resident BACKWARD kernel (17.64 -> 17.54 ms per CIFAR step; same 124 VGPRs).  The resident FORWARD kernel keeps expf():
-// with the short form hipcc's schedule of gn_fwd_res_kernel<16, 256> spills 66 VGPRs (260 B of scratch per lane under the 128-VGPR budget of four
-// workgroups per CU; a sched_barrier per row piece does not cure it) and the step gets 0.22 ms SLOWER.
+// 256 x 256 step) and by the resident BACKWARD kernel (17.64 -> 17.54 ms per CIFAR step; same 124 VGPRs).  In the resident FORWARD kernel the intrinsic form
+// makes hipcc hoist all sixty-four v_exp_f32 of gn_fwd_res_kernel<16, 256> to the top of the apply loop and spill 66 VGPRs (260 B of scratch per lane under
+// the 128-VGPR budget of four workgroups per CU: the step got 0.22 ms SLOWER; a sched_barrier per row piece does not cure it).  silu_fast_pinned issues
+// the same two instructions as volatile asm, which keep their program order: 127 VGPRs / 12 B scratch like the expf() build, 18.03 -> 17.87 ms per CIFAR
+// step, DDIM-50 502 -> 511 samples/s.
 __device__ __forceinline__ float gn_sigmoid_fast(float z) {
     return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(__fmul_rn(z, -1.44269504088896341f)));
 }
 __device__ __forceinline__ float silu_fast(float z) { return z * gn_sigmoid_fast(z); }
+// the same two instructions as volatile asm: they keep their program order, so the scheduler cannot hoist sixty-four of them to the top of a loop nest
+__device__ __forceinline__ float silu_fast_pinned(float z) {
+    float e, r;
+    const float t = __fmul_rn(z, -1.44269504088896341f);
+    asm volatile("v_exp_f32 %0, %1\n\ts_nop 0" : "=v"(e) : "v"(t));
+    e += 1.0f;
+    asm volatile("v_rcp_f32 %0, %1\n\ts_nop 0" : "=v"(r) : "v"(e));
+    return z * r;
+}
 __device__ __forceinline__ float silu_grad_fast(float z) {
     const float s = gn_sigmoid_fast(z);
     return s * (1.0f + z * (1.0f - s));
@@ -644,7 +655,7 @@ __global__ __launch_bounds__(NT, NT == 256 ? 4 : 2) void gn_fwd_res_kernel(const
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
             const float z = (in[j] - mu[j]) * rs[j] * gg[j] + bb[j];
-            o[j] = silu ? silu_dev(z) : z;
+            o[j] = silu ? silu_fast_pinned(z) : z;
         }
         v[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
