@@ -984,6 +984,13 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
 // LDS: two dY stages (2 x 16 KB) + the X ring (64 KB) = 96 KB, one workgroup per CU.
 constexpr int WG3_RING_UNITS = 8, WG3_UNIT_BYTES = 16 * 512;
 constexpr int WG3_LDS_BYTES = 2 * WG_OP_BYTES + WG3_RING_UNITS * WG3_UNIT_BYTES;
+// Compile-time ablation of conv_ps_wgrad3_kernel (timing experiments, scripts/abl_wg3.sh; results are wrong by design): 1 no steady-state DMA,
+// 2 no MFMA, 4 no X fragment reads, 16 no barrier, 32 no epilogue stores, 64 no main loop.  Compile-time because the run-time form of these
+// switches (-DBD_PS_ABLATION, p.ablate) made this kernel 5x slower by itself; DESIGN.md section 3 has the decomposition they gave.
+#ifndef BD_WG3_ABL
+#define BD_WG3_ABL 0
+#endif
+constexpr int WG3_ABL = BD_WG3_ABL;
 
 __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
     __shared__ __attribute__((aligned(128))) char smem[WG3_LDS_BYTES];
@@ -1009,6 +1016,7 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
     const int c_begin = zz * p.cps;
     int c_end = c_begin + p.cps;
     if (c_end > nchunks) c_end = nchunks;
+    if constexpr ((WG3_ABL & 64) != 0) c_end = c_begin;
 
     // ---- DMA: wave w moves pixel pairs w and w + 8 of a 32-pixel chunk; lane: pixel k = 2*pair + lane/32, 16-byte slot lane%32
     const int ps = lane & 31;
@@ -1080,6 +1088,13 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
     // one 16-pixel step of one tap: X fragments (two 32-channel tiles x hi / lo x two pixel halves)
     struct BFrag { ps_short4 b0[2][2], b1[2][2]; };
     auto readB = [&](BFrag& f, unsigned xbase) {
+        if constexpr ((WG3_ABL & 4) != 0) {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) f.b0[q][pl] = f.b1[q][pl] = ps_short4{0x3f80, 0x3f80, 0x3f80, 0x3f80};
+            return;
+        }
 #pragma unroll
         for (int q = 0; q < 2; ++q)
 #pragma unroll
@@ -1140,6 +1155,7 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
             if (i == 1) readA(fa[1], dbase, 1);
             __builtin_amdgcn_sched_barrier(0);
             const bf16x8 ah = ps_tr_join(fa[S].a0[0], fa[S].a1[0]), al = ps_tr_join(fa[S].a0[1], fa[S].a1[1]);
+            if constexpr ((WG3_ABL & 2) != 0) { asm volatile("" ::"v"(ah), "v"(al), "v"(fb[i & 1].b0[0][0]), "v"(fb[i & 1].b1[1][1])); } else
             if (ok[i]) tap_mfmas(acc[ky], ah, al, fb[i & 1]);
             if (do_db && ky == 0) {
                 accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);
@@ -1158,8 +1174,8 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
         issue_dy(c_begin); issue_x(c_begin);
         for (int c = c_begin; c < c_end; ++c) {
             asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();
-            if (c + 1 < c_end) { issue_dy(c + 1); issue_x(c + 1); }
+            if constexpr ((WG3_ABL & 16) == 0) __builtin_amdgcn_s_barrier();
+            if (c + 1 < c_end && !((WG3_ABL & 1) && c > c_begin)) { issue_dy(c + 1); issue_x(c + 1); }
             compute(c);
         }
     }
@@ -1168,6 +1184,13 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
     const int li = lane & 31;
     const int M = p.Cout, N = 9 * p.Cin;
     float* out = p.out + (p.ksplit > 1 ? (long long)zz * M * N : 0);
+    if constexpr ((WG3_ABL & 32) != 0) {     // every accumulator stays live, nothing is stored
+        float t = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) t += accb[r] + acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r] + acc[2][0][r] + acc[2][1][r];
+        if (p.P < 0) out[lane] = t;
+        return;
+    }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
