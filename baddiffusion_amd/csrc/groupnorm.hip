@@ -357,74 +357,60 @@ __global__ __launch_bounds__(1024) void gn_bwd_param_batched_kernel(GnParamTable
     }
 }
 // ---- backward group finalize: per (b, g) s1 = sum gamma*dz, s2 = sum gamma*dz*xhat from the per-channel partials
-// (fixed order, fp64); optional per-sample column sums of dx in closed form (see gn_bwd_res_kernel).  One block per sample.
-// grid = (B, ceil(G / 8)): 8 groups per block, 32 split phases per group folded with a butterfly (fixed order)
+// (fixed order, fp64); optional per-sample column sums of dx in closed form (see gn_bwd_res_kernel) and per-sample weight / bias gradient
+// partials.  Round 4 (late): ONE pass over the partials by grid = (B, G) blocks -- every (plane, channel) of the group is summed over the S splits
+// by 256 / (3 cpg) threads, folded through LDS in fixed order, and all four outputs derive from those totals.  The previous form (16 blocks of
+// 8 groups, three separate sweeps, up to S = 128 dependent-latency loads per thread) took 19 us per launch on the 256 x 256 network's large
+// layers, in front of every backward apply.
 __global__ __launch_bounds__(256) void gn_bwd_finalize_kernel(const float* __restrict__ part, int HW, int C, int G, int S,
                                                             const float* __restrict__ gamma, const float* __restrict__ rstd,
                                                             float inv_n, float* __restrict__ ds /* [B][G][2] */,
                                                             float* __restrict__ dx_colsum, long long ld_colsum,
                                                             float* __restrict__ ppart /* optional [B][2][C]: per-sample dgamma / dbeta partials */) {
-    __shared__ float sg[8][2];
-    const int b = blockIdx.x, g0 = blockIdx.y * 8;
-    const int cpg = C / G;
-    const int gl = threadIdx.x >> 5, ph = threadIdx.x & 31, g = g0 + gl;
-    double a = 0.0, e = 0.0;
-    if (g < G)
-        for (int sp = ph; sp < S; sp += 32)
-            for (int c = g * cpg; c < (g + 1) * cpg; ++c) {
-                const float* p = part + ((long long)b * S + sp) * 3 * C + c;
-                e += (double)p[0] * gamma[c];
-                a += (double)p[C] * gamma[c];
-            }
-    for (int off = 1; off < 32; off <<= 1) { a += __shfl_xor(a, off); e += __shfl_xor(e, off); }
-    if (ph == 0 && g < G) {
-        sg[gl][0] = (float)a; sg[gl][1] = (float)e;
-        ds[((long long)b * G + g) * 2] = (float)a;
-        ds[((long long)b * G + g) * 2 + 1] = (float)e;
-    }
-    __syncthreads();
-    if (ppart) {
-        // per-sample weight / bias gradient partials of this block's channels (fp64 over the S splits, fixed order): the batch
-        // sum is left to ONE bd_gn_bwd_params launch per backward segment instead of a launch per layer (round 4: large-image path too)
-        int ng = G - g0;
-        if (ng > 8) ng = 8;
-        const int nch = ng * cpg, items = 2 * nch;
-        int tpc = 1;                      // threads per (plane, channel): a power of two of contiguous lanes, splits strided, butterfly fold
-        while (tpc < 32 && tpc * 2 * items <= 256) tpc *= 2;
-        const int sub = threadIdx.x % tpc;
-        for (int base = 0; base < items; base += 256 / tpc) {      // block-uniform trip count: every lane reaches the shuffles
-            const int i = base + threadIdx.x / tpc;
-            const int plane = i < nch ? 0 : 1, c = g0 * cpg + (i < nch ? i : i - nch);
-            double s = 0.0;
-            if (i < items)
-                for (int sp = sub; sp < S; sp += tpc) s += (double)part[((long long)b * S + sp) * 3 * C + plane * C + c];
-            for (int off = 1; off < tpc; off <<= 1) s += __shfl_xor(s, off);
-            if (i < items && sub == 0) ppart[((long long)b * 2 + plane) * C + c] = (float)s;
+    extern __shared__ double gn_fin_sh[];          // red[256] + tot[3 * cpg] + sg[2]
+    double* red = gn_fin_sh;
+    double* tot = gn_fin_sh + 256;
+    const int b = blockIdx.x, g = blockIdx.y;
+    const int cpg = C / G, items = 3 * cpg;        // (plane, channel) pairs of this group; planes: 0 = sum dz xhat, 1 = sum dz, 2 = sum xhat-side term
+    double* sg = tot + items;
+    const int nsub = items <= 256 ? 256 / items : 1;
+    const int t = threadIdx.x;
+    for (int base = 0; base < items; base += 256) {          // one trip unless cpg > 85
+        const int it = base + (nsub > 1 ? t % items : t), sub = nsub > 1 ? t / items : 0;
+        double s = 0.0;
+        if (it < items && sub < nsub) {
+            const int plane = it / cpg, c = g * cpg + it - plane * cpg;
+            const float* p = part + ((long long)b * S * 3 + plane) * C + c;
+            for (int sp = sub; sp < S; sp += nsub) s += (double)p[(long long)sp * 3 * C];
         }
+        red[t] = s;
+        __syncthreads();
+        if (base + t < items && t < (nsub > 1 ? items : 256)) {
+            double v = red[t];
+            for (int k = 1; k < nsub; ++k) v += red[k * items + t];
+            tot[base + t] = v;
+        }
+        __syncthreads();
     }
+    if (t < 2) {                                   // t = 0: s1 = sum gamma * plane 1, t = 1: s2 = sum gamma * plane 0
+        double v = 0.0;
+        const double* q = tot + (t == 0 ? cpg : 0);
+        for (int c = 0; c < cpg; ++c) v += q[c] * (double)gamma[g * cpg + c];
+        sg[t] = v;
+        ds[((long long)b * G + g) * 2 + t] = (float)v;
+    }
+    if (ppart)
+        for (int i = t; i < 2 * cpg; i += 256) {
+            const int plane = i / cpg, c = g * cpg + i - plane * cpg;
+            ppart[((long long)b * 2 + plane) * C + c] = (float)tot[i];
+        }
     if (dx_colsum) {
-        // channels of this block's groups; tpc threads per channel (a power of two, contiguous lanes), splits strided
-        int ng = G - g0;
-        if (ng > 8) ng = 8;
-        const int nch = ng * cpg;
-        int tpc = 1;
-        while (tpc < 32 && tpc * 2 * nch <= 256) tpc *= 2;
-        const int sub = threadIdx.x % tpc;
-        for (int base = 0; base < nch; base += 256 / tpc) {   // block-uniform trip count: every lane reaches the shuffles
-            const int cl = base + threadIdx.x / tpc;
-            float sa = 0.f, sh2 = 0.f;
-            if (cl < nch)
-                for (int sp = sub; sp < S; sp += tpc) {
-                    const float* p = part + ((long long)b * S + sp) * 3 * C + g0 * cpg + cl;
-                    sa += p[C];
-                    sh2 += p[2 * C];
-                }
-            for (int off = 1; off < tpc; off <<= 1) { sa += __shfl_xor(sa, off); sh2 += __shfl_xor(sh2, off); }
-            if (cl < nch && sub == 0) {
-                const int c = g0 * cpg + cl, gi = cl / cpg;
-                dx_colsum[(long long)b * ld_colsum + c] =
-                    rstd[b * G + g0 + gi] * (gamma[c] * sa - ((float)HW * sg[gi][0] + sg[gi][1] * sh2) * inv_n);
-            }
+        __syncthreads();
+        const float s1 = (float)sg[0], s2 = (float)sg[1], rs = rstd[b * G + g];
+        for (int cl = t; cl < cpg; cl += 256) {
+            const int c = g * cpg + cl;
+            const float sa = (float)tot[cpg + cl], sh2 = (float)tot[2 * cpg + cl];
+            dx_colsum[(long long)b * ld_colsum + c] = rs * (gamma[c] * sa - ((float)HW * s1 + s2 * sh2) * inv_n);
         }
     }
 }
@@ -993,8 +979,9 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
     {
         const int per = gn_apply_rows(d->HW, r);
         const float inv_n = 1.0f / ((float)d->HW * (d->C / d->G));
-        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(d->B, (unsigned)cdiv(d->G, 8)), dim3(256), 0, S(stream), part, d->HW, d->C, d->G,
-                           S_, d->gamma, d->rstd, inv_n, ds, d->dx_colsum, (long long)d->ld_colsum, d->param_partials);
+        hipLaunchKernelGGL(gn_bwd_finalize_kernel, dim3(d->B, (unsigned)d->G), dim3(256), (size_t)(256 + 3 * (d->C / d->G) + 2) * sizeof(double),
+                           S(stream), part, d->HW, d->C, d->G, S_, d->gamma, d->rstd, inv_n, ds, d->dx_colsum, (long long)d->ld_colsum,
+                           d->param_partials);
         hipLaunchKernelGGL(gn_bwd_apply_kernel, dim3((unsigned)cdiv(d->HW, per), d->B), dim3(threads), 0, S(stream), d->x,
                            (long long)d->ldx, d->dy, (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, r, per, ds,
                            d->gamma, d->beta, d->mean, d->rstd, inv_n, d->silu, d->accumulate_dx, d->dx_split,
