@@ -60,6 +60,7 @@ SHAPES = {
               (128, 64, 512), (128, 16, 512)],
     "sample": [(512, 1024, 128), (512, 1024, 256), (512, 1024, 384), (512, 256, 256), (512, 256, 512), (512, 64, 512)],
     # 256 x 256 step, B = 4 (forward as two half batches of 2)
+    "pmc": [(128, 1024, 128), (128, 1024, 256), (128, 1024, 384), (128, 256, 384), (512, 1024, 128), (4, 65536, 128)],      # scripts/probes/gn_pmc.sh
     "celeba": [(2, 65536, 128), (4, 65536, 128), (4, 65536, 256), (4, 16384, 128), (4, 16384, 256), (4, 4096, 256), (4, 4096, 512),
                (4, 1024, 256), (4, 1024, 512), (4, 1024, 768), (4, 256, 512), (4, 256, 1024), (4, 64, 512), (4, 64, 1024)],
 }
@@ -69,7 +70,7 @@ if __name__ == "__main__":
     print(f"{'set':8s} {'B':>4s} {'HW':>6s} {'C':>5s} {'MB':>7s} | {'fwd us':>8s} {'GB/s(2x)':>9s} {'GB/s(3x)':>9s} | {'bwd us':>8s} {'GB/s(4x)':>9s} {'GB/s(6x)':>9s}")
     for w in which:
         for (B, HW, Cc) in SHAPES[w]:
-            tf, tb, n, res = run(B, HW, Cc)
+            tf, tb, n, res = run(B, HW, Cc, reps=2 if w == "pmc" else 20)
             # forward: 2x = x once + planes; 3x = x twice + planes (large-image path).  backward: 4x = x, dy, dx, planes; 6x = x, dy twice
             print(f"{w:8s} {B:4d} {HW:6d} {Cc:5d} {n / 1e6:7.1f} | {tf:8.1f} {2 * n / tf / 1e3:9.0f} {3 * n / tf / 1e3:9.0f} | "
                   f"{tb:8.1f} {4 * n / tb / 1e3:9.0f} {6 * n / tb / 1e3:9.0f}", flush=True)
