@@ -326,6 +326,42 @@ def test_groupnorm_large_image_path_round4(gpu):
         assert relerr(dg1, dg0) < 1e-6 and relerr(db1, db0) < 1e-6
 
 
+@pytest.mark.parametrize("B,HW,Cc,G", [(2, 4096, 256, 2), (3, 4096, 96, 8), (2, 8192, 128, 32), (1, 4096, 1024, 32)])
+def test_groupnorm_large_image_group_finalize_shapes(gpu, B, HW, Cc, G):
+    """The one-pass group finalize of the large-image backward (grid = (B, G); round 4): group sizes from 4 to 128 channels -- 3 x 128 (plane,
+    channel) sums exceed the 256 threads of a block, the looped form -- with the closed-form per-sample column sum of dx and the per-sample
+    weight / bias gradient partials taken from the same totals.  dx, dgamma, dbeta against fp64 torch (normalization.py / resnet.py:559): 1e-5;
+    the column sum against the sum of the dx it describes: 1e-4 of its scale."""
+    import ctypes as CT
+    import torch.nn.functional as F
+    from baddiffusion_amd import _lib as L, ops
+    lib = L.load()
+    torch.manual_seed(B * 1000 + Cc + G)
+    x = torch.randn(B, HW, Cc, device=gpu) * 1.5 - 0.3; dy = torch.randn(B, HW, Cc, device=gpu)
+    ga = torch.randn(Cc, device=gpu); be = torch.randn(Cc, device=gpu)
+    y, mean, rstd = ops.gn_fwd(x, ga, be, G, 1e-6, True)
+    x64 = x.double().cpu().permute(0, 2, 1).reshape(B, Cc, HW, 1).requires_grad_(True)
+    g64 = ga.double().cpu().requires_grad_(True); b64 = be.double().cpu().requires_grad_(True)
+    F.silu(F.group_norm(x64, G, g64, b64, 1e-6)).backward(dy.double().cpu().permute(0, 2, 1).reshape(B, Cc, HW, 1))
+    dx, dg, db, cs = ops.gn_bwd(x, ga, be, mean, rstd, dy, G, True, with_colsum=True)
+    ref_dx = x64.grad.reshape(B, Cc, HW).permute(0, 2, 1)
+    assert relerr(dx, ref_dx) < 1e-5 and relerr(dg, g64.grad) < 1e-5 and relerr(db, b64.grad) < 1e-5
+    ref_cs = ref_dx.sum(1)
+    assert float((cs.double().cpu() - ref_cs).abs().max()) < 1e-4 * float(ref_dx.abs().sum(1).max())
+    # deferred form: the per-sample partials fold to the same gradients
+    part = torch.empty(B, 2, Cc, device=gpu); dx2 = torch.empty_like(x)
+    dg2 = torch.empty(Cc, device=gpu); db2 = torch.empty(Cc, device=gpu)
+    ws = ops.workspace(lib.bd_gn_workspace_bytes(B, Cc), x.device)
+    d = L.GnBwdDesc(B=B, HW=HW, C=Cc, G=G, silu=1, x=L.ptr(x), ldx=Cc, gamma=L.ptr(ga), beta=L.ptr(be), mean=L.ptr(mean), rstd=L.ptr(rstd),
+                    dy=L.ptr(dy), lddy=Cc, dx=L.ptr(dx2), lddx=Cc, accumulate_dx=0, dgamma=L.ptr(dg2), dbeta=L.ptr(db2), workspace=L.ptr(ws),
+                    workspace_bytes=ws.numel(), param_partials=L.ptr(part))
+    L.check(lib.bd_gn_bwd(CT.byref(d), L.stream()))
+    items = (L.GnParamItem * 1)()
+    items[0].partials = L.ptr(part); items[0].C = Cc; items[0].dgamma = L.ptr(dg2); items[0].dbeta = L.ptr(db2)
+    L.check(lib.bd_gn_bwd_params(items, 1, B, L.stream()))
+    assert torch.equal(dx, dx2) and relerr(dg2, dg) < 1e-6 and relerr(db2, db) < 1e-6
+
+
 @pytest.mark.parametrize("topology,batch", [("google/ddpm-cifar10-32", 40), ("google/ddpm-ema-celebahq-256", 1)])
 def test_round4_paths_equal_their_fallbacks(gpu, tmp_path, topology, batch):
     """Every plan / kernel path added in round 4 against the path it replaces, on whole networks (each knob is read once per process, hence
