@@ -22,6 +22,10 @@ import os
 import sys
 import time
 
+# multi-process GPU work on this ROCm stack needs dmabuf IPC (RCCL / CUDA-tensor sharing across ranks fail with hipIpcGetMemHandle: invalid
+# argument otherwise); the driver's environment exports it, a bare shell may not
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 import numpy as np
 import torch
 import torch.distributed as dist
