@@ -504,6 +504,11 @@ static bool gn_resident_plan(int B, int HW, int C, int G, GnRes& o, bool wide_ok
             if (cdiv(HW, nt / q) <= GN_RES_EMAX && cb / cpg <= 256) best = cb;
         }
         if (!best || (best < 16 && best < C)) continue;   // rows narrower than 64 B: the split kernels coalesce better
+        // round 4 (late): a slab whose row pieces are not whole 64-byte halves of a line (12 channels per group at 32 x 32: 24 channels = 96 B rows,
+        // 48-byte half planes) writes 1.3 - 1.4x its bytes (PMC, profiles/r04_gn_pmc_by_shape.txt) and runs at 2.8 TB/s: the two-pass kernels,
+        // whose rows are whole, are faster there although they read x twice
+        static const int row_align = getenv("BD_GN_RES_ALIGN") ? atoi(getenv("BD_GN_RES_ALIGN")) : 64;      // (A/B knob: 0 = round 3's rule)
+        if (row_align > 0 && (best * 4) % row_align != 0 && best < C) continue;
         while ((long long)B * (C / best) < 512) {
             const int half = best / 2;
             if (half < 16 || half % unit || C % half) break;

@@ -61,6 +61,7 @@ SHAPES = {
     "sample": [(512, 1024, 128), (512, 1024, 256), (512, 1024, 384), (512, 256, 256), (512, 256, 512), (512, 64, 512)],
     # 256 x 256 step, B = 4 (forward as two half batches of 2)
     "pmc": [(128, 1024, 128), (128, 1024, 256), (128, 1024, 384), (128, 256, 384), (512, 1024, 128), (4, 65536, 128)],      # scripts/probes/gn_pmc.sh
+    "c384": [(64, 1024, 384), (128, 1024, 384), (512, 1024, 384), (128, 256, 384)],
     "celeba": [(2, 65536, 128), (4, 65536, 128), (4, 65536, 256), (4, 16384, 128), (4, 16384, 256), (4, 4096, 256), (4, 4096, 512),
                (4, 1024, 256), (4, 1024, 512), (4, 1024, 768), (4, 256, 512), (4, 256, 1024), (4, 64, 512), (4, 64, 1024)],
 }
