@@ -978,7 +978,10 @@ __global__ __launch_bounds__(NW * 64, NW == 8 ? 2 : 2) void conv_ps_wgrad_kernel
 // dW[co][(ky, kx)][ci] = sum_p dY[p][co] * X[p + (ky-1) W + (kx-1)][ci]: for a fixed kx the three ky taps contract the SAME dY rows
 // with X rows W pixels apart, and consecutive 32-pixel chunks slide that window by 32: every X pixel is DMA'd ONCE into a ring of
 // eight 16-pixel units and read by the three taps from three chunks; the dY fragments are read once for three taps.  Tile = 128 co x
-// (3 taps x 128 ci), 8 waves of 32 x (3 x 64), 96 accumulator registers; L2 -> LDS bytes per MFMA a third of conv_ps_wgrad_kernel's.
+// (3 taps x 128 ci), 8 waves (2 x 4) of 64 co x (3 taps x 32 ci), 96 accumulator registers; L2 -> LDS bytes per MFMA a third of
+// conv_ps_wgrad_kernel's.  (Round 4, late: the wave tile was 32 co x (3 x 64 ci) -- 4 dY + 3 x 8 X fragment reads per 18 MFMAs; the dY fragments are
+// the ones shared by the three taps, so the taller tile reads 8 + 3 x 4 = 20 instead of 28: stand-alone within 1 %, CIFAR step -0.11 ... -0.19 ms on
+// two boxes -- the kernel shares the chip with the data-gradient chain, and what it does not read from LDS it does not draw from the power budget.)
 // A tap whose X row falls outside the image is skipped for that 16-pixel step (a step never straddles image rows: W % 16 == 0), so no
 // zero rows are needed for the vertical direction; columns shifted out of the image read the zero page as before.
 // LDS: two dY stages (2 x 16 KB) + the X ring (64 KB) = 96 KB, one workgroup per CU.
@@ -997,7 +1000,7 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave >> 2, wn = wave & 3;       // wave tile = 64 co (two 32-row blocks) x 3 taps x 32 ci: 20 fragment reads per 18 MFMAs (32 x 64: 28)
     int tm, tn, zz;
     {
         const unsigned L = blockIdx.x, T = gridDim.x, q = T >> 3;
@@ -1063,20 +1066,20 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
 #pragma unroll
     for (int v = 0; v < 4; ++v) xw[v] = (v ^ kq) << 6;
     auto foff = [&](int t, int plane) { return lane_base + xw[(t & 1) * 2 + plane] + (t >> 1) * 256; };
-    unsigned aoff[2], boff[2][2];
+    unsigned aoff[2][2], boff[2];
 #pragma unroll
-    for (int pl = 0; pl < 2; ++pl) aoff[pl] = (unsigned)foff(wm, pl);
+    for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int q = 0; q < 2; ++q)
+        for (int pl = 0; pl < 2; ++pl) aoff[i][pl] = (unsigned)foff(wm * 2 + i, pl);
 #pragma unroll
-        for (int pl = 0; pl < 2; ++pl) boff[q][pl] = (unsigned)foff(wn * 2 + q, pl);
+    for (int pl = 0; pl < 2; ++pl) boff[pl] = (unsigned)foff(wn, pl);
     const unsigned smem_addr = (unsigned)(uintptr_t)(lds_ptr)smem;
     const unsigned ring_addr = smem_addr + 2 * WG_OP_BYTES;
 
-    floatx16 acc[3][2], accb;
+    floatx16 acc[3][2], accb[2];          // acc[tap][co block]
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
-        accb[r] = 0.f;
+        accb[0][r] = 0.f; accb[1][r] = 0.f;
 #pragma unroll
         for (int t = 0; t < 3; ++t) { acc[t][0][r] = 0.f; acc[t][1][r] = 0.f; }
     }
@@ -1085,47 +1088,44 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) ones[j] = (__bf16)1.0f;
 
-    // one 16-pixel step of one tap: X fragments (two 32-channel tiles x hi / lo x two pixel halves)
-    struct BFrag { ps_short4 b0[2][2], b1[2][2]; };
+    // one 16-pixel step of one tap: X fragments (one 32-channel tile x hi / lo x two pixel halves)
+    struct BFrag { ps_short4 b0[2], b1[2]; };
     auto readB = [&](BFrag& f, unsigned xbase) {
         if constexpr ((WG3_ABL & 4) != 0) {
 #pragma unroll
-            for (int q = 0; q < 2; ++q)
-#pragma unroll
-                for (int pl = 0; pl < 2; ++pl) f.b0[q][pl] = f.b1[q][pl] = ps_short4{0x3f80, 0x3f80, 0x3f80, 0x3f80};
+            for (int pl = 0; pl < 2; ++pl) f.b0[pl] = f.b1[pl] = ps_short4{0x3f80, 0x3f80, 0x3f80, 0x3f80};
             return;
         }
 #pragma unroll
-        for (int q = 0; q < 2; ++q)
-#pragma unroll
-            for (int pl = 0; pl < 2; ++pl) {
-                f.b0[q][pl] = ps_tr_read<0>(xbase + boff[q][pl]);
-                f.b1[q][pl] = ps_tr_read<4 * 512>(xbase + boff[q][pl]);
-            }
-    };
-    auto waitB = [&](BFrag& f) {
-        asm volatile("s_waitcnt lgkmcnt(0)"
-                     : "+v"(f.b0[0][0]), "+v"(f.b1[0][0]), "+v"(f.b0[0][1]), "+v"(f.b1[0][1]), "+v"(f.b0[1][0]), "+v"(f.b1[1][0]), "+v"(f.b0[1][1]),
-                       "+v"(f.b1[1][1]));
-    };
-    struct AFrag { ps_short4 a0[2], a1[2]; };
-    auto readA = [&](AFrag& f, unsigned dbase, int S) {
-#pragma unroll
         for (int pl = 0; pl < 2; ++pl) {
-            f.a0[pl] = S ? ps_tr_read<16 * 512>(dbase + aoff[pl]) : ps_tr_read<0>(dbase + aoff[pl]);
-            f.a1[pl] = S ? ps_tr_read<16 * 512 + 4 * 512>(dbase + aoff[pl]) : ps_tr_read<4 * 512>(dbase + aoff[pl]);
+            f.b0[pl] = ps_tr_read<0>(xbase + boff[pl]);
+            f.b1[pl] = ps_tr_read<4 * 512>(xbase + boff[pl]);
         }
     };
-    auto tap_mfmas = [&](floatx16 (&a)[2], bf16x8 ah, bf16x8 al, const BFrag& f) {
-        bf16x8 bh[2], bl[2];
+    auto waitB = [&](BFrag& f) { asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(f.b0[0]), "+v"(f.b1[0]), "+v"(f.b0[1]), "+v"(f.b1[1])); };
+    struct AFrag { ps_short4 a0[2][2], a1[2][2]; };      // [co block][plane]
+    auto readA = [&](AFrag& f, unsigned dbase, int S) {
 #pragma unroll
-        for (int q = 0; q < 2; ++q) { bh[q] = ps_tr_join(f.b0[q][0], f.b1[q][0]); bl[q] = ps_tr_join(f.b0[q][1], f.b1[q][1]); }
+        for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) a[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh[q], a[q], 0, 0, 0);
+            for (int pl = 0; pl < 2; ++pl) {
+                f.a0[i][pl] = S ? ps_tr_read<16 * 512>(dbase + aoff[i][pl]) : ps_tr_read<0>(dbase + aoff[i][pl]);
+                f.a1[i][pl] = S ? ps_tr_read<16 * 512 + 4 * 512>(dbase + aoff[i][pl]) : ps_tr_read<4 * 512>(dbase + aoff[i][pl]);
+            }
+    };
+    auto waitA = [&](AFrag& f) {
+        asm volatile("s_waitcnt lgkmcnt(0)"
+                     : "+v"(f.a0[0][0]), "+v"(f.a1[0][0]), "+v"(f.a0[0][1]), "+v"(f.a1[0][1]), "+v"(f.a0[1][0]), "+v"(f.a1[1][0]), "+v"(f.a0[1][1]),
+                       "+v"(f.a1[1][1]));
+    };
+    auto tap_mfmas = [&](floatx16 (&a)[2], const bf16x8 (&ah)[2], const bf16x8 (&al)[2], const BFrag& f) {
+        const bf16x8 bh = ps_tr_join(f.b0[0], f.b1[0]), bl = ps_tr_join(f.b0[1], f.b1[1]);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) a[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl[q], a[q], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) a[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh, a[i], 0, 0, 0);
 #pragma unroll
-        for (int q = 0; q < 2; ++q) a[q] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh[q], a[q], 0, 0, 0);
+        for (int i = 0; i < 2; ++i) a[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl, a[i], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < 2; ++i) a[i] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh, a[i], 0, 0, 0);
     };
 
     const int wu = VW >> 4;        // units per (virtual) image row
@@ -1146,7 +1146,7 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
         AFrag fa[2]; BFrag fb[2];
         readA(fa[0], dbase, 0);
         readB(fb[0], xb[0]);
-        asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[0].a0[0]), "+v"(fa[0].a1[0]), "+v"(fa[0].a0[1]), "+v"(fa[0].a1[1]));
+        waitA(fa[0]);
         waitB(fb[0]);
 #pragma unroll
         for (int i = 0; i < 6; ++i) {
@@ -1154,16 +1154,20 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
             if (i + 1 < 6) readB(fb[(i + 1) & 1], xb[i + 1]);
             if (i == 1) readA(fa[1], dbase, 1);
             __builtin_amdgcn_sched_barrier(0);
-            const bf16x8 ah = ps_tr_join(fa[S].a0[0], fa[S].a1[0]), al = ps_tr_join(fa[S].a0[1], fa[S].a1[1]);
-            if constexpr ((WG3_ABL & 2) != 0) { asm volatile("" ::"v"(ah), "v"(al), "v"(fb[i & 1].b0[0][0]), "v"(fb[i & 1].b1[1][1])); } else
+            const bf16x8 ah[2] = {ps_tr_join(fa[S].a0[0][0], fa[S].a1[0][0]), ps_tr_join(fa[S].a0[1][0], fa[S].a1[1][0])};
+            const bf16x8 al[2] = {ps_tr_join(fa[S].a0[0][1], fa[S].a1[0][1]), ps_tr_join(fa[S].a0[1][1], fa[S].a1[1][1])};
+            if constexpr ((WG3_ABL & 2) != 0) { asm volatile("" ::"v"(ah[0]), "v"(al[0]), "v"(ah[1]), "v"(al[1]), "v"(fb[i & 1].b0[0]), "v"(fb[i & 1].b1[1])); } else
             if (ok[i]) tap_mfmas(acc[ky], ah, al, fb[i & 1]);
             if (do_db && ky == 0) {
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, ones, accb, 0, 0, 0);
-                accb = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, ones, accb, 0, 0, 0);
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[j], ones, accb[j], 0, 0, 0);
+                    accb[j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[j], ones, accb[j], 0, 0, 0);
+                }
             }
             __builtin_amdgcn_sched_barrier(0);
             if (i + 1 < 6) {
-                if (i == 1) asm volatile("s_waitcnt lgkmcnt(0)" : "+v"(fa[1].a0[0]), "+v"(fa[1].a1[0]), "+v"(fa[1].a0[1]), "+v"(fa[1].a1[1]));
+                if (i == 1) waitA(fa[1]);
                 waitB(fb[(i + 1) & 1]);
             }
         }
@@ -1187,25 +1191,27 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
     if constexpr ((WG3_ABL & 32) != 0) {     // every accumulator stays live, nothing is stored
         float t = 0.f;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) t += accb[r] + acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r] + acc[2][0][r] + acc[2][1][r];
+        for (int r = 0; r < 16; ++r) t += accb[0][r] + accb[1][r] + acc[0][0][r] + acc[0][1][r] + acc[1][0][r] + acc[1][1][r] + acc[2][0][r] + acc[2][1][r];
         if (p.P < 0) out[lane] = t;
         return;
     }
 #pragma unroll
     for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
-        for (int q = 0; q < 2; ++q) {
-            const int nn = (ky * 3 + kx) * p.Cin + ci0 + wn * 64 + q * 32 + li;
+        for (int i = 0; i < 2; ++i) {
+            const int nn = (ky * 3 + kx) * p.Cin + ci0 + wn * 32 + li;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int m = co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                out[(long long)m * N + nn] = acc[ky][q][r];
+                const int m = co0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                out[(long long)m * N + nn] = acc[ky][i][r];
             }
         }
     if (do_db && li == 0) {
         float* o = p.ksplit > 1 ? p.out + (long long)p.ksplit * M * N + (long long)zz * M : p.db;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) o[co0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = accb[r];
+        for (int i = 0; i < 2; ++i)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) o[co0 + (wm * 2 + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * h] = accb[i][r];
     }
 }
 
