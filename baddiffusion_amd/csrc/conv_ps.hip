@@ -1510,7 +1510,10 @@ static void ps_wgrad_split(const bd_conv3x3_ps_wgrad_desc& d, int& ksplit, int& 
         const char* e = getenv("BD_PS_WG_SLOTS");
         return e ? atoi(e) : 2 * cus;   // two 64-KB workgroups per CU (two LDS stages each): the pair de-phases, 141 vs 189 us
     }();
-    static const int slots3 = getenv("BD_PS_WG3_SLOTS") ? atoi(getenv("BD_PS_WG3_SLOTS")) : slots / 2;   // 96 KB of LDS: one workgroup per CU
+    // 96 KB of LDS: one workgroup per CU -- and three quarters of the CUs (round 4, late: 192 of 256).  The kernel never runs alone: the data-gradient
+    // chain shares the chip with it, so the CUs it leaves are not idle, and a quarter fewer slabs are a quarter less slab traffic: CIFAR step
+    // 17.71 -> 17.53 ms and 18.01 -> 17.89 on two boxes (160 / 176 / 208 / 224 / 256 slots: 17.70 / 17.59 / 17.67 / 17.72 / 17.71), 256 x 256 28.06 -> 27.93.
+    static const int slots3 = getenv("BD_PS_WG3_SLOTS") ? atoi(getenv("BD_PS_WG3_SLOTS")) : slots * 3 / 8;
     static const int mincps = getenv("BD_PS_WG_MINCPS") ? atoi(getenv("BD_PS_WG_MINCPS")) : 8;   // chunks per split at least (4x4 layers: 8 slabs instead of 14; 4 / 16 measured +0.2 / +0.1 ms)
     int ks = (int)((v3 ? slots3 : slots) / tiles);
     if (ks < 1) ks = 1;
