@@ -41,16 +41,16 @@ int prof_begin(const char* name, double flops, double bytes, hipStream_t st) {
     g_cls[c].launches++; g_cls[c].flops += flops; g_cls[c].bytes += bytes;
     ProfRec r; r.cls = c; r.a = get_event(); r.b = get_event();
     if (!r.a || !r.b) return -1;
-    hipEventRecord(r.a, st);
+    (void)hipEventRecord(r.a, st);
     g_recs.push_back(r);
     return (int)g_recs.size() - 1;
 }
 void prof_end(int rec, hipStream_t st) {
-    if (rec >= 0) hipEventRecord(g_recs[rec].b, st);
+    if (rec >= 0) (void)hipEventRecord(g_recs[rec].b, st);
 }
 static void drain() {
     for (auto& r : g_recs) {
-        hipEventSynchronize(r.b);
+        (void)hipEventSynchronize(r.b);
         float ms = 0.f;
         if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) g_cls[r.cls].ms += ms;
     }
