@@ -1513,7 +1513,11 @@ static void ps_wgrad_split(const bd_conv3x3_ps_wgrad_desc& d, int& ksplit, int& 
     // 96 KB of LDS: one workgroup per CU -- and three quarters of the CUs (round 4, late: 192 of 256).  The kernel never runs alone: the data-gradient
     // chain shares the chip with it, so the CUs it leaves are not idle, and a quarter fewer slabs are a quarter less slab traffic: CIFAR step
     // 17.71 -> 17.53 ms and 18.01 -> 17.89 on two boxes (160 / 176 / 208 / 224 / 256 slots: 17.70 / 17.59 / 17.67 / 17.72 / 17.71), 256 x 256 28.06 -> 27.93.
-    static const int slots3 = getenv("BD_PS_WG3_SLOTS") ? atoi(getenv("BD_PS_WG3_SLOTS")) : slots * 3 / 8;
+    // Images walked strip by strip (W > 32: the 256 x 256 network at B = 4, whose main stream carries the three-pass GroupNorm and 2 048-tile data
+    // gradients): HALF the CUs -- 27.14 -> 26.69 ms per step (144 / 160 / 176 slots: 27.52 / 27.51 / 27.74; 112 / 96 / 64: 27.21 / 28.16 / 32.9), while the
+    // CIFAR step wants its 192 (128: 18.08 against 17.89).
+    static const int slots3_env = getenv("BD_PS_WG3_SLOTS") ? atoi(getenv("BD_PS_WG3_SLOTS")) : 0;
+    const int slots3 = slots3_env > 0 ? slots3_env : (d.W > 32 ? slots / 4 : slots * 3 / 8);
     static const int mincps = getenv("BD_PS_WG_MINCPS") ? atoi(getenv("BD_PS_WG_MINCPS")) : 8;   // chunks per split at least (4x4 layers: 8 slabs instead of 14; 4 / 16 measured +0.2 / +0.1 ms)
     int ks = (int)((v3 ? slots3 : slots) / tiles);
     if (ks < 1) ks = 1;
