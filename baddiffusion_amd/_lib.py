@@ -44,7 +44,7 @@ class GnFwdDesc(C.Structure):
     _fields_ = [("B", i32), ("HW", i32), ("C", i32), ("G", i32), ("eps", f32), ("silu", i32),
                 ("x", vp), ("ldx", i64), ("gamma", vp), ("beta", vp), ("y", vp), ("ldy", i64),
                 ("mean", vp), ("rstd", vp), ("workspace", vp), ("workspace_bytes", sz),
-                ("y_split", vp), ("ldys", i64)]
+                ("y_split", vp), ("ldys", i64), ("stats", vp), ("stats_splits", i32)]
 
 
 class GnBwdDesc(C.Structure):
@@ -103,7 +103,7 @@ class ConvPsDesc(C.Structure):
     _fields_ = [("B", i32), ("H", i32), ("W", i32), ("K", i32), ("N", i32), ("direction", i32),
                 ("x_split", vp), ("ldx", i64), ("w_split", vp), ("bias", vp), ("rowbias", vp), ("ld_rowbias", i64),
                 ("residual", vp), ("ldr", i64), ("out_scale", f32), ("y", vp), ("ldy", i64), ("accumulate", i32),
-                ("workspace", vp), ("workspace_bytes", sz)]
+                ("workspace", vp), ("workspace_bytes", sz), ("gn_part", vp), ("gn_groups", i32)]
 
 
 class ConvPsWgradDesc(C.Structure):
@@ -161,6 +161,7 @@ SIGNATURES = {
     "bd_to_image": (i32, [vp, i32, i64, i32, i32, i32, i32, vp, vp, vp]),
     "bd_timestep_embedding": (i32, [vp, i32, i32, i32, i32, f32, vp, vp]),
     "bd_gn_workspace_bytes": (sz, [i32, i32]),
+    "bd_gn_fwd_takes_stats": (i32, [i32, i32, i32, i32]),
     "bd_gn_fwd": (i32, [C.POINTER(GnFwdDesc), vp]),
     "bd_gn_bwd": (i32, [C.POINTER(GnBwdDesc), vp]),
     "bd_lincomb": (i32, [i32, C.POINTER(vp), C.POINTER(f32), i64, i32, f32, vp, vp]),
@@ -180,6 +181,7 @@ SIGNATURES = {
     "bd_split_rows_ups2": (i32, [vp, i64, i32, i32, i32, i32, vp, i64, vp]),
     "bd_conv3x3_ps": (i32, [C.POINTER(ConvPsDesc), vp]),
     "bd_conv3x3_ps_workspace_bytes": (sz, [C.POINTER(ConvPsDesc)]),
+    "bd_conv3x3_ps_gn_splits": (i32, [i32, i32, i32, i32, i32, i32]),
     "bd_upsample_weights": (i32, [vp, i32, i32, vp, vp, vp]),
     "bd_upsample_conv_fwd": (i32, [C.POINTER(UpsampleConvDesc), vp]),
     "bd_upsample_conv_dgrad": (i32, [C.POINTER(UpsampleConvDesc), vp]),

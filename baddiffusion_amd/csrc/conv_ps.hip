@@ -48,6 +48,8 @@ struct PsParams {
     unsigned short* y_split; long long ldys;   // optional second output: y in split planes (same row count, ld)
     int ablate;            // -DBD_PS_ABLATION builds only (BD_PS_ABLATE): 1 = no steady-state DMA, 2 = no MFMA, 4 = no fragment reads
     int lvw;               // conv_ps3_kernel: log2 of the VIRTUAL image width min(W, 32), see ps_v2r
+    double* gn_part;       // conv_ps3_kernel, optional: [B][H*W/256][gn_G][2] partial (sum, sum of squares) of y per pixel tile and group
+    int gn_G, gn_lcpg;     //   groups of the GroupNorm that reads y next; log2(channels per group), 2 .. 5
 };
 
 // Round 4: VIRTUAL pixel order.  The vertical-tap-sharing kernels (conv_ps3_kernel, conv_ps_wgrad3_kernel) want the rows one image row
@@ -94,8 +96,11 @@ __device__ __forceinline__ void ps_sync() {
 // of ~64 serialised memory round trips per wave that used to be a large part of the per-tile overhead.
 // mb[i] = the output row of the first of the 32 consecutive rows of the wave's i-th 32 x 32 tile (consecutive in memory: a virtual-order
 // tile of conv_ps3_kernel is 8 image-row pieces of 32 pixels, see ps_v2r)
-template <int EPI, int TM, bool FULL>
-__device__ __forceinline__ void ps_epilogue(const PsParams& p, floatx16 (&acc)[TM][2], const int (&mb)[TM], int nw, int li, int h) {
+// STATS (round 4, conv_ps3_kernel only): st[q][0 / 1] += the lane's column sums of y and y * y over its 16 rows of every tile -- the
+// statistics of the GroupNorm that reads y next come out of this epilogue instead of a pass over y (ps3_gn_partials)
+template <int EPI, int TM, bool FULL, bool STATS = false>
+__device__ __forceinline__ void ps_epilogue(const PsParams& p, floatx16 (&acc)[TM][2], const int (&mb)[TM], int nw, int li, int h,
+                                            float (*st)[2] = nullptr) {
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -129,8 +134,50 @@ __device__ __forceinline__ void ps_epilogue(const PsParams& p, floatx16 (&acc)[T
                 v *= p.out_scale;
                 if constexpr (EPI & 4) v += pc[r];
                 if (FULL || m < p.M) p.y[(long long)m * p.ldy + n] = v;
+                if constexpr (STATS) { st[q][0] += v; st[q][1] += v * v; }
             }
         }
+}
+
+// The GroupNorm statistics of a 256 x 128 output tile: the lanes' column sums (ps_epilogue<STATS>) are folded over the two half waves and the
+// cpg = 4 .. 32 adjacent columns of a group by lane exchanges, over the four wave rows through LDS (fixed order, fp64), and thread g writes the
+// partial of group n0 / cpg + g.  A tile lies inside one sample (H * W % 256 == 0), so the partials are [B][H*W/256][G][2]: what gn_stats_kernel
+// writes for S = H*W/256 pixel splits -- the finalize kernel of groupnorm.hip reads either.
+__device__ __forceinline__ void ps3_gn_partials(const PsParams& p, float (&st)[2][2], float* red /* LDS, >= 4 * 32 * 2 floats */, int m0, int n0,
+                                                int wm, int wn, int li, int h, int tid) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            float v = st[q][k];
+            v += __shfl_xor(v, 32);
+            v += __shfl_xor(v, 1);
+            v += __shfl_xor(v, 2);
+            if (p.gn_lcpg > 2) v += __shfl_xor(v, 4);
+            if (p.gn_lcpg > 3) v += __shfl_xor(v, 8);
+            if (p.gn_lcpg > 4) v += __shfl_xor(v, 16);
+            st[q][k] = v;
+        }
+    __syncthreads();                                       // every wave is done with the operand windows
+    if (h == 0 && (li & ((1 << p.gn_lcpg) - 1)) == 0) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const int g = (wn * 64 + q * 32 + li) >> p.gn_lcpg;
+            red[(wm * 32 + g) * 2 + 0] = st[q][0];
+            red[(wm * 32 + g) * 2 + 1] = st[q][1];
+        }
+    }
+    __syncthreads();
+    const int ng = PS_BN >> p.gn_lcpg;
+    if (tid < ng) {
+        double a = 0.0, c2 = 0.0;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) { a += (double)red[(w * 32 + tid) * 2 + 0]; c2 += (double)red[(w * 32 + tid) * 2 + 1]; }
+        const int b = m0 >> p.lhw, s = (m0 & ((1 << p.lhw) - 1)) >> 8, S = 1 << (p.lhw - 8);
+        double* o = p.gn_part + (((long long)b * S + s) * p.gn_G + (n0 >> p.gn_lcpg) + tid) * 2;
+        o[0] = a;
+        o[1] = c2;
+    }
 }
 
 // EPI bits: 1 = residual, 2 = per-sample row bias, 4 = accumulate into y
@@ -461,6 +508,14 @@ __global__ __launch_bounds__(PS_NT, 2) void conv_ps3_kernel(PsParams p) {
     // output rows: the wave's two 32-pixel blocks, virtual -> real (32 consecutive virtual pixels are consecutive in memory)
     const int nw = n0 + wn * 64;
     const int mb[2] = {ps_v2r(m0 + wm * 64, p.lw, lh, p.lvw), ps_v2r(m0 + wm * 64 + 32, p.lw, lh, p.lvw)};
+    if constexpr (EPI == 1 || EPI == 2) {                    // (forward conv1 / conv2 of a resnet: the producers of a GroupNorm's input)
+        if (p.gn_part) {                                     // kernel-uniform
+            float st[2][2] = {{0.f, 0.f}, {0.f, 0.f}};
+            ps_epilogue<EPI, 2, true, true>(p, acc, mb, nw, li, h, st);
+            ps3_gn_partials(p, st, reinterpret_cast<float*>(smem), m0, n0, wm, wn, li, h, tid);
+            return;
+        }
+    }
     ps_epilogue<EPI, 2, true>(p, acc, mb, nw, li, h);        // (M % 256 == 0: every tile is whole, host-checked)
 }
 
@@ -1399,6 +1454,24 @@ size_t conv3x3_ps_workspace_bytes(const bd_conv3x3_ps_desc& d) {
     return ks > 1 ? (size_t)ks * (size_t)M * d.N * sizeof(float) : 0;
 }
 
+// does this call run on conv_ps3_kernel (256 x 128 tiles, whole tiles only)?
+static bool ps_takes_v3(int B, int H, int W, int N) {
+    static const bool v3_off = getenv("BD_PS_V3") && atoi(getenv("BD_PS_V3")) == 0;
+    // round 4: any W >= 16 -- images wider than 32 pixels are walked strip by strip (virtual pixel order, ps_v2r)
+    static const int v3_maxw = getenv("BD_PS_V3_MAXW") ? atoi(getenv("BD_PS_V3_MAXW")) : (1 << 30);     // (A/B knob: 32 = round 3's gate)
+    const long long M = (long long)B * H * W;
+    const int vw = W < 32 ? W : 32;
+    return ps_large(M, N) && !v3_off && W >= 16 && W <= v3_maxw && ((long long)H * vw) % PS_BM == 0 && M % PS_BM == 0;
+}
+// Round 4: pixel splits of the GroupNorm partials a forward call can write from its epilogue (0: it cannot).  One split per 256-pixel tile.
+int conv3x3_ps_gn_splits(int B, int H, int W, int K, int N, int groups) {
+    static const bool off = getenv("BD_GN_EPI_STATS") && atoi(getenv("BD_GN_EPI_STATS")) == 0;       // (A/B knob)
+    if (off || B <= 0 || ilog2x(H) < 0 || ilog2x(W) < 0 || K <= 0 || K % 32 || N <= 0 || N % PS_BN || groups <= 0 || N % groups) return 0;
+    const int lc = ilog2x(N / groups);
+    if (lc < 2 || lc > 5 || (H * W) % PS_BM) return 0;
+    return ps_takes_v3(B, H, W, N) ? H * W / PS_BM : 0;
+}
+
 int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
     BD_CHECK(d.x_split && d.w_split && d.y, BD_ERR_INVALID, "conv3x3_ps: null pointer");
     BD_CHECK(d.B > 0 && ilog2x(d.H) >= 0 && ilog2x(d.W) >= 0, BD_ERR_UNSUPPORTED, "conv3x3_ps: H, W must be powers of two");
@@ -1438,12 +1511,14 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
         p.ablate = getenv("BD_PS_ABLATE") ? atoi(getenv("BD_PS_ABLATE")) : 0;
 #endif
         // vertical-tap sharing variant (conv_ps3_kernel): image rows of 16 or 32 pixels, whole images per tile row block
-        static const bool v3_off = getenv("BD_PS_V3") && atoi(getenv("BD_PS_V3")) == 0;
-        // round 4: any W >= 16 -- images wider than 32 pixels are walked strip by strip (virtual pixel order, ps_v2r)
-        static const int v3_maxw = getenv("BD_PS_V3_MAXW") ? atoi(getenv("BD_PS_V3_MAXW")) : (1 << 30);     // (A/B knob: 32 = round 3's gate)
         const int vw = d.W < 32 ? d.W : 32;
-        const bool v3 = !v3_off && d.W >= 16 && d.W <= v3_maxw && ((long long)d.H * vw) % PS_BM == 0 && M % PS_BM == 0;
+        const bool v3 = ps_takes_v3(d.B, d.H, d.W, d.N);
         p.lvw = ilog2x(vw);
+        if (d.gn_part) {
+            BD_CHECK(d.direction == 1 && (epi == 1 || epi == 2) && conv3x3_ps_gn_splits(d.B, d.H, d.W, d.K, d.N, d.gn_groups) > 0, BD_ERR_UNSUPPORTED,
+                     "conv3x3_ps: gn_part needs a forward call with exactly one of rowbias / residual and bd_conv3x3_ps_gn_splits() > 0");
+            p.gn_part = d.gn_part; p.gn_G = d.gn_groups; p.gn_lcpg = ilog2x(d.N / d.gn_groups);
+        }
 #define PS_LAUNCH(E) do { if (v3) hipLaunchKernelGGL((conv_ps3_kernel<E>), grid, block, 0, st, p); \
                           else hipLaunchKernelGGL((conv_ps_kernel<E>), grid, block, 0, st, p); } while (0)
         switch (epi) {          // every combination has its own instantiation: the epilogue's addends are compile-time
@@ -1459,6 +1534,7 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
 #undef PS_LAUNCH
         BD_LAUNCH_CHECK("conv_ps");
     } else {
+        BD_CHECK(!d.gn_part, BD_ERR_UNSUPPORTED, "conv3x3_ps: gn_part on a small layer (bd_conv3x3_ps_gn_splits() == 0)");
         PsSmallParams pp = {};
         p.tiles_m = (int)cdiv(M, 128); p.tiles_n = d.N / 128;
         pp.q = p;
@@ -1649,6 +1725,7 @@ extern "C" int bd_upsample_conv_wgrad(const bd_upsample_conv_desc* d, bd_stream_
     return bd::upsample_conv_wgrad(*d, bd::S(s));
 }
 extern "C" size_t bd_conv3x3_ps_workspace_bytes(const bd_conv3x3_ps_desc* d) { return d ? bd::conv3x3_ps_workspace_bytes(*d) : 0; }
+extern "C" int bd_conv3x3_ps_gn_splits(int B, int H, int W, int K, int N, int groups) { return bd::conv3x3_ps_gn_splits(B, H, W, K, N, groups); }
 extern "C" int bd_conv3x3_ps(const bd_conv3x3_ps_desc* d, bd_stream_t s) {
     BD_CHECK(d, BD_ERR_INVALID, "bd_conv3x3_ps: null descriptor");
     return bd::conv3x3_ps(*d, bd::S(s));

@@ -884,13 +884,19 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
     BD_CHECK(d->workspace_bytes >= need, BD_ERR_WORKSPACE, "bd_gn_fwd: workspace %zu < %zu", d->workspace_bytes, need);
     int threads, r;
     gn_block(d->C, threads, r);
-    double* part = reinterpret_cast<double*>(d->workspace);
-    hipLaunchKernelGGL(gn_stats_kernel, dim3(S_, d->B), dim3(threads), (size_t)r * d->C * 2 * sizeof(float), S(stream), d->x,
-                       (long long)d->ldx, d->HW, d->C, d->G, r, S_, part);
-    BD_LAUNCH_CHECK("gn_stats");
+    const double* part = reinterpret_cast<double*>(d->workspace);
+    int Sf = S_;
+    if (d->stats) {           // round 4: the producer of x left the partials (bd_conv3x3_ps gn_part): no pass over x
+        BD_CHECK(d->stats_splits > 0, BD_ERR_INVALID, "bd_gn_fwd: stats without stats_splits");
+        part = d->stats; Sf = d->stats_splits;
+    } else {
+        hipLaunchKernelGGL(gn_stats_kernel, dim3(S_, d->B), dim3(threads), (size_t)r * d->C * 2 * sizeof(float), S(stream), d->x,
+                           (long long)d->ldx, d->HW, d->C, d->G, r, S_, reinterpret_cast<double*>(d->workspace));
+        BD_LAUNCH_CHECK("gn_stats");
+    }
     {
         const int per = gn_apply_rows(d->HW, r);
-        hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(d->B), dim3(256), 0, S(stream), part, d->G, S_,
+        hipLaunchKernelGGL(gn_fwd_finalize_kernel, dim3(d->B), dim3(256), 0, S(stream), part, d->G, Sf,
                            (double)d->HW * (d->C / d->G), d->eps, d->mean, d->rstd);
         hipLaunchKernelGGL(gn_apply_kernel, dim3((unsigned)cdiv(d->HW, per), d->B), dim3(threads), 0, S(stream), d->x,
                            (long long)d->ldx, d->y, (long long)d->ldy, d->HW, d->C, d->G, r, per, d->gamma, d->beta, d->mean,
@@ -898,6 +904,11 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
     }
     BD_LAUNCH_CHECK("gn_apply");
     return BD_OK;
+}
+
+extern "C" int bd_gn_fwd_takes_stats(int B, int HW, int C, int G) {
+    GnRes rp;
+    return B > 0 && HW > 0 && C > 0 && G > 0 && C % G == 0 && (C & 3) == 0 && !gn_resident_plan(B, HW, C, G, rp) ? 1 : 0;
 }
 
 extern "C" int bd_gn_bwd_defers(int B, int HW, int C, int G) {

@@ -572,6 +572,7 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
 
     F([=](Ctx& c) {
         const bool ps1 = ps_ok(c, H, W, Cin, Cout), ps2 = ps_ok(c, H, W, Cout, Cout);
+        int st2 = 0;          // pixel splits of the norm2 partials conv1's epilogue leaves in the op workspace (0: none)
         if (ps1) {
             bd_gn_fwd_desc g = {};
             g.B = c.B; g.HW = HW; g.C = Cin; g.G = G; g.eps = cfg.norm_eps; g.silu = 1;
@@ -586,6 +587,13 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             d.x_split = U16(BP(c, b_a1s)); d.ldx = Cin; d.w_split = c.w_split + 2 * pc1w;
             d.bias = c.params + pc1b; d.rowbias = BP(c, b_tproj) + toff; d.ld_rowbias = sumC_; d.out_scale = 1.f;
             d.y = BP(c, b_h1); d.ldy = Cout;
+            // round 4: norm2's statistics from this epilogue when norm2 would otherwise make a pass over h1 for them (large images)
+            st2 = ps2 && bd_gn_fwd_takes_stats(c.B, HW, Cout, G) ? bd_conv3x3_ps_gn_splits(c.B, H, W, Cin, Cout, G) : 0;
+            if (st2 > 0) {
+                d.gn_part = reinterpret_cast<double*>(c.opws); d.gn_groups = G;
+                const size_t n = (size_t)c.B * st2 * G * 2 * sizeof(double);
+                if (c.dry && n > c.opws_need) c.opws_need = n;
+            }
             BD_TRY(conv_p(c, d));
         } else {
             BD_TRY(gn_fwd(c, x, pn1w, pn1b, BP(c, b_a1), Cin, b_st1, 1));
@@ -604,6 +612,7 @@ void bd_unet::node_resnet(const std::string& pre, const View& x, const View& y, 
             g.y_split = U16(BP(c, b_a2s)); g.ldys = Cout;
             g.mean = MEANP(c, b_st2, G); g.rstd = RSTDP(c, b_st2, G);
             g.workspace = c.opws; g.workspace_bytes = c.opws_bytes;
+            if (st2 > 0) { g.stats = reinterpret_cast<const double*>(c.opws); g.stats_splits = st2; }
             if (!c.dry) BD_TRY(bd_gn_fwd(&g, (bd_stream_t)c.st));
         } else {
             BD_TRY(gn_fwd(c, h1v, pn2w, pn2b, BP(c, b_a2), Cout, b_st2, 1));

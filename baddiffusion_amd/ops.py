@@ -275,18 +275,28 @@ def split_wT(w):
 
 
 def conv3x3_ps(x_split, w_split, B, H, W, K, N, direction=1, bias=None, rowbias=None, residual=None, out_scale=1.0,
-               out=None, accumulate=False):
-    """stride-1 pad-1 3x3 convolution (direction +1) / data gradient (-1) on pre-split operands -> fp32 [B,H,W,N]."""
+               out=None, accumulate=False, gn_groups=0):
+    """stride-1 pad-1 3x3 convolution (direction +1) / data gradient (-1) on pre-split operands -> fp32 [B,H,W,N].
+    gn_groups > 0: also the GroupNorm partials of y from the epilogue -> (y, partials [B, S, gn_groups, 2] fp64), S =
+    bd_conv3x3_ps_gn_splits() (raises when the call cannot produce them)."""
     lib = L.load(); _need_cuda(x_split, w_split, bias, rowbias, residual)
     y = torch.empty(B, H, W, N, device=x_split.device) if out is None else out
+    part = None
+    if gn_groups:
+        S = lib.bd_conv3x3_ps_gn_splits(B, H, W, K, N, gn_groups)
+        if S <= 0:
+            raise ValueError("conv3x3_ps: this call cannot write GroupNorm partials (bd_conv3x3_ps_gn_splits() == 0)")
+        part = torch.full((B, S, gn_groups, 2), float("nan"), dtype=torch.float64, device=x_split.device)
     d = L.ConvPsDesc(B=B, H=H, W=W, K=K, N=N, direction=direction, x_split=L.ptr(x_split), ldx=K, w_split=L.ptr(w_split),
                      bias=L.ptr(bias), rowbias=L.ptr(rowbias), ld_rowbias=rowbias.stride(0) if rowbias is not None else 0,
                      residual=L.ptr(residual), ldr=_ld(residual) if residual is not None else 0, out_scale=out_scale,
                      y=L.ptr(y), ldy=_ld(y), accumulate=int(accumulate))
     ws = workspace(lib.bd_conv3x3_ps_workspace_bytes(C.byref(d)), x_split.device, "ps")
     d.workspace = L.ptr(ws); d.workspace_bytes = ws.numel()
+    if part is not None:
+        d.gn_part = L.ptr(part); d.gn_groups = gn_groups
     L.check(lib.bd_conv3x3_ps(C.byref(d), L.stream()), "bd_conv3x3_ps")
-    return y
+    return y if part is None else (y, part)
 
 
 def conv3x3_ps_wgrad(x_split, dy_split, B, H, W, Cin, Cout, with_db=False):

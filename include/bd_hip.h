@@ -144,8 +144,12 @@ typedef struct {
     void* workspace; size_t workspace_bytes;
     uint16_t* y_split; int64_t ldys;   /* optional: y also / only (y == NULL) as split planes [B*HW, ldys], see
                                           "Pre-split operands" below: the operand format of bd_conv3x3_ps */
+    const double* stats; int stats_splits;   /* optional (round 4): [B][stats_splits][G][2] partial (sum, sum of squares) of x written by the
+                                          producer of x (bd_conv3x3_ps gn_part); read only when bd_gn_fwd_takes_stats(): the statistics
+                                          pass over x is skipped                                                                     */
 } bd_gn_fwd_desc;
 size_t bd_gn_workspace_bytes(int B, int C);
+int bd_gn_fwd_takes_stats(int B, int HW, int C, int G);   /* 1: this shape runs the statistics / apply passes (images too large for the one-pass kernels) */
 int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream);
 
 typedef struct {
@@ -316,8 +320,14 @@ typedef struct {
     float out_scale;                /* y = out_scale * (conv + bias + rowbias + residual)            */
     float* y; int64_t ldy; int accumulate;
     void* workspace; size_t workspace_bytes;   /* >= bd_conv3x3_ps_workspace_bytes(): K-split slabs of the small-layer variant */
+    double* gn_part; int gn_groups; /* optional (round 4): the statistics of the GroupNorm that reads y next (resnet.py:591 norm2 behind conv1,
+                                       :559 norm1 of the next block behind conv2) from this call's epilogue instead of a pass over y:
+                                       [B][S][gn_groups][2] fp64 partial (sum, sum of squares) per sample and 256-pixel tile, S =
+                                       bd_conv3x3_ps_gn_splits() > 0; forward calls with exactly one of rowbias / residual, no accumulate.
+                                       Hand them to bd_gn_fwd as stats / stats_splits.                                              */
 } bd_conv3x3_ps_desc;
 size_t bd_conv3x3_ps_workspace_bytes(const bd_conv3x3_ps_desc* d);
+int bd_conv3x3_ps_gn_splits(int B, int H, int W, int K, int N, int groups);   /* 0: this call cannot write GroupNorm partials */
 int bd_conv3x3_ps(const bd_conv3x3_ps_desc* d, bd_stream_t stream);
 /* weight (and bias) gradient of the same convolution, both operands as split planes:
  *   dw[Cout][3][3][Cin] = sum_p dy[p][co] x[p + tap][ci],  db[Cout] = sum_p dy[p][co] (optional, same launch).

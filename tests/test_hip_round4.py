@@ -282,6 +282,53 @@ def test_conv_ps_wide_images_virtual_pixel_order(gpu, B, H, W, Cin, Cout):
         assert relerr(dw[:, t // 3, t % 3], dw_ref[:, t // 3, t % 3]) < 2e-4, t
 
 
+@pytest.mark.parametrize("B,H,W,Cin,Cout,G", [(2, 128, 128, 128, 128, 32), (1, 256, 256, 128, 128, 32), (3, 64, 128, 128, 256, 32),
+                                               (2, 64, 64, 256, 512, 32), (4, 128, 64, 128, 128, 4)])
+def test_conv_ps_epilogue_groupnorm_statistics(gpu, B, H, W, Cin, Cout, G):
+    """Round 4: the forward convolution's epilogue leaves the (sum, sum of squares) partials of the GroupNorm that reads its output next
+    (resnet.py:591 norm2 behind conv1 + temb, :559 norm1 of the next block behind conv2 + shortcut) -- per sample, 256-pixel tile and group,
+    fp64 [B, S, G, 2] -- and bd_gn_fwd, handed those, skips its statistics pass: y bit-identical to the call without them, statistics equal
+    to the two-pass ones (1e-6) and to fp64 torch (1e-5); group sizes 4 .. 32 channels, both epilogue forms, wide (virtual pixel order) grids."""
+    import ctypes as CT
+    from baddiffusion_amd import _lib as L, ops
+    lib = L.load()
+    g = torch.Generator().manual_seed(B + H + Cout + G)
+    x = torch.randn(B, H, W, Cin, generator=g).cuda()
+    w = (torch.randn(Cout, 3, 3, Cin, generator=g) * 0.05).cuda(); bias = torch.randn(Cout, generator=g).cuda()
+    rb = torch.randn(B, Cout, generator=g).cuda() * 3; res = torch.randn(B, H, W, Cout, generator=g).cuda() + 1.5
+    ws_, xs = ops.split_bf16(w), ops.split_rows(x)
+    HW = H * W
+    assert lib.bd_gn_fwd_takes_stats(B, HW, Cout, G) == 1
+    for kw in (dict(rowbias=rb), dict(residual=res, out_scale=0.7)):
+        y0 = ops.conv3x3_ps(xs, ws_, B, H, W, Cin, Cout, 1, bias=bias, **kw)
+        y, part = ops.conv3x3_ps(xs, ws_, B, H, W, Cin, Cout, 1, bias=bias, gn_groups=G, **kw)
+        assert torch.equal(y, y0)
+        assert part.shape[1] == HW // 256 and not torch.isnan(part).any()
+        yg = y.double().reshape(B, HW, G, Cout // G)
+        tot = part.sum(1)
+        assert relerr(tot[..., 0], yg.sum((1, 3))) < 1e-6 and relerr(tot[..., 1], (yg * yg).sum((1, 3))) < 1e-6
+        ga = torch.randn(Cout, generator=g).cuda(); be = torch.randn(Cout, generator=g).cuda()
+        outs = []
+        for stats in (None, part):
+            st = torch.empty(2, B, G, device=gpu)
+            wsb = ops.workspace(lib.bd_gn_workspace_bytes(B, Cout), x.device)
+            z = torch.empty(B, HW, Cout, device=gpu)
+            f = L.GnFwdDesc(B=B, HW=HW, C=Cout, G=G, eps=1e-6, silu=1, x=L.ptr(y), ldx=Cout, gamma=L.ptr(ga), beta=L.ptr(be), y=L.ptr(z),
+                            ldy=Cout, mean=L.ptr(st[0]), rstd=L.ptr(st[1]), workspace=L.ptr(wsb), workspace_bytes=wsb.numel())
+            if stats is not None:
+                f.stats = L.ptr(stats); f.stats_splits = stats.shape[1]
+            L.check(lib.bd_gn_fwd(CT.byref(f), L.stream()))
+            outs.append((z, st))
+        (z0, st0), (z1, st1) = outs
+        assert relerr(st1, st0) < 1e-6 and relerr(z1, z0) < 1e-5
+        xg = y.double().reshape(B, HW, G, Cout // G).permute(0, 2, 1, 3).reshape(B, G, -1)
+        assert relerr(st1[0], xg.mean(-1)) < 1e-5 and relerr(st1[1], 1 / torch.sqrt(xg.var(-1, unbiased=False) + 1e-6)) < 1e-5
+    # calls that cannot write them say so
+    assert lib.bd_conv3x3_ps_gn_splits(2, 8, 8, 128, 128, 32) == 0
+    with pytest.raises(ValueError):
+        ops.conv3x3_ps(ops.split_rows(x[:, :8, :8].contiguous()), ws_, B, 8, 8, Cin, Cout, 1, bias=bias, rowbias=rb, gn_groups=G)
+
+
 def test_groupnorm_large_image_path_round4(gpu):
     """Round 4, the GroupNorm kernels of the 256 x 256 network (grids that do not fit the single-pass form): the backward can leave
     per-sample (dgamma, dbeta) partials -- written by its group-finalize launch -- to ONE bd_gn_bwd_params launch per backward segment
