@@ -165,6 +165,8 @@ SIGNATURES = {
     "bd_gn_fwd": (i32, [C.POINTER(GnFwdDesc), vp]),
     "bd_gn_bwd": (i32, [C.POINTER(GnBwdDesc), vp]),
     "bd_lincomb": (i32, [i32, C.POINTER(vp), C.POINTER(f32), i64, i32, f32, vp, vp]),
+    "bd_anp_apply": (i32, [vp, i64, vp, vp, vp, i32, i64, vp, vp]),
+    "bd_anp_grad": (i32, [vp, vp, vp, i32, i64, vp, vp, vp, vp, vp]),
     "bd_ssim_workspace_bytes": (sz, [i32, i32, i32, i32]),
     "bd_ssim": (i32, [vp, vp, i32, i32, i32, i32, i64, i64, i64, i64, f32, vp, vp, sz, vp]),
     "bd_conv2d_nhwc": (i32, [C.POINTER(Conv2dDesc), vp]),

@@ -427,6 +427,71 @@ __global__ __launch_bounds__(TPB) void lincomb_kernel(LincombArgs a, float* __re
     }
 }
 
+
+// ---- f-4: Adversarial Neuron Pruning (anp_model.py:490-514 PerturbConv2d = conv followed by an eval-mode batch norm with mean 0, variance 1,
+// eps 0, i.e. y_c <- w_c * conv(x; W, b)_c + b_c with ONE learnable (w_c, b_c) per output channel).  The affine map commutes with the convolution:
+//   w_c * (W_c . x + b_c0) + b_c = (w_c W_c) . x + (w_c b_c0 + b_c),
+// so the perturbed network IS the ordinary network on effective weights (anp_apply: one scaled copy of every conv weight row and bias), and the
+// gradient of the perturbation is a row-wise contraction of the ordinary weight gradient (anp_grad):
+//   dL/dw_c = sum_k dL/dW'_ck W_ck + dL/db'_c b_c0 ,   dL/db_c = dL/db'_c.
+// items: [n][5] int64 = (weight offset, bias offset or -1, Cout, row length, offset of the layer's channels in the perturbation vectors);
+// one workgroup per output channel of every convolution, fixed-order fold (deterministic).
+__device__ __forceinline__ void anp_locate(const int64_t* __restrict__ items, int n, int64_t row, int64_t& woff, int64_t& boff, int64_t& len,
+                                           int64_t& p) {
+    int64_t base = 0;
+    woff = boff = -1; len = 0; p = 0;
+    for (int i = 0; i < n; ++i) {
+        const int64_t cout = items[i * 5 + 2];
+        if (row < base + cout) {
+            const int64_t c = row - base;
+            len = items[i * 5 + 3];
+            woff = items[i * 5 + 0] + c * len;
+            boff = items[i * 5 + 1] < 0 ? -1 : items[i * 5 + 1] + c;
+            p = items[i * 5 + 4] + c;
+            return;
+        }
+        base += cout;
+    }
+}
+__global__ __launch_bounds__(TPB) void anp_apply_kernel(const float* __restrict__ params, const float* __restrict__ pw,
+                                                        const float* __restrict__ pb, const int64_t* __restrict__ items, int n,
+                                                        float* __restrict__ eff) {
+    int64_t woff, boff, len, p;
+    anp_locate(items, n, blockIdx.x, woff, boff, len, p);
+    if (woff < 0) return;
+    const float w = pw[p];
+    for (int64_t k = threadIdx.x; k < len; k += TPB) eff[woff + k] = w * params[woff + k];
+    if (threadIdx.x == 0 && boff >= 0) eff[boff] = w * params[boff] + pb[p];
+}
+// row_norm (optional): the norm of the gradient of the layer's OWN weight row and bias in the perturbed network, |w_c| * ||(dL/dW'_c, dL/db'_c)|| --
+// the reference's clip_grad_norm_ runs over them too (PerturbConv2d's weights are fresh, trainable Parameters: anp_model.py:492-505)
+__global__ __launch_bounds__(TPB) void anp_grad_kernel(const float* __restrict__ params, const float* __restrict__ geff,
+                                                       const int64_t* __restrict__ items, int n, const float* __restrict__ pw,
+                                                       float* __restrict__ gw, float* __restrict__ gb, float* __restrict__ row_norm) {
+    __shared__ float red[TPB / 64][2];
+    int64_t woff, boff, len, p;
+    anp_locate(items, n, blockIdx.x, woff, boff, len, p);
+    if (woff < 0) return;
+    float a = 0.f, q = 0.f;
+    for (int64_t k = threadIdx.x; k < len; k += TPB) {
+        const float g = geff[woff + k];
+        a += g * params[woff + k];
+        q += g * g;
+    }
+    a = wave_sum(a); q = wave_sum(q);
+    if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6][0] = a; red[threadIdx.x >> 6][1] = q; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        float t = 0.f, tq = 0.f;
+#pragma unroll
+        for (int i = 0; i < TPB / 64; ++i) { t += red[i][0]; tq += red[i][1]; }
+        const float g = boff >= 0 ? geff[boff] : 0.f;
+        gw[p] = t + (boff >= 0 ? g * params[boff] : 0.f);
+        gb[p] = g;
+        if (row_norm) row_norm[p] = fabsf(pw[p]) * sqrtf(tq + g * g);
+    }
+}
+
 }  // namespace bd
 
 using namespace bd;
@@ -631,5 +696,25 @@ extern "C" int bd_axpy(const float* src, float* dst, int64_t n, float scale, int
     BD_CHECK(src && dst && n > 0, BD_ERR_INVALID, "bd_axpy: bad args");
     hipLaunchKernelGGL(axpy_kernel, dim3(nblocks(n, TPB, 8192)), dim3(TPB), 0, S(stream), src, dst, n, scale, accumulate);
     BD_LAUNCH_CHECK("axpy");
+    return BD_OK;
+}
+
+extern "C" int bd_anp_apply(const float* params, int64_t nparams, const float* pert_w, const float* pert_b, const int64_t* items, int n_items,
+                            int64_t total_rows, float* eff, bd_stream_t stream) {
+    BD_CHECK(params && pert_w && pert_b && items && eff && nparams > 0 && n_items > 0 && total_rows > 0 && total_rows < (1ll << 31), BD_ERR_INVALID,
+             "bd_anp_apply: bad args");
+    BD_HIP_TRY(hipMemcpyAsync(eff, params, (size_t)nparams * sizeof(float), hipMemcpyDeviceToDevice, S(stream)));
+    hipLaunchKernelGGL(anp_apply_kernel, dim3((unsigned)total_rows), dim3(TPB), 0, S(stream), params, pert_w, pert_b, items, n_items, eff);
+    BD_LAUNCH_CHECK("anp_apply");
+    return BD_OK;
+}
+extern "C" int bd_anp_grad(const float* params, const float* grad_eff, const int64_t* items, int n_items, int64_t total_rows, const float* pert_w,
+                           float* grad_w, float* grad_b, float* row_norm, bd_stream_t stream) {
+    BD_CHECK(params && grad_eff && items && grad_w && grad_b && n_items > 0 && total_rows > 0 && total_rows < (1ll << 31), BD_ERR_INVALID,
+             "bd_anp_grad: bad args");
+    BD_CHECK(!row_norm || pert_w, BD_ERR_INVALID, "bd_anp_grad: row_norm needs pert_w");
+    hipLaunchKernelGGL(anp_grad_kernel, dim3((unsigned)total_rows), dim3(TPB), 0, S(stream), params, grad_eff, items, n_items, pert_w, grad_w,
+                       grad_b, row_norm);
+    BD_LAUNCH_CHECK("anp_grad");
     return BD_OK;
 }

@@ -590,6 +590,26 @@ def lincomb(terms, coeffs, clip=None, out=None):
     return out
 
 
+def anp_apply(params, pert_w, pert_b, items, total_rows, out=None):
+    """effective parameters of the ANP-perturbed network (bd_anp_apply): a copy of the flat parameter buffer with every conv weight row scaled
+    by its channel's pert_w and every conv bias mapped to pert_w * b + pert_b.  items: int64 device tensor [n, 5] (include/bd_hip.h)."""
+    lib = L.load(); _need_cuda(params, pert_w, pert_b, items)
+    if out is None:
+        out = torch.empty_like(params)
+    L.check(lib.bd_anp_apply(L.ptr(params), params.numel(), L.ptr(pert_w), L.ptr(pert_b), L.ptr(items), items.shape[0], int(total_rows),
+                             L.ptr(out), L.stream()), "bd_anp_apply")
+    return out
+
+
+def anp_grad(params, grad_eff, items, total_rows, grad_w, grad_b, pert_w=None, row_norm=None):
+    """gradient of the ANP perturbation from the ordinary flat weight gradient (bd_anp_grad); row_norm: per-channel gradient norm of the
+    layer's own weights in the perturbed network (for the reference's clip norm), needs pert_w."""
+    lib = L.load(); _need_cuda(params, grad_eff, items, grad_w, grad_b, pert_w, row_norm)
+    L.check(lib.bd_anp_grad(L.ptr(params), L.ptr(grad_eff), L.ptr(items), items.shape[0], int(total_rows), L.ptr(pert_w), L.ptr(grad_w),
+                            L.ptr(grad_b), L.ptr(row_norm), L.stream()), "bd_anp_grad")
+    return grad_w, grad_b
+
+
 def ssim(preds, target, data_range=1.0):
     """Mean SSIM (torchmetrics defaults, see bd_hip.h) of two [N,C,H,W] float32 GPU tensors with identical strides (any
     layout: a permuted NHWC buffer is fine).  Returns a 0-dim device tensor; batches with N*C > 65535 are chunked."""

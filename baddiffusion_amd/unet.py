@@ -396,18 +396,20 @@ class UNet2DModel(nn.Module):
             return (sample_out,)
         return UNet2DOutput(sample=sample_out)
 
-    def _forward_chunked(self, x_nhwc, t, chunk):
+    def _forward_chunked(self, x_nhwc, t, chunk, flat=None):
         """Inference over `chunk`-sample pieces (samples are independent: chunking is exact and bounds the workspace).  A failed
-        workspace allocation halves the chunk and starts over instead of failing the call."""
+        workspace allocation halves the chunk and starts over instead of failing the call.  `flat`: another parameter buffer of this
+        topology (anp.py: the effective weights of the perturbed network)."""
         B = x_nhwc.shape[0]
+        flat = self.flat.detach() if flat is None else flat
         while True:
             try:
                 if B <= chunk:
-                    return self._run_forward(self.flat.detach(), x_nhwc, t, False)[0]
+                    return self._run_forward(flat, x_nhwc, t, False)[0]
                 outs = []
                 for s in range(0, B, chunk):
                     tt = t if t.numel() == 1 else t[s: s + chunk]
-                    outs.append(self._run_forward(self.flat.detach(), x_nhwc[s: s + chunk], tt, False)[0])
+                    outs.append(self._run_forward(flat, x_nhwc[s: s + chunk], tt, False)[0])
                 return torch.cat(outs, 0)
             except torch.cuda.OutOfMemoryError:
                 if chunk <= 1:

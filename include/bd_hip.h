@@ -119,6 +119,23 @@ int bd_ddim_step(const bd_ddim_step_desc* d, bd_stream_t stream);
 int bd_lincomb(int k, const float* const* terms, const float* coeffs, int64_t n, int clip, float clip_range, float* out,
                bd_stream_t stream);
 
+/* f-4: Adversarial Neuron Pruning (anp_model.py:490-514 PerturbConv2d; anp_util.py:60-88 convert_model; anp_defense.py:147 the loss that is
+ * maximised).  Every Conv2d of the network is followed by a per-output-channel affine map y_c <- w_c y_c + b_c (an eval-mode batch norm with mean 0,
+ * variance 1, eps 0); it commutes with the convolution, so the perturbed network is bd_unet_forward on EFFECTIVE parameters
+ *   W'_c = w_c W_c,  b'_c = w_c b_c + b_c(perturbation)
+ * and the perturbation's gradient is a row-wise contraction of bd_unet_backward's ordinary weight gradient:
+ *   dL/dw_c = sum_k dL/dW'_ck W_ck + dL/db'_c b_c,   dL/db_c = dL/db'_c.
+ * items: DEVICE array [n_items][5] int64 = (weight offset, bias offset or -1, Cout, row length = elements per output channel, offset of the
+ * layer's channels in pert_w / pert_b / grad_w / grad_b); total_rows = sum of Cout.  bd_anp_apply first copies params -> eff (all other
+ * tensors unchanged), then rewrites the conv rows and biases. */
+int bd_anp_apply(const float* params, int64_t nparams, const float* pert_w, const float* pert_b, const int64_t* items, int n_items,
+                 int64_t total_rows, float* eff, bd_stream_t stream);
+/* row_norm (optional, needs pert_w): |w_c| * ||(dL/dW'_c, dL/db'_c)||, the gradient norm of the layer's own weight row + bias in the perturbed
+ * network.  PerturbConv2d's conv weights are fresh trainable Parameters (anp_model.py:492-505; anp_util.freeze ran before the wrap), so the
+ * reference's clip_grad_norm_(model.parameters(), 1.0) (anp_defense.py:152) takes its coefficient from bn AND conv gradients. */
+int bd_anp_grad(const float* params, const float* grad_eff, const int64_t* items, int n_items, int64_t total_rows, const float* pert_w,
+                float* grad_w, float* grad_b, float* row_norm, bd_stream_t stream);
+
 /* (x/2+0.5).clamp(0,1): NCHW or NHWC(ld) in -> NHWC float [B,H,W,C] and/or uint8 round(255 x). */
 int bd_to_image(const float* x, int src_is_nhwc, int64_t ld, int B, int C, int H, int W,
                 float* out_f32, uint8_t* out_u8, bd_stream_t stream);

@@ -153,16 +153,25 @@ def timestep_embedding(t, dim, flip_sin_to_cos, freq_shift, max_period=10000):
     return emb
 
 
+def conv2d(P, name, x, **kw):
+    """nn.Conv2d `name`; when P holds `<name>.bn.weight / .bn.bias` the layer is the ANP-wrapped PerturbConv2d (anp_model.py:490-514):
+    the convolution followed by F.batch_norm(..., mean 0, var 1, weight, bias, training=False, eps=0.0) = a per-channel affine map."""
+    y = F.conv2d(x, P[name + ".weight"], P[name + ".bias"], **kw)
+    if name + ".bn.weight" in P:
+        y = y * P[name + ".bn.weight"][None, :, None, None] + P[name + ".bn.bias"][None, :, None, None]
+    return y
+
+
 def resnet_block(P, pre, x, emb, groups, eps, scale=1.0):
     # resnet.py:551-601 (time_embedding_norm="default", dropout p=0)
     h = F.silu(F.group_norm(x, groups, P[pre + "norm1.weight"], P[pre + "norm1.bias"], eps))
-    h = F.conv2d(h, P[pre + "conv1.weight"], P[pre + "conv1.bias"], padding=1)
+    h = conv2d(P, pre + "conv1", h, padding=1)
     t = F.linear(F.silu(emb), P[pre + "time_emb_proj.weight"], P[pre + "time_emb_proj.bias"])
     h = h + t[:, :, None, None]
     h = F.silu(F.group_norm(h, groups, P[pre + "norm2.weight"], P[pre + "norm2.bias"], eps))
-    h = F.conv2d(h, P[pre + "conv2.weight"], P[pre + "conv2.bias"], padding=1)
+    h = conv2d(P, pre + "conv2", h, padding=1)
     if pre + "conv_shortcut.weight" in P:
-        x = F.conv2d(x, P[pre + "conv_shortcut.weight"], P[pre + "conv_shortcut.bias"])
+        x = conv2d(P, pre + "conv_shortcut", x)
     return (x + h) / scale
 
 
@@ -193,13 +202,13 @@ def downsample(P, pre, x, padding):
     # resnet.py:199-208
     if padding == 0:
         x = F.pad(x, (0, 1, 0, 1), mode="constant", value=0)
-    return F.conv2d(x, P[pre + "conv.weight"], P[pre + "conv.bias"], stride=2, padding=padding)
+    return conv2d(P, pre + "conv", x, stride=2, padding=padding)
 
 
 def upsample(P, pre, x):
     # resnet.py:126-161
     x = F.interpolate(x, scale_factor=2.0, mode="nearest")
-    return F.conv2d(x, P[pre + "conv.weight"], P[pre + "conv.bias"], padding=1)
+    return conv2d(P, pre + "conv", x, padding=1)
 
 
 def unet_forward(cfg: UNetConfig, P, sample, timestep):
@@ -216,7 +225,7 @@ def unet_forward(cfg: UNetConfig, P, sample, timestep):
     emb = F.linear(t_emb, P["time_embedding.linear_1.weight"], P["time_embedding.linear_1.bias"])
     emb = F.linear(F.silu(emb), P["time_embedding.linear_2.weight"], P["time_embedding.linear_2.bias"])
 
-    h = F.conv2d(sample, P["conv_in.weight"], P["conv_in.bias"], padding=1)
+    h = conv2d(P, "conv_in", sample, padding=1)
     skips = [h]
     n = len(cfg.block_out_channels)
     for i, bt in enumerate(cfg.down_block_types):
@@ -241,4 +250,4 @@ def unet_forward(cfg: UNetConfig, P, sample, timestep):
         if i != n - 1:
             h = upsample(P, f"up_blocks.{i}.upsamplers.0.", h)
     h = F.silu(F.group_norm(h, G, P["conv_norm_out.weight"], P["conv_norm_out.bias"], eps))
-    return F.conv2d(h, P["conv_out.weight"], P["conv_out.bias"], padding=1)
+    return conv2d(P, "conv_out", h, padding=1)

@@ -168,3 +168,26 @@ def pndm_fake_model(x, t):
 def pndm_init():
     import torch
     return torch.randn(2, 3, 8, 8, generator=torch.Generator().manual_seed(77))
+
+
+# ---- G13: Adversarial Neuron Pruning (f-4; anp_model.py / anp_util.py / anp_defense.py) ------------------------------------------
+ANP_LR, ANP_BUDGET, ANP_B = 1e-3, 1.25, 2
+
+
+def anp_bn_init(conv_couts):
+    """seeded bn.weight ~ 1 + 0.3 N(0,1) (a fifth of them beyond the budget), bn.bias ~ 0.2 N(0,1); conv_couts: [(conv name, Cout)] in
+    state-dict order.  The reference initialises (1, 0); a trained state exercises the effective-weight algebra."""
+    g = torch.Generator().manual_seed(1234)
+    out = {}
+    for name, c in conv_couts:
+        out[name + ".bn.weight"] = 1.0 + 0.3 * torch.randn(c, generator=g)
+        out[name + ".bn.bias"] = 0.2 * torch.randn(c, generator=g)
+    return out
+
+
+def anp_inputs(cfg, B=ANP_B):
+    """(clean, trigger_images, target_images, t, noise): batch['image'], batch['pixel_values'], batch['target'] of anp_defense.py:122-124."""
+    x0, R, t, eps = train_inputs(cfg, B)
+    S = cfg.sample_size
+    clean = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(5)) * 2 - 1
+    return clean, R, x0, t, eps

@@ -398,7 +398,87 @@ def g12():
     save("full_size_b4.npz", **out)
 
 
+# ---- G13: Adversarial Neuron Pruning with the reference's own PerturbConv2d (anp_model.py) on the reference's UNet2DModel ----------
+def g13():
+    import anp_model as ref_anp                     # pure torch: imports as is
+    # torch >= 2.x's Python wrapper F.batch_norm refuses eps = 0.0, which PerturbBatchNorm2d passes on purpose (anp_model.py:187-205, written for
+    # torch 1.x); the aten op behind it takes it.  Shim of the WRAPPER's argument check only -- the reference class still decides every argument.
+    class _F:
+        def __getattr__(self, k): return getattr(torch.nn.functional, k)
+        @staticmethod
+        def batch_norm(input, running_mean, running_var, weight=None, bias=None, training=False, momentum=0.1, eps=1e-5):
+            return torch.batch_norm(input, weight, bias, running_mean, running_var, training, momentum, eps, torch.backends.cudnn.enabled)
+    ref_anp.F = _F()
+    try:                                             # anp_util.convert_model / freeze (anp_util.py:60-101); its imports need the same stubs as dataset.py
+        _c = os.getcwd(); os.chdir("/tmp")
+        import anp_util as ref_anp_util
+        os.chdir(_c)
+        convert_model, freeze = ref_anp_util.convert_model, ref_anp_util.freeze
+        how = "anp_util.convert_model"
+    except Exception as e:                           # fall back to the same walk over the reference's PerturbConv2d class
+        os.chdir(_c)
+        print("anp_util not importable here (%s): wrapping with anp_model.PerturbConv2d directly" % type(e).__name__)
+        how = "anp_model.PerturbConv2d applied by attribute type (anp_util.py:60-88 not importable)"
+
+        def convert_model(model):
+            def rec(module):
+                for a in dir(module):
+                    tgt = getattr(module, a)
+                    if type(tgt) == torch.nn.Conv2d:
+                        setattr(module, a, ref_anp.PerturbConv2d(layer=tgt))
+                for _, ch in module.named_children():
+                    rec(ch)
+            rec(model)
+            return model
+
+        def freeze(model):
+            for ch in model.children():
+                for p in ch.parameters():
+                    p.requires_grad = False
+            return model
+    cfg = SMALL_CFGS["small"]
+    m = ref_unet(cfg, U.gen_params(cfg, 7)); m.eval()
+    clean, trig, targ, t, eps = anp_inputs(cfg)
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    with torch.no_grad():
+        plain = m(ref_loss.q_sample_diffuser(sched, clean, torch.zeros_like(clean), t, eps)[0], t, return_dict=False)[0]
+    pm = convert_model(freeze(m))
+    named = [(n, p) for n, p in pm.named_parameters() if "bn" in n]           # anp_util.py:133
+    convs = [(n[: -len(".bn.weight")], p.numel()) for n, p in named if n.endswith(".bn.weight")]
+    out = {"how": np.array(how), "bn_names": np.array([n for n, _ in named]), "conv_names": np.array([n for n, _ in convs]),
+           "conv_couts": np.array([c for _, c in convs])}
+    xn = ref_loss.q_sample_diffuser(sched, clean, torch.zeros_like(clean), t, eps)[0]
+    with torch.no_grad():
+        out["pred_identity"] = pm(xn, t, return_dict=False)[0]                   # bn = (1, 0): the wrapped model IS the model (diff_output, anp_util.py:103-121)
+        out["pred_plain"] = plain
+    init = anp_bn_init(convs)
+    with torch.no_grad():
+        for n, p in named:
+            p.copy_(init[n])
+        out["pred_perturbed"] = pm(xn, t, return_dict=False)[0]
+        ref_anp.disable_perturb(pm)
+        out["pred_disabled"] = pm(xn, t, return_dict=False)[0]
+        ref_anp.enable_perturb(pm)
+    opt = torch.optim.Adam([p for _, p in named], lr=ANP_LR)                   # anp_util.py:135
+    loss = -ref_loss.p_losses_diffuser(sched, model=pm, x_start=clean, R=torch.full_like(trig, 0), timesteps=t, noise=eps, loss_type="l2")
+    loss.backward()                                                             # anp_defense.py:147-148
+    out["loss"] = loss.detach()
+    out["bn_grads"] = torch.cat([p.grad.flatten() for _, p in named])
+    out["total_norm"] = torch.nn.utils.clip_grad_norm_(pm.parameters(), 1.0)   # anp_defense.py:152
+    opt.step()
+    with torch.no_grad():                                                       # clip_weight, anp_defense.py:68-75
+        for n, p in named:
+            p.clamp_(-ANP_BUDGET, ANP_BUDGET)
+        out["bn_after"] = torch.cat([p.detach().flatten() for _, p in named])
+        x_noisy, _ = ref_loss.q_sample_diffuser(sched, clean, torch.full_like(trig, 0), t, eps)      # backdoor_mse_fn, anp_defense.py:47-66
+        _, btarget = ref_loss.q_sample_diffuser(sched, targ, trig, t, eps)
+        out["backdoor_mse"] = torch.nn.functional.mse_loss(btarget, pm(x_noisy.contiguous(), t.contiguous(), return_dict=False)[0])
+        out["pred_after"] = pm(xn, t, return_dict=False)[0]
+    print("G13 via", how, "| loss", float(loss), "| norm", float(out["total_norm"]), "| backdoor mse", float(out["backdoor_mse"]))
+    save("anp.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
     for w in which:
         globals()[w]()

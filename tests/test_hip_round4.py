@@ -31,6 +31,8 @@ def gpu():
 
 
 def relerr(a, b):
+    a = torch.as_tensor(a) if not torch.is_tensor(a) else a
+    b = torch.as_tensor(b) if not torch.is_tensor(b) else b
     a = a.detach().cpu().double(); b = b.detach().cpu().double()
     return float((a - b).norm() / (b.norm() + 1e-30))
 
@@ -428,3 +430,84 @@ def test_round4_paths_equal_their_fallbacks(gpu, tmp_path, topology, batch):
     assert relerr(res["new"]["out"], res["old"]["out"]) < 2e-5
     assert relerr(res["new"]["grad"], res["old"]["grad"]) < 1e-4
     assert torch.isfinite(res["new"]["grad"]).all()
+
+
+# ------------------------------------------------------------------------------------------------ f-4: Adversarial Neuron Pruning
+def test_anp_perturbed_unet_and_train_step_vs_reference(gpu, golden):
+    """The ANP defense on the HIP path (baddiffusion_amd/anp.py: effective weights through bd_anp_apply, perturbation gradient through bd_anp_grad,
+    clip + Adam + clamp as bd_sumsq / bd_adam_clip / bd_lincomb) against G13 -- vectors made by the reference's own PerturbConv2d /
+    convert_model on its UNet2DModel (anp_model.py:490-514, anp_util.py:60-88, anp_defense.py:47-75, 136-160): the wrapped model with bn = (1, 0) and
+    the disabled one ARE the model, perturbed forward, -loss, every bn gradient, the clip norm, bn parameters after Adam + clip_weight, backdoor MSE,
+    forward after the step (no-grad path, and inside a sampling loop's static-weights block).  1e-3 as everywhere; both compute modes."""
+    from oracle import unet_ref as U
+    from tests.golden import cases as C
+    from baddiffusion_amd import anp, unet as unet_mod
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    g = golden("anp")
+    cfg = C.SMALL_CFGS["small"]
+    clean, trig, targ, t, eps = [v.cuda() for v in C.anp_inputs(cfg)]
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    from baddiffusion_amd.loss import q_sample_diffuser
+    xn = q_sample_diffuser(sched, clean, torch.zeros_like(clean), t, eps)[0]
+    for mode in ("f32", "bf16x3"):
+        m = unet_mod.unet_from_config(cfg).cuda()
+        m.load_state_dict(U.gen_params(cfg, 7))
+        m.set_compute_mode(mode)
+        with torch.no_grad():
+            plain = m(xn, t).sample
+        assert relerr(plain, g["pred_plain"]) < 1e-3
+        pm = anp.convert_model(m)
+        bn_names = [str(n) for n in g["bn_names"]]             # the reference's named_parameters() order
+        assert sorted(n for n, _ in pm.named_bn_parameters()) == sorted(bn_names)
+        assert [p.requires_grad for p in pm.parameters()] == [False, True] or [n for n, p in pm.named_parameters() if p.requires_grad] == ["perturb"]
+        with torch.no_grad():
+            assert torch.equal(pm(xn, t).sample, plain)                      # bn = (1, 0): w * W is W, 1 * b + 0 is b -- bit-identical
+            names = [str(n) for n in g["conv_names"]]
+            pm.load_bn_state(C.anp_bn_init(list(zip(names, [int(c) for c in g["conv_couts"]]))))
+            assert relerr(pm(xn, t).sample, g["pred_perturbed"]) < 1e-3
+            anp.disable_perturb(pm)
+            assert torch.equal(pm(xn, t).sample, plain)
+            anp.enable_perturb(pm)
+        tr = anp.AnpTrainer(pm, sched, anp.AnpConfig(learning_rate=C.ANP_LR, perturb_budget=C.ANP_BUDGET))
+        logs = tr.step(clean, trig, targ, t, eps)
+        assert abs(float(logs["loss"]) - float(g["loss"])) < 1e-3 * abs(float(g["loss"]))
+        gref = torch.from_numpy(g["bn_grads"])
+        bg = pm.bn_grads()
+        gflat = torch.cat([bg[n].flatten() for n in bn_names])
+        assert relerr(gflat, gref) < 1e-3, relerr(gflat, gref)
+        assert abs(float(logs["grad_norm"]) - float(g["total_norm"])) < 1e-3 * float(g["total_norm"])
+        bp = dict(pm.named_bn_parameters())
+        after = torch.cat([bp[n].detach().flatten() for n in bn_names]).cpu()
+        big = gref.abs() > 1e-2 * gref.abs().max()
+        np.testing.assert_allclose(after[big].numpy(), g["bn_after"][big.numpy()], rtol=1e-4, atol=1e-5)
+        assert float(after.abs().max()) <= C.ANP_BUDGET + 1e-7
+        assert abs(float(logs["backdoor_mse"]) - float(g["backdoor_mse"])) < 1e-3 * float(g["backdoor_mse"])
+        with torch.no_grad():
+            o1 = pm(xn, t).sample
+            with pm.static_weights():
+                o2 = pm(xn, t).sample; o3 = pm(xn, t).sample
+        assert relerr(o1, g["pred_after"]) < 2e-3 and torch.equal(o1, o2) and torch.equal(o2, o3)
+        sd = pm.state_dict()
+        assert all(k in sd for k in (names[0] + ".bn.weight", names[-1] + ".bn.bias", "conv_in.weight"))
+    # the kernels themselves: a non-conv tensor is copied untouched, a conv row is scaled, the gradient contraction is the row dot product
+    flat = m.flat.detach()
+    T_ = pm.total_rows
+    w = torch.randn(T_, device=gpu); b = torch.randn(T_, device=gpu)
+    from baddiffusion_amd import ops
+    eff = ops.anp_apply(flat, w, b, pm._items, T_)
+    off, shape, _ = m._table["time_embedding.linear_1.weight"]
+    assert torch.equal(eff[off: off + int(np.prod(shape))], flat[off: off + int(np.prod(shape))])
+    it = pm._items.cpu().tolist()
+    for (wo, bo, co, ln, po) in (it[0], it[3], it[-1]):
+        ref = flat[wo: wo + co * ln].view(co, ln) * w[po: po + co, None]
+        assert torch.equal(eff[wo: wo + co * ln].view(co, ln), ref)
+        assert torch.allclose(eff[bo: bo + co], w[po: po + co] * flat[bo: bo + co] + b[po: po + co], rtol=1e-6, atol=1e-7)
+    ge = torch.randn_like(flat)
+    gw = torch.empty(T_, device=gpu); gb = torch.empty(T_, device=gpu)
+    rn = torch.empty(T_, device=gpu)
+    ops.anp_grad(flat, ge, pm._items, T_, gw, gb, pert_w=w, row_norm=rn)
+    for (wo, bo, co, ln, po) in (it[0], it[3], it[-1]):
+        ref = (ge[wo: wo + co * ln].view(co, ln).double() * flat[wo: wo + co * ln].view(co, ln).double()).sum(1) + ge[bo: bo + co].double() * flat[bo: bo + co].double()
+        assert relerr(gw[po: po + co], ref) < 1e-5 and torch.equal(gb[po: po + co], ge[bo: bo + co])
+        nref = w[po: po + co].double().abs() * torch.sqrt((ge[wo: wo + co * ln].view(co, ln).double() ** 2).sum(1) + ge[bo: bo + co].double() ** 2)
+        assert relerr(rn[po: po + co], nref) < 1e-5

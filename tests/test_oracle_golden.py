@@ -388,3 +388,41 @@ def test_pndm_oracle_matches_reference_chains(golden):
         x = r.step(C.pndm_fake_model(x, t), t, x)
         ref = torch.from_numpy(g["skip_chain_10"][i])
         assert float((x - ref).abs().max()) <= 2e-6 * float(ref.abs().max()), i
+
+
+# ------------------------------------------------------------------ G13: Adversarial Neuron Pruning (f-4)
+def test_anp_oracle_matches_reference_vectors(golden):
+    """oracle/anp_ref.py against what the reference's own PerturbConv2d / convert_model computed (tests/golden/anp.npz): wrapped model with
+    bn = (1, 0) IS the model, perturbed / disabled forward, -loss, every bn gradient, the clip norm, bn parameters after Adam + clip_weight,
+    the backdoor MSE.  Also: parameter naming and order ('bn' parameters as anp_util.py:133 selects them)."""
+    from oracle import anp_ref as A
+    g = golden("anp")
+    cfg = C.SMALL_CFGS["small"]
+    P = U.gen_params(cfg, 7)
+    names = [str(n) for n in g["conv_names"]]              # the reference's named_parameters() order (up_blocks before mid_block)
+    assert sorted(names) == sorted(A.conv_names(cfg))      # the same layers: every nn.Conv2d, nothing else
+    assert [P[n + ".weight"].shape[0] for n in names] == [int(c) for c in g["conv_couts"]]
+    bn_names = [str(n) for n in g["bn_names"]]
+    assert bn_names == [n + s for n in names for s in (".bn.weight", ".bn.bias")]
+    _, a, ac = sched_ref.make_tables()
+    clean, trig, targ, t, eps = C.anp_inputs(cfg)
+    xn, _ = loss_ref.q_sample(a, ac, clean, torch.zeros_like(clean), t, eps)
+    with torch.no_grad():
+        plain = U.unet_forward(cfg, P, xn, t)
+        close(plain, g["pred_plain"], rtol=1e-4, atol=1e-5)
+        ident = dict(P); ident.update(A.init_bn(cfg, P))
+        close(U.unet_forward(cfg, ident, xn, t), g["pred_identity"], rtol=1e-4, atol=1e-5)
+        assert np.array_equal(g["pred_identity"], g["pred_plain"]) and np.array_equal(g["pred_disabled"], g["pred_plain"])
+        bn = C.anp_bn_init(list(zip(names, [int(c) for c in g["conv_couts"]])))
+        full = dict(P); full.update(bn)
+        close(U.unet_forward(cfg, full, xn, t), g["pred_perturbed"], rtol=1e-4, atol=1e-5)
+    loss, G, norm, bn2, _, bm = A.anp_step(cfg, P, bn, {}, a, ac, clean, trig, targ, t, eps, C.ANP_LR, 1, C.ANP_BUDGET)
+    close(loss, g["loss"], rtol=1e-5)
+    gflat = torch.cat([G[n].flatten() for n in bn_names])
+    assert float((gflat - T(g["bn_grads"])).norm() / T(g["bn_grads"]).norm()) < 1e-4
+    close(norm, g["total_norm"], rtol=1e-5)
+    after = torch.cat([bn2[n].flatten() for n in bn_names])
+    big = T(g["bn_grads"]).abs() > 1e-3 * T(g["bn_grads"]).abs().max()        # (Adam's first step is lr * sign(g): exclude gradients at noise level)
+    close(after[big], g["bn_after"][big.numpy()], rtol=1e-5, atol=1e-6)
+    assert float(after.abs().max()) <= C.ANP_BUDGET + 1e-7 and float((after.abs() >= C.ANP_BUDGET - 1e-7).float().mean()) > 0.05
+    close(bm, g["backdoor_mse"], rtol=1e-4)
