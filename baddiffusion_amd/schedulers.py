@@ -64,6 +64,11 @@ class _Base:
     def __len__(self):
         return self.config.num_train_timesteps
 
+    @property
+    def num_train_timesteps(self):
+        """`noise_sched.num_train_timesteps` (baddiffusion.py:600, anp_defense.py:131): diffusers' config attribute shortcut."""
+        return self.config.num_train_timesteps
+
     def add_noise(self, original_samples, noise, timesteps):
         # scheduling_ddpm.py:422-443  (q_sample with R = 0)
         a, ac = self.device_tables(original_samples.device)

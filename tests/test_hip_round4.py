@@ -511,3 +511,51 @@ def test_anp_perturbed_unet_and_train_step_vs_reference(gpu, golden):
         assert relerr(gw[po: po + co], ref) < 1e-5 and torch.equal(gb[po: po + co], ge[bo: bo + co])
         nref = w[po: po + co].double().abs() * torch.sqrt((ge[wo: wo + co * ln].view(co, ln).double() ** 2).sum(1) + ge[bo: bo + co].double() ** 2)
         assert relerr(rn[po: po + co], nref) < 1e-5
+
+
+def test_anp_defense_cli_loop_end_to_end(gpu, tmp_path):
+    """anp_defense.py (the reference's anp_defense.py:113-186 + anp_config.py + anp_util.py:149-260): flags / output-dir naming / args.json of the
+    backdoor run, the all-poisoned data loader, two epochs of the loop on the small UNet (32 x 32), per-epoch sample grids, score.json with one
+    (MSE, SSIM) per measure() call, the saved bn parameters inside the budget -- and the loop does what ANP is for: the clean loss it MAXIMISES goes up."""
+    import dataclasses, json, os
+    from PIL import Image
+    import anp_defense as cli
+    from oracle import unet_ref as U
+    from tests.golden import cases as C
+    from baddiffusion_amd import anp
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.unet import unet_from_config
+    ck = tmp_path / "res_backdoored"
+    os.makedirs(ck)
+    json.dump({"trigger": "BOX_14", "target": "CORNER", "poison_rate": 0.1, "dataset": "CIFAR10"}, open(ck / "args.json", "w"))
+    config = cli.get_config(["--ckpt", str(ck), "--epoch", "2", "-lr", "0.05", "-pb", "1.5", "--output_dir", str(tmp_path / "out"), "--batch", "8",
+                             "--tag", "t"])
+    assert os.path.basename(config.output_dir) == "res_anp_2_lr0.05_pb1.5_t_res_backdoored" and os.path.exists(os.path.join(config.output_dir, "config.json"))
+    assert (config.trigger, config.target, config.dataset) == ("BOX_14", "CORNER", "CIFAR10")
+    config.num_images = 16; config.eval_sample_n = 4; config.measure_sample_n = 6; config.eval_max_batch = 4; config.dataset_path = None
+    dsl = cli.get_data_loader(config, device=gpu)
+    b = next(iter(dsl.get_dataloader()))
+    assert not bool(b["is_clean"].any()) and b["image"].shape == (8, 3, 32, 32)      # clean_rate 0, poison_rate 1 (anp_util.py:152)
+    cfg_net = dataclasses.replace(C.SMALL_CFGS["small"], sample_size=32)
+    model = unet_from_config(cfg_net).cuda()
+    model.load_state_dict(U.gen_params(cfg_net, 7))
+    pm = anp.convert_model(model)
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    sched.set_timesteps(1000)
+    import baddiffusion_amd.pipelines as P_
+    keep = P_.DDPMPipeline.__call__
+    # (1000-step chains on 10 images would dominate the test: the loop's pipelines sample with 5 steps here)
+    cli.DDPMPipeline = type("FastDDPM", (P_.DDPMPipeline,), {"__call__": lambda self, *a, **k: keep(self, *a, **{**k, "num_inference_steps": 5})})
+    try:
+        pipe, hist = cli.train_loop(config, pm, sched, dsl, log=lambda *_: None)
+    finally:
+        cli.DDPMPipeline = P_.DDPMPipeline
+    assert len(hist) == 4 and all(np.isfinite(h["loss"]) and np.isfinite(h["backdoor_mse"]) for h in hist)
+    assert hist[-1]["clean_mse"] > hist[0]["clean_mse"]                              # gradient ASCENT on the clean loss
+    sc = json.load(open(os.path.join(config.output_dir, "score.json")))
+    assert sc["epoch"] == [1, 2, 2] and len(sc["MSE"]) == 3 and all(0 <= v <= 1 for v in sc["MSE"]) and all(-1 <= v <= 1 for v in sc["SSIM"])
+    for name in ("0000.png", "0001.png", "final.png"):
+        assert Image.open(os.path.join(config.output_dir, "samples", name)).size == (2 * 32, 2 * 32)
+    bn = torch.load(os.path.join(config.output_dir, "anp_bn.pt"))
+    assert len(bn) == 2 * len(pm.conv_names) and max(float(v.abs().max()) for v in bn.values()) <= 1.5 + 1e-6
+    assert any(float((v - 1).abs().max()) > 0.05 for k, v in bn.items() if k.endswith("bn.weight"))
