@@ -169,6 +169,15 @@ def _cpu_baseline_worker(kind="train"):
     eps = torch.randn(B, 3, S, S, generator=g)
     t = torch.randint(0, 1000, (B,), generator=g)
     state = {}
+    if kind == "anp":         # SURVEY f-4: one batch of the ANP defense loop (anp_defense.py:136-160) on the CIFAR network, batch 16
+        from oracle import anp_ref
+        bn = anp_ref.init_bn(cfg, P)
+        trig = torch.rand(B, 3, S, S, generator=g) * 2 - 1
+        for step in range(64):
+            t0 = time.time()
+            _, _, _, bn, state, _ = anp_ref.anp_step(cfg, P, bn, state, a, ac, x0, trig, x0.flip(0), t, eps, 1e-4, step + 1, 4.0)
+            print(json.dumps({"step": step, "s": time.time() - t0, "cores": torch.get_num_threads(), "B": B}), flush=True)
+        return
     for step in range(64):
         t0 = time.time()
         loss, G = train_ref.loss_and_grads(cfg, P, a, ac, x0, R, t, eps)
@@ -215,6 +224,11 @@ def cpu_baseline(seconds_budget=40.0, kind="train"):
     if kind == "sample":
         return {"seconds_per_step": med, "batch": B, "cores": recs[0]["cores"], "cpu_model": _cpu_model(), "kind": "port",
                 "timed_steps": len(timed)}
+    if kind == "anp":
+        return {"value": B / med, "unit": "images/s", "cores": recs[0]["cores"], "cpu_model": _cpu_model(), "kind": "port",
+                "sample": f"{len(timed)} timed ANP batches ({len(recs) - len(timed)} warm-up) of the CIFAR-32 UNet, batch {B}: perturbed forward + backward, clip + "
+                          f"Adam on the bn parameters, clamp, backdoor-MSE forward; fp32, oracle/anp_ref.py on the host CPU (median {med:.3f} s/batch, "
+                          f"budget {seconds_budget:.0f} s)"}
     return {"value": B / med, "unit": "images/s", "cores": recs[0]["cores"], "cpu_model": _cpu_model(), "kind": "port",
             "sample": f"{len(timed)} timed train steps ({len(recs) - len(timed)} warm-up) of the CIFAR-32 UNet, batch {B}, "
                       f"poison_rate 0.0, fp32, oracle/train_ref.py on the host CPU (median {med:.3f} s/step, "
@@ -322,6 +336,56 @@ def bench_sampling(args, world, rank, dev):
         line.update({k: v for k, v in res.items() if k not in line})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = sampling_cpu_baseline()["ddpm1000" if args.workload == "ddpm1000" else "ddim50"]
+        print(json.dumps(line), file=_JSON_OUT, flush=True)
+    return 0
+
+
+def bench_anp(args, world, rank, dev):
+    """--workload anp: one batch of the ANP defense loop (SURVEY f-4; anp_defense.py:136-160) on the DDPM-CIFAR10-32 topology: perturbed forward +
+    backward (bd_anp_apply, the plan, bd_anp_grad), clip + Adam on the bn parameters, clamp, the backdoor-MSE forward.  One JSON line (side
+    measurement); ranks run replicas (the reference's loop has no gradient exchange of its own beyond DataParallel; not wired here)."""
+    from baddiffusion_amd import anp
+    from baddiffusion_amd.model import KNOWN_TOPOLOGIES
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.unet import UNet2DModel
+    B = args.batch if args.batch > 0 else 128
+    model = UNet2DModel(**KNOWN_TOPOLOGIES["google/ddpm-cifar10-32"], compute_mode=args.mode).to(dev)
+    pm = anp.convert_model(model)
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    tr = anp.AnpTrainer(pm, sched, anp.AnpConfig())
+    g = torch.Generator(device=dev); g.manual_seed(rank)
+    clean = torch.rand(B, 3, 32, 32, device=dev, generator=g) * 2 - 1
+    trig = torch.rand(B, 3, 32, 32, device=dev, generator=g) * 2 - 1
+    targ = torch.rand(B, 3, 32, 32, device=dev, generator=g) * 2 - 1
+    noise = torch.randn(B, 3, 32, 32, device=dev, generator=g)
+    t = torch.randint(0, 1000, (B,), device=dev, generator=g)
+    for _ in range(args.warmup):
+        logs = tr.step(clean, trig, targ, t, noise)
+    torch.cuda.synchronize(dev)
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        logs = tr.step(clean, trig, targ, t, noise)
+    torch.cuda.synchronize(dev)
+    dt = torch.tensor([time.perf_counter() - t0], device=dev)
+    if world > 1:
+        dist.barrier()
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+        dist.destroy_process_group()
+    if rank == 0:
+        sec = float(dt)
+        line = {"metric": "ANP defense images/sec (32x32 UNet, DDPM-CIFAR10-32 topology, bs%d/GPU)" % B, "value": world * B * args.steps / sec,
+                "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": sec / args.steps * 1e3,
+                "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": "f32" if args.mode == "f32" else "f32 (split-bf16 hi+lo products, fp32 accumulate)",
+                "data": "synthetic (seeded uniform images, seeded default-init weights, bn = (1, 0) at the start)",
+                "config": {"workload": "SURVEY f-4: one batch of anp_defense.train_loop -- perturbed forward + backward, clip + Adam on the bn "
+                                       "parameters, clamp to the budget, backdoor-MSE forward", "global_batch": world * B,
+                           "parallelism": f"replicas x{world}", "bn_parameters": int(pm.perturb.numel())},
+                "final_loss": float(logs["loss"]), "final_backdoor_mse": float(logs["backdoor_mse"])}
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(30.0, kind="anp")
         print(json.dumps(line), file=_JSON_OUT, flush=True)
     return 0
 
@@ -466,10 +530,11 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 128 for cifar, 4 for celeba)")
-    ap.add_argument("--workload", default="cifar", choices=["cifar", "celeba", "ddim50", "ddpm1000", "pndm50"],
+    ap.add_argument("--workload", default="cifar", choices=["cifar", "celeba", "ddim50", "ddpm1000", "pndm50", "anp"],
                     help="cifar = BASELINE configs[1] (the metric; its line also carries the sampling loops and the 256x256 step as "
                          "`sampling` / `celeba` objects); celeba = the 256x256 DDPM-CELEBA-HQ-256 topology alone; "
-                         "ddim50 / ddpm1000 / pndm50 = one CIFAR sampling loop alone (samples/s, --batch samples per GPU, --steps ignored)")
+                         "ddim50 / ddpm1000 / pndm50 = one CIFAR sampling loop alone (samples/s, --batch samples per GPU, --steps ignored); "
+                         "anp = one batch of the ANP defense loop on the CIFAR network (SURVEY f-4)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-prof", action="store_true")
     ap.add_argument("--no-sampling", action="store_true", help="skip the DDIM-50 x 2048 and DDPM-1000 x 256 loops of the default line")
@@ -522,6 +587,8 @@ def main():
     torch.manual_seed(0)
     if args.workload in ("ddim50", "ddpm1000", "pndm50"):
         return bench_sampling(args, world, rank, dev)
+    if args.workload == "anp":
+        return bench_anp(args, world, rank, dev)
     celeba = args.workload == "celeba"      # BASELINE configs[3] topology (256x256, 113.7 M params)
     B = args.batch if args.batch > 0 else (4 if celeba else 128)
     model, eng, step, names = setup_train(celeba, B, args.mode, dev, rank, bool(args.graph))

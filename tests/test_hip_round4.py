@@ -559,3 +559,20 @@ def test_anp_defense_cli_loop_end_to_end(gpu, tmp_path):
     bn = torch.load(os.path.join(config.output_dir, "anp_bn.pt"))
     assert len(bn) == 2 * len(pm.conv_names) and max(float(v.abs().max()) for v in bn.values()) <= 1.5 + 1e-6
     assert any(float((v - 1).abs().max()) > 0.05 for k, v in bn.items() if k.endswith("bn.weight"))
+
+
+def test_bench_anp_workload_line(gpu):
+    """`python bench.py --workload anp`: the side-measurement line of the ANP defense batch (SURVEY f-4) -- one JSON line, the contract's keys,
+    a finite loss that is the NEGATIVE clean MSE (anp_defense.py:147), the CPU baseline object when asked for."""
+    import json, os, subprocess, sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--workload", "anp", "--steps", "3", "--warmup", "1", "--batch", "8",
+                        "--no-cpu-baseline"], capture_output=True, text=True, cwd=root, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in d, k
+    assert d["unit"] == "images/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and abs(d["value"] - 8 * 1000 / d["ms_per_step"]) < 1e-6 * d["value"]
+    assert d["final_loss"] < 0 and np.isfinite(d["final_backdoor_mse"]) and d["config"]["bn_parameters"] > 0
