@@ -576,3 +576,47 @@ def test_bench_anp_workload_line(gpu):
         assert k in d, k
     assert d["unit"] == "images/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["value"] > 0 and abs(d["value"] - 8 * 1000 / d["ms_per_step"]) < 1e-6 * d["value"]
     assert d["final_loss"] < 0 and np.isfinite(d["final_backdoor_mse"]) and d["config"]["bn_parameters"] > 0
+
+
+def test_anp_step_cifar_topology_vs_oracle(gpu):
+    """The ANP batch on the full DDPM-CIFAR10-32 topology (35.7 M parameters, 65 wrapped convolutions, every kernel path of the CIFAR step: LDS-DMA
+    convolutions, phase-decomposed up / down sampling, split-plane attention) against oracle/anp_ref.py (itself pinned on G13) on the same seeded
+    inputs, two consecutive steps (the second one sees Adam moments and a clamped state): loss, bn gradients, clip norm, bn parameters, backdoor MSE."""
+    from oracle import anp_ref as A, sched_ref
+    from oracle import unet_ref as U
+    from tests.golden import cases as C
+    from baddiffusion_amd import anp, unet as unet_mod
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    cfg = U.CIFAR10_32
+    P = U.gen_params(cfg, 3)
+    B = 4
+    g = torch.Generator().manual_seed(11)
+    clean = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1; trig = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1
+    targ = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1; eps = torch.randn(B, 3, 32, 32, generator=g)
+    t = torch.tensor([7, 450, 820, 999])
+    names = A.conv_names(cfg)
+    bn = C.anp_bn_init([(n, P[n + ".weight"].shape[0]) for n in names])
+    _, a, ac = sched_ref.make_tables()
+    m = unet_mod.unet_from_config(cfg).cuda()
+    m.load_state_dict(P)
+    pm = anp.convert_model(m)
+    assert sorted(n for n, _, _ in pm.conv_names) == sorted(names) and len(names) == 65
+    pm.load_bn_state(bn)
+    tr = anp.AnpTrainer(pm, DDPMScheduler(num_train_timesteps=1000), anp.AnpConfig(learning_rate=C.ANP_LR, perturb_budget=C.ANP_BUDGET))
+    state = {}
+    for step in (1, 2):
+        loss, G, norm, bn, state, bm = A.anp_step(cfg, P, bn, state, a, ac, clean, trig, targ, t, eps, C.ANP_LR, step, C.ANP_BUDGET)
+        logs = tr.step(clean.cuda(), trig.cuda(), targ.cuda(), t.cuda(), eps.cuda())
+        assert abs(float(logs["loss"]) - float(loss)) < 1e-3 * abs(float(loss)), step
+        bg = pm.bn_grads()
+        keys = [n + sfx for n in names for sfx in (".bn.weight", ".bn.bias")]
+        gref = torch.cat([G[k].flatten() for k in keys])
+        assert relerr(torch.cat([bg[k].flatten() for k in keys]), gref) < 1e-3, step
+        assert abs(float(logs["grad_norm"]) - float(norm)) < 1e-3 * float(norm), step
+        bp = dict(pm.named_bn_parameters())
+        big = gref.abs() > 1e-2 * gref.abs().max()
+        got = torch.cat([bp[k].detach().flatten() for k in keys]).cpu()
+        want = torch.cat([bn[k].flatten() for k in keys])
+        np.testing.assert_allclose(got[big].numpy(), want[big].numpy(), rtol=2e-4, atol=2e-5)
+        assert abs(float(logs["backdoor_mse"]) - float(bm)) < 1e-3 * float(bm), step
+        pm.load_bn_state(bn)          # continue both sides from the oracle's state (sign flips of noise-level gradients do not accumulate)
