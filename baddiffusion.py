@@ -298,7 +298,7 @@ def fid_of_dirs(net, real_u8, gen_u8, batch=500):
     return metrics.fid_from_features(feats(real_u8), feats(gen_u8))
 
 
-def update_score_file(config, score_file, fid_sc, mse_sc, ssim_sc, fid_reason=None):
+def update_score_file(config, score_file, fid_sc, mse_sc, ssim_sc, fid_reason=None, extra=None):
     def key(k):
         r = f"{k}_ep{config.sample_ep}" if config.sample_ep is not None else k
         return r + ("_noclip" if not config.clip else "")
@@ -314,6 +314,11 @@ def update_score_file(config, score_file, fid_sc, mse_sc, ssim_sc, fid_reason=No
         sc[key("FID_reason")] = fid_reason or FID_UNAVAILABLE      # a null FID is never silent
     else:
         sc.pop(key("FID_reason"), None)
+        sc[key("FID_real_set")] = ("first measure_sample_n rows of np.random.default_rng(seed).permutation(N) (HF datasets' shuffle rule) over this "
+                                   "loader's row order, unflipped uint8 images; upstream's row order comes from an unseeded train_test_split and its "
+                                   "PNGs carry RandomHorizontalFlip, so the subset differs from upstream's")
+    for k, v in (extra or {}).items():
+        sc[key(k)] = v
     with open(path, "w") as f:
         json.dump(sc, f, indent=2, sort_keys=True)
     return sc
@@ -364,7 +369,12 @@ def measure(config, dsl, folder_name, pipeline, rank=0, world=1):
     net = load_fid_weights(device=dev) if str(dev) != "cpu" else None
     if net is not None:
         n_real = min(config.measure_sample_n, len(dsl))
-        order = torch.randperm(len(dsl), generator=torch.Generator().manual_seed(config.seed))[:n_real]       # ds.shuffle(seed)[:n] (:488, 503)
+        # The reference scores against `get_dataset().shuffle(seed=config.seed)[:n]` (:488, 503): HF datasets' shuffle is
+        # np.random.default_rng(seed).permutation(len) -- reproduced here -- over ITS row order, which in FIXED mode is the concatenation of an
+        # UNSEEDED train_test_split (SURVEY D-5), and it saves the TRANSFORMED images (resize + RandomHorizontalFlip) as PNGs.  So the permutation
+        # rule is the reference's, but the subset and the flips are not reproducible from upstream: FID values are comparable in distribution,
+        # not digit for digit (score.json: FID_real_set).
+        order = torch.from_numpy(np.random.default_rng(config.seed).permutation(len(dsl))[:n_real].astype(np.int64))
         real = dsl.device_images[dsl._rows()[order].to(dsl.device_images.device)]
         if real.shape[-1] == 1:
             real = real.expand(-1, -1, -1, 3).contiguous()
@@ -373,7 +383,9 @@ def measure(config, dsl, folder_name, pipeline, rank=0, world=1):
         fid_reason = None
     print(f"[{config.sample_ep}] FID: {fid_sc if fid_sc is not None else 'None (BD_FID_WEIGHTS not set: pytorch_fid Inception weights unavailable)'}, "
           f"MSE: {mse_sc}, SSIM: {ssim_sc}")
-    return update_score_file(config, "score.json", fid_sc, mse_sc, ssim_sc, fid_reason=fid_reason)
+    # the inference chunk decides which kernels the plan picks (fp32 summation order): recorded with the scores it produced
+    return update_score_file(config, "score.json", fid_sc, mse_sc, ssim_sc, fid_reason=fid_reason,
+                             extra={"inference_chunk": getattr(pipeline.unet, "last_chunk", None)})
 
 
 def checkpoint(config, engine, pipeline, cur_epoch, cur_step):

@@ -1276,6 +1276,7 @@ void bd_unet::layout(int B, int training) {
     opws_bytes = align_up(c.opws_need, 256);
     gnpart_floats = training ? c.gnpart_need : 0;
     lay_B = B; lay_train = training;
+    prep_params = nullptr; prep_ws = nullptr; prep_B = -1;   // a new layout moves the prepared planes inside the workspace
 }
 
 // ----------------------------------------------------------------------------------------------------
@@ -1341,8 +1342,16 @@ extern "C" int bd_unet_set_static_weights(bd_unet* u, int enabled) {
 }
 extern "C" int bd_unet_set_compute_mode(bd_unet* u, int mode) {
     BD_CHECK(u && (mode == BD_MODE_F32 || mode == BD_MODE_BF16X3), BD_ERR_INVALID, "bd_unet_set_compute_mode: bad arguments");
-    if (u->cfg.compute_mode != mode) u->lay_B = -1;   // the op-workspace bound depends on which kernels the mode selects: lay out again
+    if (u->cfg.compute_mode != mode) {
+        u->lay_B = -1;   // the op-workspace bound depends on which kernels the mode selects: lay out again
+        u->prep_params = nullptr; u->prep_ws = nullptr; u->prep_B = -1;   // ... and the prepared weight planes belong to the old mode
+    }
     u->cfg.compute_mode = mode;
+    return BD_OK;
+}
+extern "C" int bd_unet_reset_static_cache(bd_unet* u) {
+    BD_CHECK(u, BD_ERR_INVALID, "bd_unet_reset_static_cache: null plan");
+    u->prep_params = nullptr; u->prep_ws = nullptr; u->prep_B = -1;
     return BD_OK;
 }
 extern "C" int64_t bd_unet_num_params(const bd_unet* u) { return u ? u->nparams : 0; }

@@ -112,6 +112,21 @@ class RcclComm:
         assert t.dtype == torch.float32 and t.is_contiguous()
         _check(_load().ncclBroadcast(t.data_ptr(), t.data_ptr(), t.numel(), _NCCL_FLOAT32, root, self._comm, stream.cuda_stream), "ncclBroadcast")
 
+    def self_test(self, n=4099):
+        """All-reduce a rank-dependent vector (v[i] = (rank + 1) * (i % 7 + 1)) and compare with the closed form
+        world * (world + 1) / 2 * (i % 7 + 1) -- exact in fp32.  Returns None when it matches, else a reason string.  Runs once per
+        communicator, before the first gradient is trusted to it (bench.py prints the outcome; a multi-GPU node is leased rarely)."""
+        s = torch.cuda.current_stream(self.device)
+        base = (torch.arange(n, device=self.device) % 7 + 1).float()
+        v = base * float(self.rank + 1)
+        self.all_reduce_(v, s)
+        s.synchronize()
+        want = base * (self.world * (self.world + 1) / 2.0)
+        if not torch.equal(v, want):
+            bad = int((v != want).sum())
+            return f"ncclAllReduce self-test: {bad} of {n} elements differ from the closed form at world {self.world} (rank {self.rank})"
+        return None
+
     def destroy(self):
         if self._comm:
             _load().ncclCommDestroy(self._comm)

@@ -92,19 +92,26 @@ def plan_segments(model):
     return [r[0] for r in plan_segment_ranges(model)]
 
 
-def merge_ranges(ranges):
+def merge_ranges(ranges, pads=None):
     """union of [lo, hi) ranges as a sorted list of disjoint ranges (adjacent / overlapping ones fused): consecutive backward
-    segments own adjacent stretches of the flat gradient -- alignment pads between tensors are zero and ride along"""
+    segments own adjacent stretches of the flat gradient -- alignment pads between tensors are zero and ride along.  A gap is
+    bridged only when it IS padding: with `pads` (model._pads, the exact [lo, hi) pad stretches of the flat buffer) the gap must lie
+    inside one of them; without, it must be shorter than one alignment unit (tensors start on 32-float boundaries, so a real pad is
+    <= 31 floats -- a wider tolerance could swallow a small foreign tensor whose backward segment has not run yet)."""
+    def is_pad(a, b):
+        if pads is None:
+            return b - a <= 31
+        return any(plo <= a and b <= phi for plo, phi in pads)
     out = []
     for lo, hi in sorted(r for r in ranges if r[1] > r[0]):
-        if out and lo <= out[-1][1] + 64:       # (tensors start on 32-float boundaries: gaps are alignment pads)
+        if out and (lo <= out[-1][1] or is_pad(out[-1][1], lo)):
             out[-1] = (out[-1][0], max(out[-1][1], hi))
         else:
             out.append((lo, hi))
     return out
 
 
-def plan_buckets(seg_ranges, bucket_bytes, tail_bytes=8 << 20):
+def plan_buckets(seg_ranges, bucket_bytes, tail_bytes=8 << 20, pads=None):
     """Group the backward segments (in the order they finish) into communication buckets: a bucket closes with the first segment
     that brings it to `bucket_bytes`.  The LAST bucket is the only collective nothing can hide (it is issued behind the last
     data-gradient kernel), so it holds just the trailing segments that fit `tail_bytes`; a short remainder in front of it joins the
@@ -112,7 +119,7 @@ def plan_buckets(seg_ranges, bucket_bytes, tail_bytes=8 << 20):
     sizes = [sum(hi - lo for lo, hi in rs) * 4 for rs in seg_ranges]
     n = len(seg_ranges)
     if bucket_bytes <= 0:
-        return [(s, merge_ranges(rs)) for s, rs in enumerate(seg_ranges)]
+        return [(s, merge_ranges(rs, pads)) for s, rs in enumerate(seg_ranges)]
     tail, acc = n, 0
     while tail > 1 and acc + sizes[tail - 1] <= tail_bytes:
         tail -= 1
@@ -131,7 +138,7 @@ def plan_buckets(seg_ranges, bucket_bytes, tail_bytes=8 << 20):
             groups.append(cur)
     if tail < n:
         groups.append(list(range(tail, n)))
-    return [(g[-1], merge_ranges([r for s in g for r in seg_ranges[s]])) for g in groups]
+    return [(g[-1], merge_ranges([r for s in g for r in seg_ranges[s]], pads)) for g in groups]
 
 
 def plan_segment_ranges(model):
@@ -190,7 +197,7 @@ class TrainEngine:
         # communication buckets: every collective has a fixed cost beside the backward kernels, xGMI rings
         # are per-link bound and want large messages -- segments are fused until a bucket holds BD_DP_BUCKET_MB (default 32 MB:
         # 5 buckets / 8 collectives for the CIFAR UNet's 143 MB instead of 12 / 30)
-        self._buckets = plan_buckets(self._seg_ranges, int(float(os.environ.get("BD_DP_BUCKET_MB", "32")) * 2 ** 20))
+        self._buckets = plan_buckets(self._seg_ranges, int(float(os.environ.get("BD_DP_BUCKET_MB", "32")) * 2 ** 20), pads=model._pads)
         self._bucket_at = {s: rs for s, rs in self._buckets}
         # hipGraph replay of the whole step (fused q_sample -> forward -> loss -> backward -> clip + Adam): one launch per
         # step from the host instead of ~700.  Single-process, no gradient accumulation; BD_TRAIN_GRAPH=0/1 overrides.
@@ -204,20 +211,13 @@ class TrainEngine:
         # transport of the gradient exchange: RCCL called directly on our own stream (rccl.py) whenever the ranks own one GPU each
         # (default group backend nccl, or the forced 1-rank path); c10d otherwise (gloo: CPU tests / ranks sharing a GPU)
         self._rccl = None
+        self.transport_note = None       # why the direct RCCL transport is not in use (None: it is, or it was never asked for)
         if self.dp and self.world == 1 and os.environ.get("BD_DP_TRANSPORT", "rccl") == "none":
             self._rccl = "none"
         if self.dp and os.environ.get("BD_DP_TRANSPORT", "rccl") == "rccl":
             be = dist.get_backend(process_group) if (dist.is_available() and dist.is_initialized()) else "none"
             if process_group is None and (be == "nccl" or self.world == 1):
-                try:
-                    from .rccl import RcclComm
-                    self._rccl = RcclComm(dev)
-                except (RuntimeError, OSError) as e:       # no librccl.so / communicator init refused: the c10d transport still works
-                    import warnings
-                    warnings.warn(f"direct RCCL transport unavailable ({e}); gradients go through torch.distributed.all_reduce")
-                    if self.world == 1:
-                        ensure_single_rank_group()
-                    self._rccl = None
+                self._rccl, self.transport_note = self._open_rccl(dev)
         self._comm = torch.cuda.Stream(device=dev) if (self.dp and (self._defer or self._rccl is not None)) else None
         self._dp_shadow = torch.zeros(n, device=dev) if (dp_check and self.dp) else None
         if dp_check and self.accum != 1:
@@ -225,6 +225,56 @@ class TrainEngine:
         self.collective_bytes = 0
         self.alphas, self.alphas_cumprod = noise_sched.device_tables(dev)
         self.sync_state()
+
+    def _open_rccl(self, dev):
+        """(communicator or None, reason): the direct RCCL transport, agreed on COLLECTIVELY.  Every rank tries to load librccl and says so
+        (all_reduce MIN over the launcher's group) BEFORE anyone enters the unique-id broadcast / ncclCommInitRank, then the communicator
+        is created and checked -- an all-reduce of a rank-dependent vector against its closed form -- and the outcome is agreed on again.  If
+        any rank failed at either point, EVERY rank destroys what it has and uses torch.distributed.all_reduce: ranks that picked their
+        transport locally would sit in mismatched collectives (a silent hang)."""
+        import warnings
+        multi = self.world > 1
+
+        def all_ok(ok):
+            if not multi:
+                return ok
+            flag = torch.tensor([1 if ok else 0], device=dev, dtype=torch.int32)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            return bool(int(flag.item()))
+
+        err = None
+        try:
+            from . import rccl
+            rccl._load()
+            if os.environ.get("BD_RCCL_FAIL_RANK", "") == str(dist.get_rank() if multi else 0):      # fault injection (tests)
+                raise RuntimeError("BD_RCCL_FAIL_RANK fault injection")
+        except (RuntimeError, OSError) as e:
+            err = f"librccl not loadable: {e}"
+        if not all_ok(err is None):
+            reason = err or "librccl failed to load on another rank"
+            warnings.warn(f"direct RCCL transport unavailable ({reason}); gradients go through torch.distributed.all_reduce on every rank")
+            if not multi:
+                ensure_single_rank_group()
+            return None, reason
+        comm = None
+        try:
+            comm = rccl.RcclComm(dev)
+            err = comm.self_test()
+        except (RuntimeError, OSError) as e:
+            err = f"{type(e).__name__}: {e}"
+        if not all_ok(err is None):
+            reason = err or "communicator creation / self-test failed on another rank"
+            if comm is not None:
+                try:
+                    torch.cuda.synchronize()
+                    comm.destroy()
+                except Exception:
+                    pass
+            warnings.warn(f"direct RCCL transport unavailable ({reason}); gradients go through torch.distributed.all_reduce on every rank")
+            if not multi:
+                ensure_single_rank_group()
+            return None, reason
+        return comm, None
 
     def close(self):
         """Tear the gradient communicator down explicitly (while the HIP runtime is still up; otherwise it goes with the object)."""

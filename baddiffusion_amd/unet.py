@@ -247,6 +247,7 @@ class UNet2DModel(nn.Module):
             if tuple(src.shape) != tuple(shape):
                 raise RuntimeError(f"size mismatch for {key}: checkpoint {tuple(src.shape)} vs model {tuple(shape)}")
             self._logical_view(self.flat.data, key).copy_(src.to(self.flat.device, torch.float32))
+        self._reset_static_cache()
         return torch.nn.modules.module._IncompatibleKeys(missing, unexpected)
 
     def named_logical_parameters(self):
@@ -279,19 +280,37 @@ class UNet2DModel(nn.Module):
         return self._lib.bd_unet_workspace_bytes(self._plan, int(B), int(bool(training)))
 
     def effective_chunk(self, B):
-        """Largest inference chunk <= min(B, max_chunk) whose workspace fits in 85 % of the currently free device memory (a
-        pooled workspace of that size counts as free: it is reused).  Halves until it fits; never below 1."""
-        chunk = max(1, min(int(B), self.max_chunk))
+        """Inference chunk for a batch of B: min(B, max_chunk) when its workspace fits in 85 % of the currently free device memory (a
+        pooled workspace of that size counts as free: it is reused); otherwise the largest rung of the FIXED ladder max_chunk / 2^k that
+        does.  The plan picks kernels by batch (two-pipeline threshold, small-layer K-splits), so the chunk decides the fp32 summation
+        order: a ladder makes a reduced chunk reproducible for a given B instead of depending on how many bytes happened to be free, the
+        reduction is logged once, and `last_chunk` records what ran (score.json / the bench line carry it)."""
+        want = max(1, min(int(B), self.max_chunk))
         dev = self.flat.device
-        if dev.type != "cuda" or self._ws_pool.get((chunk, False, str(dev))):
-            return chunk        # (a pooled workspace of this size exists: nothing to allocate, no driver query on the sampling loop's path)
-        free, _ = torch.cuda.mem_get_info(dev)
-        free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # the caching allocator's idle blocks
-        while chunk > 1:
-            if self._ws_pool.get((chunk, False, str(dev))) or self.workspace_bytes(chunk, False) <= 0.85 * free:
-                break
-            chunk = (chunk + 1) // 2
+        chunk = want
+        if dev.type == "cuda" and not self._ws_pool.get((chunk, False, str(dev))):
+            # (a pooled workspace of this size exists: nothing to allocate, no driver query on the sampling loop's path)
+            free, _ = torch.cuda.mem_get_info(dev)
+            free += torch.cuda.memory_reserved(dev) - torch.cuda.memory_allocated(dev)      # the caching allocator's idle blocks
+            fits = lambda c: self._ws_pool.get((c, False, str(dev))) or self.workspace_bytes(c, False) <= 0.85 * free
+            if not fits(chunk):
+                rung = self.max_chunk
+                while rung > 1 and (rung >= want or not fits(rung)):
+                    rung = (rung + 1) // 2
+                chunk = max(1, rung)
+        if chunk < want and not getattr(self, "_chunk_warned", False):
+            import warnings
+            self._chunk_warned = True
+            warnings.warn(f"UNet2DModel: inference chunk reduced from {want} to {chunk} samples (workspace does not fit the free device "
+                          f"memory); kernel selection and fp32 summation order follow the chunk, so samples / scores may differ in the last digits")
+        self.last_chunk = chunk
         return chunk
+
+    def _reset_static_cache(self):
+        """forget the prepared (split / transposed) weight planes of a static_weights() block: the parameters changed in place, or the
+        workspace they were built in is gone (the C side keys its cache on pointers + batch only)"""
+        if getattr(self, "_plan", None):
+            self._lib.bd_unet_reset_static_cache(self._plan)
 
     @contextmanager
     def static_weights(self):
@@ -416,7 +435,13 @@ class UNet2DModel(nn.Module):
                     raise
                 self._ws_pool = {k: v for k, v in self._ws_pool.items() if k[1]}     # drop pooled inference workspaces
                 torch.cuda.empty_cache()
-                chunk = (min(chunk, B) + 1) // 2
+                self._reset_static_cache()       # the allocator may hand the same address back: never match a stale prepared workspace
+                rung = self.max_chunk
+                while rung > 1 and rung >= min(chunk, B):
+                    rung = (rung + 1) // 2
+                import warnings
+                warnings.warn(f"UNet2DModel: workspace allocation for {min(chunk, B)} samples failed; continuing with chunks of {rung}")
+                chunk = self.last_chunk = rung
                 self.max_chunk = min(self.max_chunk, chunk)
 
     # ------------------------------------------------------------------ diffusers-layout I/O (SURVEY f-2)

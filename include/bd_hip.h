@@ -337,8 +337,9 @@ typedef struct {
     float out_scale;                /* y = out_scale * (conv + bias + rowbias + residual)            */
     float* y; int64_t ldy; int accumulate;
     void* workspace; size_t workspace_bytes;   /* >= bd_conv3x3_ps_workspace_bytes(): K-split slabs of the small-layer variant */
-    double* gn_part; int gn_groups; /* optional (round 4): the statistics of the GroupNorm that reads y next (resnet.py:591 norm2 behind conv1,
-                                       :559 norm1 of the next block behind conv2) from this call's epilogue instead of a pass over y:
+    double* gn_part; int gn_groups; /* optional (round 4): the statistics of the GroupNorm that reads y next from this call's epilogue instead
+                                       of a pass over y.  The plan uses it for resnet.py:591 (norm2 behind conv1) only: a conv2 -> next
+                                       block's norm1 hand-over is NOT implemented (norm1 inputs are concat buffers / residual sums):
                                        [B][S][gn_groups][2] fp64 partial (sum, sum of squares) per sample and 256-pixel tile, S =
                                        bd_conv3x3_ps_gn_splits() > 0; forward calls with exactly one of rowbias / residual, no accumulate.
                                        Hand them to bd_gn_fwd as stats / stats_splits.                                              */
@@ -481,6 +482,10 @@ int bd_unet_set_aux_stream(bd_unet* u, int enabled);
  * skips the per-forward weight preprocessing (split-plane copy of the flat buffer, pre-summed upsample tap planes).  The caller
  * promises not to modify the parameters in between; switching it on or off re-reads them once.  Training forwards never skip. */
 int bd_unet_set_static_weights(bd_unet* u, int enabled);
+/* Forget the prepared planes without leaving the block: call after an in-place parameter change (load_state_dict, an optimizer step on
+ * the same buffer) or when the workspace was freed and may be re-allocated at the same address.  bd_unet_set_compute_mode and every
+ * re-layout (another batch size / training flag) do the same internally. */
+int bd_unet_reset_static_cache(bd_unet* u);
 int bd_unet_num_segments(const bd_unet* u);
 int bd_unet_segment_range(const bd_unet* u, int seg, int64_t* lo, int64_t* hi);   /* host-only query: the main range */
 /* a segment finalises 1 or 3 ranges of the flat gradient: k = 0 its own parameters, k = 1 / 2 its resnets' rows of the

@@ -191,3 +191,35 @@ def anp_inputs(cfg, B=ANP_B):
     S = cfg.sample_size
     clean = torch.rand(B, 3, S, S, generator=torch.Generator().manual_seed(5)) * 2 - 1
     return clean, R, x0, t, eps
+
+
+# ---- G14: a K-step training trajectory (baddiffusion.py:590-615: p_losses_diffuser -> backward -> clip 1.0 -> Adam -> cosine LR) ----------
+TRAJ_STEPS, TRAJ_B, TRAJ_POOL = 32, 8, 64
+TRAJ_LR, TRAJ_WARMUP, TRAJ_TOTAL = 2e-4, 8, 48          # warm-up ends inside the trajectory; the cosine part is exercised as well
+TRAJ_TRIGGER, TRAJ_TARGET = "BOX_8", "CORNER"          # 16 x 16 images: an 8 x 8 grey box two pixels from the corner, the 10 x 10 corner target
+TRAJ_SAMPLE_STEPS, TRAJ_SAMPLE_N = 5, 4
+
+
+def traj_pool():
+    """(uint8 images [POOL,16,16,3], poison flags [POOL]): a seeded pool; every fourth row is a backdoor row (poison_rate 0.25)"""
+    S = SMALL_CFGS["small"].sample_size
+    u8 = torch.randint(0, 256, (TRAJ_POOL, S, S, 3), generator=torch.Generator().manual_seed(140), dtype=torch.uint8)
+    return u8, (torch.arange(TRAJ_POOL) % 4 == 0)
+
+
+def traj_rows(step):
+    """rows of the pool that make up the batch of optimisation step `step` (a stride walk: every batch mixes clean and backdoor rows)"""
+    return (torch.arange(TRAJ_B) * 5 + step * 3) % TRAJ_POOL
+
+
+def traj_noise(step):
+    """(noise [B,3,S,S], timesteps [B]) of step `step` (baddiffusion.py:596, 600 draw them from the global RNG; here they are seeded per step)"""
+    S = SMALL_CFGS["small"].sample_size
+    g = torch.Generator().manual_seed(14000 + step)
+    return torch.randn(TRAJ_B, 3, S, S, generator=g), torch.randint(0, 1000, (TRAJ_B,), generator=g)
+
+
+def traj_sample_init():
+    """clean noise for the trigger-initialised DDPM chains of baddiffusion.py:497-499 (the trigger is added by the caller)"""
+    S = SMALL_CFGS["small"].sample_size
+    return torch.randn(TRAJ_SAMPLE_N, 3, S, S, generator=torch.Generator().manual_seed(141))

@@ -22,6 +22,8 @@ Fixtures:
                     split-plane attention path takes (modules.npz has 8 x 8 / 4 x 4 blocks, which stay on the unfused path)
   full_size_b4.npz G12 the same 256x256 network at B = 4, the per-GPU batch of BASELINE configs[3] (four timesteps, per-sample output
                     slices + checksums, every gradient tensor's norm + leading elements)
+  trajectory.npz G14 32 optimisation steps of baddiffusion.py:590-615 on the small UNet (per-step loss, clip norm, LR; final weights;
+                    DDPM images from noise + trigger with the trained weights)
   pndm.npz      G9  PNDMScheduler timesteps + full chains with a stand-in model, the scheduler every `--sched` other than
                     DDPM / DDIM ends up as (pipeline_pndm.py:46 converts whatever it is given), PNDMPipeline images
 """
@@ -478,7 +480,65 @@ def g13():
     save("anp.npz", **out)
 
 
+# ---- G14: a 32-step training trajectory of the reference's loop body + trigger-initialised sampling from the trained weights -------------
+def g14():
+    """baddiffusion.py:590-615 step by step on SMALL_CFGS["small"]: batches built by the reference's own Backdoor class and blend
+    (dataset.py:275-276, 306-315), loss.p_losses_diffuser, clip_grad_norm_(1.0), torch.optim.Adam, diffusers' get_cosine_schedule_with_warmup;
+    then DDPMPipeline from noise + trigger (baddiffusion.py:497-499) with the weights the trajectory ends with."""
+    import util as ref_util
+    from diffusers.optimization import get_cosine_schedule_with_warmup
+    cfg = SMALL_CFGS["small"]
+    S = cfg.sample_size
+    bd = ref_dataset.Backdoor(root="/tmp")
+    trigger = bd.get_trigger(type=TRAJ_TRIGGER, channel=3, image_size=S)
+    target = bd.get_target(type=TRAJ_TARGET, trigger=trigger)
+    mask = torch.where(trigger > -1.0, 0, 1)                                              # dataset.py:275-276
+    u8, flags = traj_pool()
+    img = ref_util.normalize(vmin_in=0.0, vmax_in=1.0, vmin_out=-1.0, vmax_out=1.0, x=u8.permute(0, 3, 1, 2).float() / 255.0)
+    m = ref_unet(cfg, U.gen_params(cfg, 7)); m.train()
+    sched = DDPMScheduler(num_train_timesteps=1000)
+    opt = torch.optim.Adam(m.parameters(), lr=TRAJ_LR)                                     # baddiffusion.py:320
+    lr_sched = get_cosine_schedule_with_warmup(optimizer=opt, num_warmup_steps=TRAJ_WARMUP, num_training_steps=TRAJ_TOTAL)   # :327-331
+    names = [k for k, _ in m.named_parameters()]
+    losses, norms, lrs, wnorm = [], [], [], []
+    for step in range(TRAJ_STEPS):
+        rows = traj_rows(step)
+        x, f = img[rows], flags[rows]
+        # clean rows: pixel_values = 0, target = image (dataset.py:288-304); backdoor rows: blended image, fixed target (:306-315)
+        R = torch.where(f[:, None, None, None], mask * x + (1 - mask) * trigger, torch.zeros_like(x))
+        x0 = torch.where(f[:, None, None, None], target.expand_as(x), x)
+        noise, t = traj_noise(step)
+        loss = ref_loss.p_losses_diffuser(sched, model=m, x_start=x0, R=R, timesteps=t, noise=noise, loss_type="l2")     # :607
+        loss.backward()
+        gn = torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)                          # :612
+        lrs.append(lr_sched.get_last_lr()[0])                                             # the LR this optimizer step uses
+        opt.step(); lr_sched.step(); opt.zero_grad()                                      # :613-615
+        losses.append(float(loss)); norms.append(float(gn))
+        wnorm.append(float(torch.sqrt(sum((p.detach().double() ** 2).sum() for p in m.parameters()))))
+    out = {"loss": np.array(losses, np.float64), "grad_norm": np.array(norms, np.float64), "lr": np.array(lrs, np.float64),
+           "weight_norm": np.array(wnorm, np.float64), "names": np.array(names),
+           "p8_final": torch.stack([torch.nn.functional.pad(p.detach().flatten()[:8], (0, max(0, 8 - p.numel()))) for p in m.parameters()]),
+           "pnorm_final": torch.stack([p.detach().double().norm() for p in m.parameters()]),
+           "trigger": trigger, "target": target}
+    # distance of every tensor from its start: what 32 Adam steps moved (the tolerance of the test is stated against it)
+    P0 = U.gen_params(cfg, 7)
+    out["pmove_final"] = torch.stack([(p.detach().double() - P0[k].double()).norm() for k, p in m.named_parameters()])
+    m.eval()
+    with torch.no_grad():
+        x, R0, t, eps = train_inputs(cfg, 2)
+        out["pred_final"] = m(ref_loss.q_sample_diffuser(sched, x, R0, t, eps)[0], t, return_dict=False)[0]
+    init = traj_sample_init() + trigger.unsqueeze(0)                                      # :497-499
+    for clip in (True, False):
+        pipe = DDPMPipeline(m, DDPMScheduler(num_train_timesteps=1000, clip_sample=clip))
+        pipe.set_progress_bar_config(disable=True)
+        r = pipe(batch_size=init.shape[0], generator=torch.Generator().manual_seed(PIPE_SEED), init=init, output_type=None,
+                 num_inference_steps=TRAJ_SAMPLE_STEPS)
+        out[f"ddpm{TRAJ_SAMPLE_STEPS}_trigger_init_{int(clip)}"] = r.images
+    print("G14 loss", losses[0], "->", losses[-1], "| lr", lrs[0], lrs[TRAJ_WARMUP], lrs[-1], "| clip norm", norms[0], norms[-1])
+    save("trajectory.npz", **out)
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13"]
+    which = sys.argv[1:] or ["g1", "g2", "g3", "g4", "g5", "g6", "g7", "g8", "g9", "g10", "g11", "g12", "g13", "g14"]
     for w in which:
         globals()[w]()

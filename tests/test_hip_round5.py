@@ -1,0 +1,121 @@
+"""GPU parity, round 5.
+
+  * G14 (tests/golden/trajectory.npz): 32 optimisation steps of the reference's loop body (baddiffusion.py:590-615: p_losses_diffuser -> backward ->
+    clip_grad_norm_(1.0) -> torch.optim.Adam -> get_cosine_schedule_with_warmup) run by the reference's own modules on SMALL_CFGS["small"]; TrainEngine
+    replays it from the raw uint8 rows in both compute modes: per-step loss, pre-clip norm, LR, the weights it ends with, a forward with them, and the
+    trigger-initialised DDPM images (baddiffusion.py:497-499).  The drift of the split-bf16 mode against the exact mode is reported next to both.
+Tolerance: 1e-3 relative fp32 (BASELINE.json north_star) unless a tighter one is stated."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import backdoor_ref as BD
+from oracle import unet_ref as U
+from tests.golden import cases as C
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    if not torch.cuda.is_available():
+        pytest.skip("no GPU")
+    return torch.device("cuda")
+
+
+def make_model(cfg, seed, dev, mode=None):
+    from baddiffusion_amd.unet import unet_from_config
+    m = unet_from_config(cfg, **({"compute_mode": mode} if mode else {})).to(dev)
+    m.load_state_dict(U.gen_params(cfg, seed))
+    return m
+
+
+def _replay_trajectory(mode, gpu):
+    """TrainEngine over the G14 inputs; returns (losses, norms, lrs, state_dict on the CPU, model)"""
+    from baddiffusion_amd.dataset import Backdoor
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    cfg = C.SMALL_CFGS["small"]
+    bd = Backdoor(root=None)
+    trigger = bd.get_trigger(C.TRAJ_TRIGGER, 3, cfg.sample_size)
+    target = bd.get_target(C.TRAJ_TARGET, trigger)
+    m = make_model(cfg, 7, gpu, mode)
+    eng = TrainEngine(m, DDPMScheduler(), lr=C.TRAJ_LR, lr_warmup_steps=C.TRAJ_WARMUP, num_training_steps=C.TRAJ_TOTAL)
+    u8, flags = C.traj_pool()
+    u8, flags = u8.to(gpu), flags.to(gpu)
+    tr, tg = trigger.to(gpu), target.to(gpu)
+    losses, norms, lrs = [], [], []
+    for step in range(C.TRAJ_STEPS):
+        rows = C.traj_rows(step).to(gpu)
+        noise, t = C.traj_noise(step)
+        lrs.append(eng.current_lr())
+        loss = eng.train_step(u8[rows].contiguous(), flags[rows], tr, tg, noise.to(gpu), t.to(gpu))
+        losses.append(float(loss)); norms.append(float(eng.grad_norm))
+    eng.close()
+    return np.array(losses), np.array(norms), np.array(lrs), {k: v.detach().cpu() for k, v in m.state_dict().items()}, m, trigger, target
+
+
+def test_train_engine_replays_reference_trajectory(gpu, golden):
+    from baddiffusion_amd import ops
+    from baddiffusion_amd.pipelines import DDPMPipeline
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    g = golden("trajectory")
+    cfg = C.SMALL_CFGS["small"]
+    names = [str(n) for n in g["names"]]
+    numel = {k: int(v.numel()) for k, v in U.gen_params(cfg, 7).items()}
+    per_elem_move = np.array([g["pmove_final"][i] / np.sqrt(numel[k]) for i, k in enumerate(names)])
+    report, final = {}, {}
+    for mode in ("f32", "bf16x3"):
+        losses, norms, lrs, sd, m, trigger, target = _replay_trajectory(mode, gpu)
+        assert torch.equal(trigger, torch.from_numpy(g["trigger"])) and torch.equal(target, torch.from_numpy(g["target"]))
+        np.testing.assert_allclose(lrs, g["lr"], rtol=1e-9, atol=1e-15)                    # optimization.py:134-138, the LR each step used
+        rl = np.abs(losses - g["loss"]) / g["loss"]
+        rn = np.abs(norms - g["grad_norm"]) / g["grad_norm"]
+        assert rl.max() <= 1e-3, (mode, rl.argmax(), rl.max())                             # every one of the 32 steps, north_star's bound
+        assert rn.max() <= 2e-3, (mode, rn.argmax(), rn.max())
+        worst = worst_rel_move = 0.0
+        for i, k in enumerate(names):
+            if k.endswith("key.bias"):        # gradient mathematically zero (softmax shift invariance): Adam amplifies rounding noise to +-lr steps
+                continue
+            got = sd[k].flatten()[:8].numpy()
+            d = float(np.abs(got - g["p8_final"][i][: got.size]).max())
+            worst = max(worst, d)
+            worst_rel_move = max(worst_rel_move, d / max(per_elem_move[i], 1e-12))
+            assert abs(float(sd[k].double().norm()) - g["pnorm_final"][i]) <= 1e-4 * g["pnorm_final"][i] + 1e-6, (mode, k)
+        # The 32 steps displace an element by ~7.7e-4 (median of pmove_final / sqrt(numel)); Adam's m / sqrt(v) is a sign-like function of small
+        # gradients, so a 1e-3-relative gradient difference can move single elements by a fraction of an lr per step.  Held to 5e-5 absolute
+        # (6 % of the typical displacement); the CPU oracle, same arithmetic as the reference, reaches 2.4e-7.
+        assert worst <= 5e-5, (mode, worst, worst_rel_move)
+        x, R0, t, eps = C.train_inputs(cfg, 2)
+        xn, _ = ops.qsample(x.to(gpu), R0.to(gpu), eps.to(gpu), t.to(gpu), *DDPMScheduler().device_tables(gpu))
+        with torch.no_grad():
+            pred = m(xn.permute(0, 3, 1, 2), t.to(gpu), return_dict=False)[0].cpu().numpy()
+        np.testing.assert_allclose(pred, g["pred_final"], rtol=1e-3, atol=1e-3 * float(np.abs(g["pred_final"]).max()))
+        imgs = {}
+        for clip in (True, False):
+            pipe = DDPMPipeline(m, DDPMScheduler(clip_sample=clip))
+            init = C.traj_sample_init() + trigger.unsqueeze(0)                              # baddiffusion.py:497-499
+            r = pipe(batch_size=init.shape[0], generator=torch.Generator().manual_seed(C.PIPE_SEED), init=init, output_type=None,
+                     num_inference_steps=C.TRAJ_SAMPLE_STEPS)
+            np.testing.assert_allclose(r.images, g[f"ddpm{C.TRAJ_SAMPLE_STEPS}_trigger_init_{int(clip)}"], rtol=1e-3, atol=1e-3)
+            imgs[clip] = r.images
+        final[mode] = (losses, sd, pred, imgs)
+        report[mode] = {"max_rel_loss_err": float(rl.max()), "max_rel_clipnorm_err": float(rn.max()), "worst_weight_abs_err_first8": worst,
+                        "worst_weight_err_over_typical_displacement": worst_rel_move,
+                        "pred_final_max_abs_err": float(np.abs(pred - g["pred_final"]).max())}
+    # drift of the split-bf16 mode against the exact mode over the 32 steps
+    lf, sf, pf, _ = final["f32"]
+    lb, sb, pb, _ = final["bf16x3"]
+    wd = max(float((sf[k] - sb[k]).abs().max()) for k in sf if not k.endswith("key.bias"))
+    report["bf16x3_vs_f32"] = {"max_rel_loss_diff": float((np.abs(lf - lb) / lf).max()), "max_weight_abs_diff": wd,
+                               "pred_final_max_abs_diff": float(np.abs(pf - pb).max())}
+    assert report["bf16x3_vs_f32"]["max_rel_loss_diff"] <= 1e-3 and wd <= 2.5 * C.TRAJ_LR
+    os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+    with open(os.path.join(ROOT, "gpurun_out", "r05_trajectory_drift.json"), "w") as f:
+        json.dump(report, f, indent=1)
+    print("G14 drift report:", json.dumps(report))

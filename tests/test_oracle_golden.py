@@ -426,3 +426,59 @@ def test_anp_oracle_matches_reference_vectors(golden):
     close(after[big], g["bn_after"][big.numpy()], rtol=1e-5, atol=1e-6)
     assert float(after.abs().max()) <= C.ANP_BUDGET + 1e-7 and float((after.abs() >= C.ANP_BUDGET - 1e-7).float().mean()) > 0.05
     close(bm, g["backdoor_mse"], rtol=1e-4)
+
+
+# ------------------------------------------------------------------ G14: a 32-step trajectory of the reference's loop body
+def traj_batch(step, trigger, target):
+    """(R, x0, noise, t) of optimisation step `step`, built with the oracle's blend (pinned by G3) from the seeded pool of cases.py"""
+    u8, flags = C.traj_pool()
+    rows = C.traj_rows(step)
+    x = torch.stack([BD.image_u8_to_float(u8[i]) for i in rows.tolist()])
+    R, x0 = BD.make_batch(x, flags[rows], trigger, target)
+    noise, t = C.traj_noise(step)
+    return R, x0, noise, t
+
+
+def test_oracle_replays_reference_training_trajectory(golden):
+    """G14 (tests/golden/trajectory.npz): 32 steps of baddiffusion.py:590-615 run by the reference's own modules, optimizer and LR schedule.  The
+    oracle (loss_ref + unet_ref + train_ref.clip_and_adam + cosine_lr_lambda) replays it: per-step loss, pre-clip norm and LR, the final weights, and
+    the 5-step DDPM images from noise + trigger (baddiffusion.py:497-499) with those weights."""
+    g = golden("trajectory")
+    cfg = C.SMALL_CFGS["small"]
+    trigger, target = BD.get_trigger(C.TRAJ_TRIGGER, 3, cfg.sample_size), None
+    target = BD.get_target(C.TRAJ_TARGET, trigger)
+    assert torch.equal(trigger, T(g["trigger"])) and torch.equal(target, T(g["target"]))
+    _, a, ac = sched_ref.make_tables()
+    P, state = U.gen_params(cfg, 7), {}
+    for step in range(C.TRAJ_STEPS):
+        R, x0, noise, t = traj_batch(step, trigger, target)
+        loss, G = train_ref.loss_and_grads(cfg, P, a, ac, x0, R, t, noise)
+        lr = C.TRAJ_LR * train_ref.cosine_lr_lambda(step, C.TRAJ_WARMUP, C.TRAJ_TOTAL)
+        P, state, norm = train_ref.clip_and_adam(P, G, state, lr, step + 1)
+        assert abs(lr - g["lr"][step]) <= 1e-12 + 1e-9 * g["lr"][step], (step, lr, g["lr"][step])
+        # fp32 on the same host, different op order (functional oracle vs nn.Module autograd): 1e-4 holds over the whole trajectory
+        assert abs(float(loss) - g["loss"][step]) <= 1e-4 * g["loss"][step], (step, float(loss), g["loss"][step])
+        assert abs(float(norm) - g["grad_norm"][step]) <= 5e-4 * g["grad_norm"][step], (step, float(norm), g["grad_norm"][step])
+    names = [str(n) for n in g["names"]]
+    move = g["pmove_final"]
+    for i, k in enumerate(names):
+        if k.endswith("key.bias"):        # gradient mathematically zero: Adam turns rounding noise into +-lr steps on both sides
+            continue
+        got = P[k].flatten()[:8].numpy()
+        want = g["p8_final"][i][: got.size]
+        # measured: 2.4e-7 worst element against a typical per-element displacement of 7.7e-4 over the 32 steps (pmove_final / sqrt(numel));
+        # held to 1e-5 = 1.3 % of that displacement
+        assert abs(float(P[k].double().norm()) - g["pnorm_final"][i]) <= 1e-5 * g["pnorm_final"][i] + 1e-7, k
+        assert np.abs(got - want).max() <= 1e-5, (k, got, want, move[i])
+    with torch.no_grad():
+        x, R0, t, eps = C.train_inputs(cfg, 2)
+        pred = U.unet_forward(cfg, P, loss_ref.q_sample(a, ac, x, R0, t, eps)[0], t)
+        close(pred, g["pred_final"], 2e-3, 2e-4)
+        for clip in (True, False):
+            gen = torch.Generator().manual_seed(C.PIPE_SEED)
+            x = C.traj_sample_init() + trigger.unsqueeze(0)
+            for tt in sched_ref.ddpm_timesteps(C.TRAJ_SAMPLE_STEPS):
+                e = U.unet_forward(cfg, P, x, int(tt))
+                z = torch.randn(x.shape, generator=gen) if tt > 0 else None
+                x, _ = sched_ref.ddpm_step(ac, e, int(tt), x, z, num_inference_steps=C.TRAJ_SAMPLE_STEPS, clip_sample=clip)
+            close(sched_ref.to_image(x), g[f"ddpm{C.TRAJ_SAMPLE_STEPS}_trigger_init_{int(clip)}"], 2e-3, 5e-4)
