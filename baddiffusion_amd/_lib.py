@@ -235,6 +235,7 @@ SIGNATURES = {
     "bd_unet_set_aux_stream": (i32, [vp, i32]),
     "bd_unet_set_static_weights": (i32, [vp, i32]),
     "bd_unet_reset_static_cache": (i32, [vp]),
+    "bd_tune_set": (i32, [C.c_char_p, i32]),
     "bd_unet_segment_range": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
     "bd_unet_segment_num_ranges": (i32, [vp, i32]),
     "bd_unet_segment_range_k": (i32, [vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]),

@@ -71,6 +71,9 @@ __device__ __forceinline__ float silu_grad_f(float z) {
     return s * (1.0f + z * (1.0f - s));
 }
 
+// ---- run-time tuning knobs (bd_tune_set): a generation counter that makes every plan lay its workspace out again -----------------
+extern int g_tune_gen;
+
 // ---- internal (non-ABI) launchers shared between files -------------------------------------------
 int igemm_launch(const bd_igemm_desc& d, hipStream_t stream);
 size_t igemm_workspace_bytes(const bd_igemm_desc& d);

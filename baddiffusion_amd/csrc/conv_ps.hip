@@ -17,6 +17,7 @@
 // with the gather direction negated (sign = -1) over the TRANSPOSED weight planes Wt[ci][tap][co] (bd_split_wt).
 // Replaces aten::convolution / convolution_backward(input) of resnet.py:493,514 for the stride-1 convolutions.
 #include "common.h"
+#include <string.h>
 
 #include <type_traits>
 #include <cstdlib>
@@ -1576,6 +1577,7 @@ static bool ps_wgrad_v3(const bd_conv3x3_ps_wgrad_desc& d) {
     // round 4: any W >= 16 -- wider images are walked strip by strip (virtual pixel order, ps_v2r): a chunk = one 32-pixel strip row
     return !off && d.W >= 16 && d.W <= maxw && ((long long)d.B * d.H * d.W) % 32 == 0;
 }
+static int g_wg3_slots_override = 0;     // 0: environment / default (set by bd_tune_set)
 static void ps_wgrad_split(const bd_conv3x3_ps_wgrad_desc& d, int& ksplit, int& cps) {
     const bool v3 = ps_wgrad_v3(d);
     const long long tiles = (long long)(d.Cout / WG_BM) * ((v3 ? 3 : 9) * d.Cin / WG_BN);
@@ -1592,7 +1594,8 @@ static void ps_wgrad_split(const bd_conv3x3_ps_wgrad_desc& d, int& ksplit, int& 
     // Images walked strip by strip (W > 32: the 256 x 256 network at B = 4, whose main stream carries the three-pass GroupNorm and 2 048-tile data
     // gradients): HALF the CUs -- 27.14 -> 26.69 ms per step (144 / 160 / 176 slots: 27.52 / 27.51 / 27.74; 112 / 96 / 64: 27.21 / 28.16 / 32.9), while the
     // CIFAR step wants its 192 (128: 18.08 against 17.89).
-    static const int slots3_env = getenv("BD_PS_WG3_SLOTS") ? atoi(getenv("BD_PS_WG3_SLOTS")) : 0;
+    static const int slots3_getenv = getenv("BD_PS_WG3_SLOTS") ? atoi(getenv("BD_PS_WG3_SLOTS")) : 0;
+    const int slots3_env = g_wg3_slots_override > 0 ? g_wg3_slots_override : slots3_getenv;      // bd_tune_set("ps_wg3_slots", n) wins over the environment
     const int slots3 = slots3_env > 0 ? slots3_env : (d.W > 32 ? slots / 4 : slots * 3 / 8);
     static const int mincps = getenv("BD_PS_WG_MINCPS") ? atoi(getenv("BD_PS_WG_MINCPS")) : 8;   // chunks per split at least (4x4 layers: 8 slabs instead of 14; 4 / 16 measured +0.2 / +0.1 ms)
     int ks = (int)((v3 ? slots3 : slots) / tiles);
@@ -1715,8 +1718,16 @@ int upsample_conv_wgrad(const bd_upsample_conv_desc& d, hipStream_t st) {
     return BD_OK;
 }
 
+int g_tune_gen = 0;
+int tune_set(const char* key, int value) {
+    BD_CHECK(key, BD_ERR_INVALID, "bd_tune_set: null key");
+    if (!strcmp(key, "ps_wg3_slots")) { g_wg3_slots_override = value > 0 ? value : 0; ++g_tune_gen; return BD_OK; }
+    set_error("bd_tune_set: unknown key '%s' (known: ps_wg3_slots)", key);
+    return BD_ERR_INVALID;
+}
 }  // namespace bd
 
+extern "C" int bd_tune_set(const char* key, int value) { return bd::tune_set(key, value); }
 extern "C" size_t bd_upsample_conv_wgrad_workspace_bytes(const bd_upsample_conv_desc* d) {
     return d ? bd::upsample_conv_wgrad_workspace_bytes(*d) : 0;
 }

@@ -140,7 +140,7 @@ struct bd_unet {
     std::vector<Seg> segs;   // indexed by segment id (backward order)
     int cur_seg = 0, cur_group = 0;
     // layout cache
-    int lay_B = -1, lay_train = -1;
+    int lay_B = -1, lay_train = -1, lay_gen = -1;
     int64_t value_floats = 0, grad_floats = 0, scratch_floats = 0;
     size_t opws_bytes = 0, gnpart_floats = 0;
     int T = 0, sumC = 0;     // time-embed dim, total time_emb_proj rows
@@ -1247,7 +1247,7 @@ void bd_unet::build() {
 }
 
 void bd_unet::layout(int B, int training) {
-    if (lay_B == B && lay_train == training) return;
+    if (lay_B == B && lay_train == training && lay_gen == bd::g_tune_gen) return;
     auto al = [](int64_t x) { return (x + 63) / 64 * 64; };
     int64_t v = 0, g = 0;
     for (auto& b : bufs) if (b.region == R_VALUE) { b.off = v; if (!b.live || b.live(B, training)) v += al(b.per_sample * B + b.fixed); }
@@ -1275,7 +1275,7 @@ void bd_unet::layout(int B, int training) {
     if (training) for (auto it = bwd.rbegin(); it != bwd.rend(); ++it) it->fn(c);
     opws_bytes = align_up(c.opws_need, 256);
     gnpart_floats = training ? c.gnpart_need : 0;
-    lay_B = B; lay_train = training;
+    lay_B = B; lay_train = training; lay_gen = bd::g_tune_gen;
     prep_params = nullptr; prep_ws = nullptr; prep_B = -1;   // a new layout moves the prepared planes inside the workspace
 }
 

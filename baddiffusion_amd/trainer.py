@@ -212,8 +212,8 @@ class TrainEngine:
         # (default group backend nccl, or the forced 1-rank path); c10d otherwise (gloo: CPU tests / ranks sharing a GPU)
         self._rccl = None
         self.transport_note = None       # why the direct RCCL transport is not in use (None: it is, or it was never asked for)
-        if self.dp and self.world == 1 and os.environ.get("BD_DP_TRANSPORT", "rccl") == "none":
-            self._rccl = "none"
+        if self.dp and os.environ.get("BD_DP_TRANSPORT", "rccl") == "none":
+            self._rccl = "none"          # measurement only: at world > 1 the replicas drift apart (nothing is exchanged)
         if self.dp and os.environ.get("BD_DP_TRANSPORT", "rccl") == "rccl":
             be = dist.get_backend(process_group) if (dist.is_available() and dist.is_initialized()) else "none"
             if process_group is None and (be == "nccl" or self.world == 1):
@@ -223,6 +223,9 @@ class TrainEngine:
         if dp_check and self.accum != 1:
             raise ValueError("dp_check needs grad_accum_steps == 1")
         self.collective_bytes = 0
+        # measurement hooks (bench.py): events on the communication stream around every bucket's collective(s)
+        self.time_buckets = False
+        self._bucket_events = []
         self.alphas, self.alphas_cumprod = noise_sched.device_tables(dev)
         self.sync_state()
 
@@ -275,6 +278,33 @@ class TrainEngine:
                 ensure_single_rank_group()
             return None, reason
         return comm, None
+
+    # ---- measurement hooks (bench.py --gpus N) ---------------------------------------------------------------
+    def set_buckets(self, bucket_mb):
+        """re-plan the communication buckets (sweeps): same segments, another fusion size"""
+        self._buckets = plan_buckets(self._seg_ranges, int(float(bucket_mb) * 2 ** 20), pads=self.model._pads)
+        self._bucket_at = {s: rs for s, rs in self._buckets}
+
+    def set_collectives(self, enabled):
+        """False: every step runs the whole data-parallel path EXCEPT the collective calls (exposed-communication measurement: the
+        replicas drift apart -- call sync_state() afterwards).  True: restore the transport chosen at construction."""
+        if not enabled:
+            if getattr(self, "_rccl_saved", None) is None:
+                self._rccl_saved = (self._rccl,)
+            self._rccl = "none"
+        elif getattr(self, "_rccl_saved", None) is not None:
+            self._rccl = self._rccl_saved[0]
+            self._rccl_saved = None
+
+    def bucket_times(self):
+        """[(last segment of the bucket, bytes, mean ms, launches)] from the events recorded while time_buckets was on (synchronises)"""
+        torch.cuda.synchronize()
+        acc = {}
+        for s, e0, e1, nbytes in self._bucket_events:
+            a = acc.setdefault(s, [nbytes, 0.0, 0])
+            a[1] += e0.elapsed_time(e1); a[2] += 1
+        self._bucket_events = []
+        return [(s, a[0], a[1] / a[2], a[2]) for s, a in sorted(acc.items())]
 
     def close(self):
         """Tear the gradient communicator down explicitly (while the HIP runtime is still up; otherwise it goes with the object)."""
@@ -333,7 +363,13 @@ class TrainEngine:
                 if self._defer:     # (without the deferred join the segment call has already ordered `main` behind the side stream)
                     L.check(self._lib.bd_unet_stream_wait_aux(model._plan, self._comm.cuda_stream), "bd_unet_stream_wait_aux")
                 with torch.cuda.stream(self._comm):
+                    if self.time_buckets:     # `e0` fires once the waits above are satisfied, `e1` when the collective has finished
+                        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                        e0.record()
                     red.reduce_ranges(ranges)
+                    if self.time_buckets:
+                        e1.record()
+                        self._bucket_events.append((s, e0, e1, sum(hi - lo for lo, hi in ranges) * 4))
             else:
                 red.reduce_ranges(ranges)
         red.finish()          # the main stream waits for every collective (work.wait() orders the CURRENT stream)

@@ -320,19 +320,25 @@ def bench_sampling(args, world, rank, dev):
     from baddiffusion_amd.model import KNOWN_TOPOLOGIES
     from baddiffusion_amd.unet import UNet2DModel
     model = UNet2DModel(**KNOWN_TOPOLOGIES["google/ddpm-cifar10-32"], compute_mode=args.mode).to(dev)
-    n = args.batch if args.batch > 0 else 512
+    # BASELINE configs[4]: ONE job of eval_max_batch 2048 chains sharded over the GPUs (rows contiguous per rank, no collective): strong scaling.
+    # --batch n keeps n chains per GPU instead (weak scaling).
+    strong = args.batch <= 0
+    total = args.total if args.total > 0 else 2048
+    n = args.batch if args.batch > 0 else max(1, total // world)
     res = run_sampling(model, args.workload, n, args.mode, world, rank, dev, L.load(), want_roofline=not args.no_prof)
     if world > 1:
         dist.destroy_process_group()
     if rank == 0:
         steps = 1000 if args.workload == "ddpm1000" else 50
         line = {"metric": res["metric"], "value": res["value"], "unit": "samples/s", "n_gpus": world, "steps": steps, "warmup": 5,
-                "ms_per_step": res["seconds_per_loop"] / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "ms_per_step": res["seconds_per_loop"] / steps * 1e3, "higher_is_better": True, "scaling": "strong" if strong else "weak",
+                "vs_baseline": None,
                 "dtype": "f32" if args.mode == "f32" else "f32 (split-bf16 hi+lo products, fp32 accumulate)",
                 "data": "synthetic (seeded N(0,1) init, seeded default-init weights)",
                 "config": {"workload": f"BASELINE configs[4]-style sampling: {args.workload} loop, {n} samples per GPU, images to float NHWC "
                                        f"at the end, no PNG I/O", "global_batch": world * n,
-                           "parallelism": f"replicas x{world} (rows sharded, no collective)"}}
+                           "parallelism": f"replicas x{world} (rows sharded, no collective)",
+                           "inference_chunk": getattr(model, "last_chunk", None)}}
         line.update({k: v for k, v in res.items() if k not in line})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = sampling_cpu_baseline()["ddpm1000" if args.workload == "ddpm1000" else "ddim50"]
@@ -524,6 +530,67 @@ def timed_steps(step, first, n, barrier, dev, world, prof=None):
     return dt, loss, per
 
 
+def measure_dp(eng, model, step, lib, barrier, dev, world, args, log, first):
+    """N > 1, behind the contract region (every rank runs the same sequence, so collectives stay matched): (1) per-bucket collective time from
+    events on the communication stream; (2) EXPOSED communication = the step with the collectives minus the same step with every part of the
+    data-parallel path except the collective calls (TrainEngine.set_collectives(False); the replicas are re-synchronised from rank 0 afterwards);
+    (3) sweeps of the bucket size and of the large weight-gradient kernel's K-split slot count (collectives take CUs from kernels sized for all
+    256) -- one multi-GPU lease yields the scaling curve AND the two settings that matter for it.  Each point: 2 untimed + 6 timed steps under the
+    same barrier rule as the contract region."""
+    state = {"i": first}
+
+    def timed(n=6, warm=2):
+        for _ in range(warm):
+            step(state["i"]); state["i"] += 1
+        dt, _, _ = timed_steps(step, state["i"], n, barrier, dev, world)
+        state["i"] += n
+        return dt / n * 1e3
+
+    direct = getattr(eng, "_rccl", None) not in (None, "none")
+    out = {"transport": "rccl-direct" if direct else "c10d", "ms_per_step": timed(8)}
+    eng.time_buckets = True
+    for _ in range(4):
+        step(state["i"]); state["i"] += 1
+    eng.time_buckets = False
+    out["buckets_timed"] = [{"closes_with_segment": s, "bytes": b, "ms_on_comm_stream": ms, "launches": n,
+                             "ring_bus_GBs": 2.0 * (world - 1) / world * b / (ms * 1e-3) / 1e9 if ms > 0 else None}
+                            for s, b, ms, n in eng.bucket_times()]
+    out["buckets_timed_note"] = ("events on the engine's communication stream around each bucket's grouped ncclAllReduce, 4 steps, in schedule (beside the "
+                                 "backward kernels)" if direct else "c10d transport: the collectives run on the process group's own stream / threads, "
+                                 "these events do not bracket them")
+    barrier()
+    eng.set_collectives(False)
+    out["ms_per_step_without_collectives"] = timed(8)
+    eng.set_collectives(True)
+    eng.sync_state()           # the replicas applied their own gradients for those steps: start again from rank 0's state
+    barrier()
+    out["exposed_comm_ms"] = out["ms_per_step"] - out["ms_per_step_without_collectives"]
+    if not args.no_dp_sweep:
+        default_mb = float(os.environ.get("BD_DP_BUCKET_MB", "32"))
+        sw = []
+        for mb in [float(v) for v in args.dp_sweep_buckets.split(",") if v.strip()]:
+            eng.set_buckets(mb)
+            sw.append({"bucket_mb": mb, "buckets": len(eng._buckets), "collectives_per_step": sum(len(rs) for _, rs in eng._buckets),
+                       "ms_per_step": timed()})
+            log(f"dp sweep: bucket {mb:g} MB -> {sw[-1]['buckets']} buckets, {sw[-1]['ms_per_step']:.2f} ms/step")
+        eng.set_buckets(default_mb)
+        out["bucket_sweep"] = sw
+        ss = []
+        for sl in [int(v) for v in args.dp_sweep_slots.split(",") if v.strip()]:
+            L_check = lib.bd_tune_set(b"ps_wg3_slots", sl)
+            model._ws_pool = {}            # workspace sizes follow the slot count
+            if L_check != 0:
+                ss.append({"ps_wg3_slots": sl, "error": "bd_tune_set refused"}); continue
+            ss.append({"ps_wg3_slots": sl, "ms_per_step": timed()})
+            log(f"dp sweep: wgrad3 slots {sl} -> {ss[-1]['ms_per_step']:.2f} ms/step")
+        lib.bd_tune_set(b"ps_wg3_slots", 0)
+        model._ws_pool = {}
+        out["wgrad3_slot_sweep"] = ss
+        out["sweep_note"] = ("defaults: BD_DP_BUCKET_MB=%g, ps_wg3_slots = 3/4 of the CUs; each point 2 untimed + 6 timed steps behind the contract region; "
+                             "set BD_DP_BUCKET_MB / BD_PS_WG3_SLOTS in the environment to make a value the default of a run" % default_mb)
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -543,6 +610,15 @@ def main():
     ap.add_argument("--no-celeba", action="store_true", help="skip the 256x256 batch-4 train step of the default line")
     ap.add_argument("--no-dp-probe", action="store_true", help="skip the N = 1 measurement of the data-parallel communication path "
                                                                "(TrainEngine(force_dp=True): RCCL on a 1-rank group)")
+    ap.add_argument("--no-dp-sweep", action="store_true", help="N > 1: skip the bucket-size / weight-gradient-slot sweep and the exposed-communication "
+                                                               "measurement behind the timed region")
+    ap.add_argument("--dp-sweep-buckets", default=os.environ.get("BD_BENCH_SWEEP_BUCKETS", "0,8,32,64,1000000"),
+                    help="N > 1: BD_DP_BUCKET_MB values timed behind the contract region (0 = one bucket per backward segment, 1000000 = ONE bucket)")
+    ap.add_argument("--dp-sweep-slots", default=os.environ.get("BD_BENCH_SWEEP_SLOTS", "128,160,192,224"),
+                    help="N > 1: K-split slot counts of the large weight-gradient kernel (bd_tune_set ps_wg3_slots) timed behind the contract region: "
+                         "collectives take CUs from kernels sized for all 256")
+    ap.add_argument("--total", type=int, default=0, help="sampling workloads: GLOBAL number of chains, sharded over the ranks (strong scaling; "
+                                                         "default 2048 = BASELINE configs[4]'s eval_max_batch); --batch gives a per-GPU count instead")
     ap.add_argument("--sustain", type=float, default=10.0, help="seconds of back-to-back train steps after the timed region "
                                                                 "(a sustained figure on a power-limited part); 0 = skip")
     ap.add_argument("--graph", type=int, default=int(os.environ.get("BD_TRAIN_GRAPH", "0")),
@@ -629,6 +705,14 @@ def main():
                      "ms_per_step_median": sper[len(sper) // 2], "ms_per_step_p90": sper[int(len(sper) * 0.9)]}
         log(f"sustained: {n_sus} steps in {sdt:.1f} s = {sdt / n_sus * 1e3:.2f} ms/step")
 
+    dp_meas = None
+    if world > 1 and not celeba:
+        try:
+            dp_meas = measure_dp(eng, model, step, lib, barrier, dev, world, args, log, args.warmup + 4 * args.steps + 100000)
+            log(f"dp: {dp_meas['ms_per_step']:.2f} ms/step, without collectives {dp_meas['ms_per_step_without_collectives']:.2f}")
+        except Exception as e:        # never lose the headline line to a side measurement
+            dp_meas = {"error": f"{type(e).__name__}: {e}"}
+
     dp_probe = None
     if world == 1 and not celeba and not args.no_dp_probe:
         # the data-parallel communication path at N = 1 (task 3): a second engine over the same model with
@@ -700,6 +784,13 @@ def main():
         for kind, n in (("ddim50", n_ddim), ("ddpm1000", n_ddpm)):
             sampling[kind] = run_sampling(smodel, kind, n, args.mode, world, rank, dev, lib, want_roofline=not args.no_prof)
             log(f"{kind}: {sampling[kind]['value']:.1f} samples/s ({sampling[kind]['seconds_per_loop']:.1f} s)")
+        if world > 1:
+            # BASELINE configs[4] itself: ONE job of eval_max_batch 2048 DDIM-50 chains sharded over the ranks (strong scaling, no collective)
+            tot = args.total if args.total > 0 else 2048
+            sh = run_sampling(smodel, "ddim50", max(1, tot // world), args.mode, world, rank, dev, lib, want_roofline=False)
+            sh["scaling"] = "strong"; sh["global_samples"] = max(1, tot // world) * world
+            sampling["ddim50_sharded"] = sh
+            log(f"ddim50 sharded ({sh['global_samples']} chains over {world} ranks): {sh['value']:.1f} samples/s")
         del smodel
         torch.cuda.empty_cache()
 
@@ -760,6 +851,10 @@ def main():
                "distributed": {"world": world, "backend": backend if world > 1 else "none (single process)",
                                "gradient_transport": ("RCCL called directly on the engine's communication stream (baddiffusion_amd/rccl.py)"
                                                       if eng._rccl is not None else ("torch.distributed (c10d)" if world > 1 else "none")),
+                               "rccl_ranks": (eng._rccl.world if getattr(eng, "_rccl", None) not in (None, "none") else None),
+                               "rccl_self_test": ("passed: ncclAllReduce of a rank-dependent vector equals its closed form on every rank (collective MIN)"
+                                                  if getattr(eng, "_rccl", None) not in (None, "none") else None),
+                               "transport_fallback_reason": getattr(eng, "transport_note", None),
                                "collectives_per_step": sum(len(rs) for _, rs in eng._buckets) if world > 1 else 0,
                                "segments": nseg, "buckets": len(eng._buckets), "bytes_per_bucket": coll, "bytes_per_step": sum(coll),
                                "note": "backward segments are fused into buckets of >= BD_DP_BUCKET_MB (32); when a bucket's last segment has run, "
@@ -772,6 +867,8 @@ def main():
                 roofline_object(classes, classes_iso, prof_steps, args.mode, ms, probe, "celeba" if celeba else "")
         if dp_probe:
             out["dp_path_at_world_1"] = dp_probe
+        if dp_meas:
+            out["distributed"]["measured"] = dp_meas
         if world == 1 and not args.no_cpu_baseline:
             log("cpu baseline (oracle on host cores) ...")
             out["cpu_baseline"] = cpu_baseline(kind="celeba") if celeba else cpu_baseline()
@@ -781,7 +878,8 @@ def main():
             if sampling:
                 sb = sampling_cpu_baseline()
                 for k in sampling:
-                    sampling[k]["cpu_baseline"] = sb[k]
+                    if k in sb:
+                        sampling[k]["cpu_baseline"] = sb[k]
         if sampling:
             out["sampling"] = sampling
         if side:

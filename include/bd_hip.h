@@ -358,6 +358,11 @@ typedef struct {
     float* dw; float* db;
     void* workspace; size_t workspace_bytes;
 } bd_conv3x3_ps_wgrad_desc;
+/* Run-time tuning knob for measurement sweeps (bench.py --gpus N sweeps the weight-gradient slot count inside ONE process, because a
+ * multi-GPU node is leased once): key "ps_wg3_slots" = K-split slots of conv_ps_wgrad3_kernel (0 restores BD_PS_WG3_SLOTS / the default:
+ * 3/4 of the CUs, 1/2 for strip-order images).  Workspace sizes depend on it: every plan lays out again on its next call, callers must
+ * re-query bd_unet_workspace_bytes.  Results are unchanged up to the fp32 summation order of the K-split. */
+int bd_tune_set(const char* key, int value);
 size_t bd_conv3x3_ps_wgrad_workspace_bytes(const bd_conv3x3_ps_wgrad_desc* d);
 int bd_conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc* d, bd_stream_t stream);
 

@@ -40,7 +40,7 @@ def procedural_images(n, size=32, seed=0):
         x0, y0 = rng.integers(0, size - 8, 2)
         w_, h_ = rng.integers(4, 12, 2)
         img[y0:y0 + h_, x0:x0 + w_] = rng.random(3)
-        out[i] = img
+        out[i] = img * (0.05 + 0.95 * rng.random() ** 2)          # overall brightness from near-black to full (natural sets hold dark images too)
     return (np.clip(out, 0, 1) * 255 + 0.5).astype(np.uint8)
 
 
@@ -109,12 +109,17 @@ def main():
             out[tag] = float(((pred.permute(0, 2, 3, 1) - tg) ** 2).mean())
         return out
 
+    hx = (held[: args.eval_n].permute(0, 3, 1, 2).float() / 255.0).cpu() / (1.0 + 1e-5) * 2.0 - 1.0
+    mask = dsl.get_mask(dsl.trigger).float()
+    held_R = mask * hx + (1 - mask) * dsl.trigger                                                   # dataset.py:306-315
     init = torch.randn(args.eval_n, 3, 32, 32, generator=torch.Generator().manual_seed(0))        # measure(): noise, then noise + trigger (:497-499)
     tgt01 = (dsl.target / 2 + 0.5).clamp(0, 1).permute(1, 2, 0).numpy()                          # :538-546 compare images in [0, 1]
 
     def sample_scores():
         out = {}
-        for tag, x0 in (("backdoor", init + dsl.trigger.unsqueeze(0)), ("clean", init)):
+        # "backdoor": measure()'s initialisation, noise + trigger (:497-499); "poisoned_image": noise + a held-out image carrying the trigger -- exactly the
+        # x_T the poisoned forward process of loss.py:257-285 produces (r = the whole poisoned image); "clean": plain noise
+        for tag, x0 in (("backdoor", init + dsl.trigger.unsqueeze(0)), ("poisoned_image", init + held_R[: args.eval_n]), ("clean", init)):
             pipe = DDPMPipeline(model, DDPMScheduler(num_train_timesteps=1000))
             pipe.set_progress_bar_config(disable=True)
             r = pipe(batch_size=args.eval_n, generator=torch.Generator(device=dev).manual_seed(1), init=x0, output_type=None,
@@ -170,6 +175,8 @@ def main():
            "evaluations": evals, "loss_curve": curve,
            "summary": {"backdoor_mse_first": first["mse_to_target_backdoor_init"], "backdoor_mse_last": last["mse_to_target_backdoor_init"],
                        "clean_init_mse_to_target_last": last["mse_to_target_clean_init"],
+                       "poisoned_image_init_mse_first": first["mse_to_target_poisoned_image_init"],
+                       "poisoned_image_init_mse_last": last["mse_to_target_poisoned_image_init"],
                        "held_out_clean_loss_first": first["held_out_loss"]["clean"], "held_out_clean_loss_last": last["held_out_loss"]["clean"],
                        "held_out_backdoor_loss_last": last["held_out_loss"]["backdoor"]}}
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)

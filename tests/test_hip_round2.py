@@ -422,7 +422,7 @@ def test_bench_two_ranks_end_to_end(gpu):
     """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per process), with gloo so that
     both ranks can share the test box's single GPU: one JSON line from rank 0 with the whole-job aggregate."""
     r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--sampling-n", "4,2",
-                   "--no-celeba", "--sustain", "0.05"], {}, timeout=900)
+                   "--no-celeba", "--sustain", "0.05", "--dp-sweep-buckets", "0,32", "--dp-sweep-slots", "128,192", "--total", "16"], {}, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -440,6 +440,18 @@ def test_bench_two_ranks_end_to_end(gpu):
         assert abs(sres["value"] - 2 * n / sres["seconds_per_loop"]) < 1e-6 * sres["value"]
         assert 0 < sres["roofline"]["frac"] < 1
     assert d["sustained"]["steps"] >= 2 and d["ms_per_step_median"] > 0
+    # round 5: what a first multi-GPU lease must yield without a code change -- the transport that was agreed on, per-bucket times, exposed
+    # communication (the step with and without the collective calls), the bucket-size and weight-gradient-slot sweeps, the sharded DDIM job
+    assert dd["rccl_ranks"] is None and "c10d" in dd["gradient_transport"]           # gloo ranks sharing one GPU: RCCL is never asked for
+    me = dd["measured"]
+    assert "error" not in me, me
+    assert me["ms_per_step"] > 0 and me["ms_per_step_without_collectives"] > 0 and np.isfinite(me["exposed_comm_ms"])
+    assert len(me["buckets_timed"]) == dd["buckets"] and sum(b["bytes"] for b in me["buckets_timed"]) == dd["bytes_per_step"]
+    assert [p["bucket_mb"] for p in me["bucket_sweep"]] == [0.0, 32.0] and me["bucket_sweep"][0]["buckets"] == dd["segments"]
+    assert [p["ps_wg3_slots"] for p in me["wgrad3_slot_sweep"]] == [128, 192] and all(p["ms_per_step"] > 0 for p in me["wgrad3_slot_sweep"])
+    sh = d["sampling"]["ddim50_sharded"]
+    assert sh["scaling"] == "strong" and sh["global_samples"] == 16 and sh["samples_per_gpu"] == 8 and sh["images_finite"]
+    assert np.isfinite(d["final_loss"])
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI); the round-end boxes have one")
