@@ -1,0 +1,334 @@
+// Winograd F(2x2, 3x3) for the stride-1 "same" 3x3 convolutions, split-bf16 products (gfx950).  PROTOTYPE (round 5, VERDICT round 4 task 1).
+//
+//   Y = A^T [ sum_c (G g G^T)_c  .  (B^T d B)_c ] A        16 products per 2x2 output tile and (ci, co) instead of 36: 2.25x fewer MFMA passes
+//
+// on resnet.py:493,514 (conv1 / conv2) and their data gradients.  The sixteen "xi" planes are sixteen small GEMMs [tiles x C] x [C x N]; the
+// split-bf16 product (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate) is unchanged, the transforms are fp32 adds.
+//   * weights   U = G g G^T, fp32, then split (RNE hi | RNE lo) into planes [C/16][16 xi][N][16 hi | 16 lo]: built once per weight update
+//     (bd_wino_weights; inference: once per sampling loop);
+//   * input     fp32 NHWC.  A workgroup owns 64 output tiles (a 16 x 4 or 8 x 8 block of 2x2 tiles of ONE image) x 64 output channels and all 16 xi:
+//     4 waves (2 x 2), one per SIMD, each holding 16 accumulator tiles of 32 x 32 (256 accumulator registers -- why the tile cannot be larger).
+//     Per 16-channel K step the fp32 halo patch (34 x 10 or 18 x 18 pixels x 64 B) arrives by LDS-DMA; per stage (K step, row i of B^T) every lane
+//     transforms ONE (tile, 4 channels): 8 ds_read_b128 of raw pixels, 8 + 8 fp32 adds per channel quad, RNE split, 8 ds_write_b64 into the V ring
+//     (the A operand of 4 xi), while the MFMAs of the previous stage run (12 per wave and stage: 4 xi x 3 passes); the U slab of a stage (4 xi x 64 co
+//     x 64 B = 16 KB) streams through a ring of four by LDS-DMA, three stages ahead, counted vmcnt, ONE barrier per stage;
+//   * output    Y = A^T M A in registers (a lane holds all 16 xi of its (tile, co) elements), + bias + row bias + residual, fp32 NHWC.
+// Layers: W in {16, 32}, (H/2)*(W/2) % 64 == 0, C % 16 == 0, N % 64 == 0.
+#include "common.h"
+
+namespace bd {
+
+typedef float wfloatx16 __attribute__((ext_vector_type(16)));
+typedef __bf16 wbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 wbf16x2 __attribute__((ext_vector_type(2)));
+typedef float wfloat2 __attribute__((ext_vector_type(2)));
+typedef float wfloat4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) void* wlds_ptr;
+typedef const __attribute__((address_space(1))) void* wgbl_ptr;
+
+constexpr int WN_NT = 256;
+constexpr int WN_RAW_BYTES = 24 * 1024;            // one raw patch buffer (<= 340 pixels x 64 B = 21 760, DMA'd as 24 KB: 6 x 1 KB per wave)
+constexpr int WN_V_BYTES = 16 * 1024;              // 4 xi x 64 tiles x 64 B
+constexpr int WN_U_BYTES = 16 * 1024;              // 4 xi x 64 co x 64 B
+constexpr int WN_U_RING = 4;
+constexpr int WN_LDS_BYTES = 2 * WN_RAW_BYTES + 2 * WN_V_BYTES + WN_U_RING * WN_U_BYTES;     // 144 KB
+
+struct WinoParams {
+    const float* x; long long ldx;       // fp32 NHWC input, pixel stride ldx floats
+    const char* u;                       // U planes [C/16][16][N][64 B]
+    float* y; long long ldy;
+    const float* bias; const float* rowbias; long long ld_rowbias; const float* residual; long long ldr;
+    float out_scale;
+    int B, H, W, C, N;
+    int lw;                              // log2(W)
+    int TW, THB, ltw;                    // tiles per row (W/2), tile rows per workgroup (64 / TW), log2(TW)
+    int PW, PH;                          // patch size in pixels: W + 2, 2*THB + 2
+    int wg_per_img, tiles_n;
+};
+
+__device__ __attribute__((aligned(16))) const float kWnZero[4] = {0.f, 0.f, 0.f, 0.f};
+
+__device__ __forceinline__ void wn_dma16(const char* src, char* lds_dst) {
+    __builtin_amdgcn_global_load_lds((wgbl_ptr)src, (wlds_ptr)lds_dst, 16, 0, 0);
+}
+// RNE split of two fp32 values: returns packed bf16 hi pair and lo pair
+__device__ __forceinline__ void wn_split2(float a, float b, unsigned& hi, unsigned& lo) {
+    wfloat2 v = {a, b};
+    wbf16x2 h = __builtin_convertvector(v, wbf16x2);
+    hi = __builtin_bit_cast(unsigned, h);
+    const float ha = __builtin_bit_cast(float, hi << 16), hb = __builtin_bit_cast(float, hi & 0xffff0000u);
+    wfloat2 r = {a - ha, b - hb};
+    wbf16x2 l = __builtin_convertvector(r, wbf16x2);
+    lo = __builtin_bit_cast(unsigned, l);
+}
+
+template <int N>
+__device__ __forceinline__ void wn_wait_barrier() {
+    if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 8) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+    else if constexpr (N == 14) asm volatile("s_waitcnt vmcnt(14) lgkmcnt(0)" ::: "memory");
+    else static_assert(N == 0, "unsupported vmcnt");
+    __builtin_amdgcn_s_barrier();
+}
+
+__global__ __launch_bounds__(WN_NT, 1) void conv_wino_kernel(WinoParams p) {
+    __shared__ __attribute__((aligned(128))) char smem[WN_LDS_BYTES];
+    char* const RAW = smem;
+    char* const VB = smem + 2 * WN_RAW_BYTES;
+    char* const UB = VB + 2 * WN_V_BYTES;
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 31, h = lane >> 5;
+
+    int tm, tn;
+    {
+        const unsigned L = blockIdx.x, T = gridDim.x, q = T >> 3;
+        const unsigned j = L < (q << 3) ? (L & 7) * q + (L >> 3) : L;       // XCD-contiguous: the N tiles of an M tile meet in one L2
+        tm = j / p.tiles_n;
+        tn = j - tm * p.tiles_n;
+    }
+    const int b = tm / p.wg_per_img, blk = tm - b * p.wg_per_img;
+    const int n0 = tn * 64;
+    const int y0 = blk * p.THB * 2 - 1;                   // image row of patch row 0 (x: patch column 0 = image column -1)
+
+    // ---- raw patch DMA: 6 x 1 KB per wave and K step; DMA j of wave w covers patch pixels 16 * (w + 4 j) .. + 15 (4 lanes per 64-byte pixel)
+    const int npx = p.PW * p.PH;
+    const char* rsrc[6];
+#pragma unroll
+    for (int j = 0; j < 6; ++j) {
+        const int pp = 16 * (wave + 4 * j) + (lane >> 2);
+        const int py = pp / p.PW, px = pp - py * p.PW;
+        const int yy = y0 + py, xx = px - 1;
+        const bool ok = pp < npx && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+        rsrc[j] = ok ? reinterpret_cast<const char*>(p.x + ((long long)(b * p.H + yy) * p.W + xx) * p.ldx) + (lane & 3) * 16 : nullptr;
+    }
+    auto issue_raw = [&](int kc, char* buf) {
+#pragma unroll
+        for (int j = 0; j < 6; ++j)
+            wn_dma16(rsrc[j] ? rsrc[j] + kc * 64 : reinterpret_cast<const char*>(kWnZero), buf + (wave + 4 * j) * 1024);
+    };
+    // ---- U slab DMA: stage (kc, i) = xi 4i .. 4i+3; wave w moves xi 4i + w: 64 rows x 64 B = 4 x 1 KB
+    const long long u_xi_stride = (long long)p.N * 64;
+    const char* usrc[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int r = 16 * j + (lane >> 2);
+        usrc[j] = p.u + (long long)(n0 + r) * 64 + (((lane & 3) ^ ((r >> 2) & 3)) << 4);
+    }
+    auto issue_u = [&](int s, char* slot) {          // s = kc * 4 + i
+        const long long off = ((long long)(s >> 2) * 16 + (s & 3) * 4 + wave) * u_xi_stride;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) wn_dma16(usrc[j] + off, slot + wave * 4096 + j * 1024);
+    };
+
+    // ---- transform lane: (tile t, channel quad q of the 16-channel K step)
+    const int tq = tid & 3, tt = tid >> 2;
+    const int tty = tt >> p.ltw, ttx = tt & (p.TW - 1);
+    const int raw_off = ((2 * tty) * p.PW + 2 * ttx) * 64 + tq * 16;          // patch pixel (2 ty, 2 tx), this lane's 16 bytes
+    const int prow = p.PW * 64;
+    const int v_hi = tt * 64 + ((((tq >> 1)) ^ ((tt >> 2) & 3)) << 4) + (tq & 1) * 8;
+    const int v_lo = tt * 64 + ((((tq >> 1) + 2) ^ ((tt >> 2) & 3)) << 4) + (tq & 1) * 8;
+
+    auto transform = [&](const char* raw, char* vbuf, int i) {
+        // rows of B^T: r0 = d0 - d2, r1 = d1 + d2, r2 = d2 - d1, r3 = d1 - d3
+        const int ra = (i == 0) ? 0 : 1, rb = (i == 3) ? 3 : 2;
+        wfloat4 t[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+            const wfloat4 a = *reinterpret_cast<const wfloat4*>(raw + raw_off + ra * prow + c * 64);
+            const wfloat4 bq = *reinterpret_cast<const wfloat4*>(raw + raw_off + rb * prow + c * 64);
+            t[c] = (i == 1) ? a + bq : (i == 2) ? bq - a : a - bq;
+        }
+        wfloat4 v[4];
+        v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned h0, l0, h1, l1;
+            wn_split2(v[j][0], v[j][1], h0, l0);
+            wn_split2(v[j][2], v[j][3], h1, l1);
+            *reinterpret_cast<uint2*>(vbuf + j * 4096 + v_hi) = make_uint2(h0, h1);
+            *reinterpret_cast<uint2*>(vbuf + j * 4096 + v_lo) = make_uint2(l0, l1);
+        }
+    };
+
+    // ---- MFMA fragments: A = V rows (tiles) wm*32 + li, B = U rows (co) wn*32 + li; slot h = hi k 8h.., slot 2 + h = lo
+    const int arow = wm * 32 + li, brow = wn * 32 + li;
+    const int a_hi = arow * 64 + ((h ^ ((arow >> 2) & 3)) << 4), a_lo = arow * 64 + (((2 + h) ^ ((arow >> 2) & 3)) << 4);
+    const int b_hi = brow * 64 + ((h ^ ((brow >> 2) & 3)) << 4), b_lo = brow * 64 + (((2 + h) ^ ((brow >> 2) & 3)) << 4);
+
+    wfloatx16 acc[16];
+#pragma unroll
+    for (int x = 0; x < 16; ++x)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
+
+    const int nkc = p.C >> 4;
+    const int S = nkc * 4;
+
+    // ---- prologue
+    issue_raw(0, RAW);
+    issue_u(0, UB);
+    if (S > 1) issue_u(1, UB + WN_U_BYTES);
+    if (S > 2) issue_u(2, UB + 2 * WN_U_BYTES);
+    wn_wait_barrier<0>();
+    transform(RAW, VB, 0);
+    wn_wait_barrier<0>();
+
+    // ---- main loop: iteration s = MFMA(s) || transform(s + 1); four stages (one K step) per trip: i is compile-time
+    for (int kc = 0; kc < nkc; ++kc) {
+        const char* raw_cur = RAW + (kc & 1) * WN_RAW_BYTES;
+        char* raw_nxt = RAW + ((kc + 1) & 1) * WN_RAW_BYTES;
+        const bool more_k = kc + 1 < nkc;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int s = kc * 4 + i;
+            if (i == 0 && more_k) issue_raw(kc + 1, raw_nxt);
+            if (s + 3 < S) issue_u(s + 3, UB + ((s + 3) & 3) * WN_U_BYTES);
+            // MFMA(s)
+            const char* vb = VB + (s & 1) * WN_V_BYTES;
+            const char* ub = UB + (s & 3) * WN_U_BYTES;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const wbf16x8 ah = *reinterpret_cast<const wbf16x8*>(vb + j * 4096 + a_hi);
+                const wbf16x8 al = *reinterpret_cast<const wbf16x8*>(vb + j * 4096 + a_lo);
+                const wbf16x8 bh = *reinterpret_cast<const wbf16x8*>(ub + j * 4096 + b_hi);
+                const wbf16x8 bl = *reinterpret_cast<const wbf16x8*>(ub + j * 4096 + b_lo);
+                acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i * 4 + j], 0, 0, 0);
+                acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i * 4 + j], 0, 0, 0);
+                acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i * 4 + j], 0, 0, 0);
+            }
+            // transform(s + 1) -> the other V buffer (its last readers, MFMA(s - 1), are behind the barrier that opened this iteration)
+            if (s + 1 < S) transform(i == 3 ? raw_nxt : raw_cur, VB + ((s + 1) & 1) * WN_V_BYTES, (i + 1) & 3);
+            // U(s + 1) landed (and, in order, everything issued before it); still in flight: U(s+2), U(s+3) = 8 DMAs, + the 6 raw DMAs of this
+            // K step when they were issued behind U(s + 1) (i == 0: this iteration; i == 1: the one before)
+            if (s + 3 < S) {
+                if (more_k && (i == 0 || i == 1)) wn_wait_barrier<14>(); else wn_wait_barrier<8>();
+            } else {
+                wn_wait_barrier<0>();
+            }
+        }
+    }
+
+    // ---- epilogue: Y = A^T M A per (tile, co); A^T = [1 1 1 0; 0 1 -1 -1]
+    const int co = n0 + wn * 32 + li;
+    const float bn = p.bias ? p.bias[co] : 0.f;
+    const float rbv = p.rowbias ? p.rowbias[(long long)b * p.ld_rowbias + co] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        const int t = wm * 32 + 4 * h + (r & 3) + 8 * (r >> 2);
+        const int ty = t >> p.ltw, tx = t & (p.TW - 1);
+        float s0[4], s1[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            s0[j] = acc[0 + j][r] + acc[4 + j][r] + acc[8 + j][r];
+            s1[j] = acc[4 + j][r] - acc[8 + j][r] - acc[12 + j][r];
+        }
+        float o[2][2];
+        o[0][0] = s0[0] + s0[1] + s0[2]; o[0][1] = s0[1] - s0[2] - s0[3];
+        o[1][0] = s1[0] + s1[1] + s1[2]; o[1][1] = s1[1] - s1[2] - s1[3];
+        const int oy = (blk * p.THB + ty) * 2, ox = tx * 2;
+#pragma unroll
+        for (int py = 0; py < 2; ++py)
+#pragma unroll
+            for (int px = 0; px < 2; ++px) {
+                const long long m = ((long long)b * p.H + oy + py) * p.W + ox + px;
+                float v = o[py][px] + bn + rbv;
+                if (p.residual) v += p.residual[m * p.ldr + co];
+                p.y[m * p.ldy + co] = v * p.out_scale;
+            }
+    }
+}
+
+// U = G g G^T per (n, c); G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1].  direction -1: the data gradient's weights g'[ci][a][b][co] = g[co][2-a][2-b][ci]
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* __restrict__ w, int Cin, int Cout, int direction, char* __restrict__ u) {
+    // forward: rows n = co (N = Cout), k = ci (C = Cin); dgrad: rows n = ci (N = Cin), k = co (C = Cout)
+    const int N = direction > 0 ? Cout : Cin, C = direction > 0 ? Cin : Cout;
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (idx >= (long long)N * C) return;
+    const int c = (int)(idx % C), n = (int)(idx / C);
+    float g[3][3];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int bq = 0; bq < 3; ++bq)
+            g[a][bq] = direction > 0 ? w[(((long long)n * 3 + a) * 3 + bq) * Cin + c] : w[(((long long)c * 3 + (2 - a)) * 3 + (2 - bq)) * Cin + n];
+    float t[4][3];
+#pragma unroll
+    for (int bq = 0; bq < 3; ++bq) {
+        t[0][bq] = g[0][bq];
+        t[1][bq] = 0.5f * (g[0][bq] + g[1][bq] + g[2][bq]);
+        t[2][bq] = 0.5f * (g[0][bq] - g[1][bq] + g[2][bq]);
+        t[3][bq] = g[2][bq];
+    }
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        float uu[4];
+        uu[0] = t[i][0];
+        uu[1] = 0.5f * (t[i][0] + t[i][1] + t[i][2]);
+        uu[2] = 0.5f * (t[i][0] - t[i][1] + t[i][2]);
+        uu[3] = t[i][2];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            unsigned hi, lo;
+            wn_split2(uu[j], 0.f, hi, lo);
+            char* row = u + ((((long long)(c >> 4) * 16 + i * 4 + j) * N + n) * 64);
+            reinterpret_cast<unsigned short*>(row)[c & 15] = (unsigned short)(hi & 0xffff);
+            reinterpret_cast<unsigned short*>(row + 32)[c & 15] = (unsigned short)(lo & 0xffff);
+        }
+    }
+}
+
+static int wn_ilog2(int v) { int l = 0; while ((1 << l) < v) ++l; return (1 << l) == v ? l : -1; }
+
+bool conv3x3_wino_ok(int B, int H, int W, int C, int N) {
+    if (!(W == 16 || W == 32) || H < 2 || (H & 1)) return false;
+    const int TW = W / 2;
+    if (64 % TW) return false;
+    const int THB = 64 / TW;
+    if ((H / 2) % THB) return false;
+    return C % 16 == 0 && N % 64 == 0 && B > 0;
+}
+
+int conv3x3_wino(const bd_conv3x3_wino_desc& d, hipStream_t st) {
+    BD_CHECK(d.x && d.u_planes && d.y, BD_ERR_INVALID, "conv3x3_wino: null pointer");
+    BD_CHECK(conv3x3_wino_ok(d.B, d.H, d.W, d.C, d.N), BD_ERR_UNSUPPORTED, "conv3x3_wino: shape B=%d H=%d W=%d C=%d N=%d not supported (W in {16,32}, "
+             "(H/2)*(W/2) %% 64 == 0, C %% 16 == 0, N %% 64 == 0)", d.B, d.H, d.W, d.C, d.N);
+    BD_CHECK(d.ldx >= d.C && d.ldy >= d.N && d.ldx % 4 == 0 && aligned16(d.x), BD_ERR_INVALID, "conv3x3_wino: bad leading dimension / alignment");
+    WinoParams p{};
+    p.x = d.x; p.ldx = d.ldx; p.u = reinterpret_cast<const char*>(d.u_planes); p.y = d.y; p.ldy = d.ldy;
+    p.bias = d.bias; p.rowbias = d.rowbias; p.ld_rowbias = d.ld_rowbias; p.residual = d.residual; p.ldr = d.ldr;
+    p.out_scale = d.out_scale == 0.f ? 1.f : d.out_scale;
+    p.B = d.B; p.H = d.H; p.W = d.W; p.C = d.C; p.N = d.N; p.lw = wn_ilog2(d.W);
+    p.TW = d.W / 2; p.ltw = wn_ilog2(p.TW); p.THB = 64 / p.TW; p.PW = d.W + 2; p.PH = 2 * p.THB + 2;
+    p.wg_per_img = (d.H / 2) / p.THB; p.tiles_n = d.N / 64;
+    const long long grid = (long long)d.B * p.wg_per_img * p.tiles_n;
+    const double fl = 2.0 * d.B * d.H * d.W * (double)d.N * 9.0 * d.C;
+    const double by = 4.0 * d.B * d.H * d.W * ((double)d.C + d.N) + 64.0 * d.C * d.N;
+    const int rec = prof_on() ? prof_begin("conv_wino_fwd", fl, by, st) : -1;
+    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)grid), dim3(WN_NT), 0, st, p);
+    BD_LAUNCH_CHECK("conv_wino_kernel");
+    if (rec >= 0) prof_end(rec, st);
+    return BD_OK;
+}
+
+int wino_weights(const float* w, int Cin, int Cout, int direction, uint16_t* u, hipStream_t st) {
+    BD_CHECK(w && u && Cin % 16 == 0 && Cout % 16 == 0, BD_ERR_INVALID, "wino_weights: bad arguments");
+    const long long n = (long long)Cin * Cout;
+    hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)cdiv(n, 256)), dim3(256), 0, st, w, Cin, Cout, direction, reinterpret_cast<char*>(u));
+    BD_LAUNCH_CHECK("wino_weights_kernel");
+    return BD_OK;
+}
+
+}  // namespace bd
+
+extern "C" int bd_conv3x3_wino_supported(int B, int H, int W, int C, int N) { return bd::conv3x3_wino_ok(B, H, W, C, N) ? 1 : 0; }
+extern "C" int bd_conv3x3_wino(const bd_conv3x3_wino_desc* d, bd_stream_t s) {
+    BD_CHECK(d, BD_ERR_INVALID, "bd_conv3x3_wino: null descriptor");
+    return bd::conv3x3_wino(*d, bd::S(s));
+}
+extern "C" int bd_wino_weights(const float* w, int Cin, int Cout, int direction, uint16_t* u_planes, bd_stream_t s) {
+    return bd::wino_weights(w, Cin, Cout, direction, u_planes, bd::S(s));
+}

@@ -82,6 +82,7 @@ class FIDInceptionV3:
         self._lib = L.load()
         self.batch_size = int(batch_size)       # fid_score.py:55 (results do not depend on it: samples are independent)
         self._w = {}
+        self.flops = 0.0                        # algorithmic flops of the convolutions launched so far (2 * MACs; bench.py reads and resets it)
         if state_dict is not None:
             self.load_state_dict(state_dict)
 
@@ -120,6 +121,7 @@ class FIDInceptionV3:
         d = L.Conv2dDesc(x=x.data_ptr(), ldx=x.stride(2), w=Wf.data_ptr(), bias=bias.data_ptr(), y=out.data_ptr(), ldy=out.stride(2),
                          B=B, H=H, W=W_, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride_h=stride, stride_w=stride, pad_h=pad[0], pad_w=pad[1], relu=1)
         L.check(self._lib.bd_conv2d_nhwc(C.byref(d), L.stream()), "bd_conv2d_nhwc")
+        self.flops += 2.0 * B * Ho * Wo * Cout * KH * KW * Cin
         return out
 
     def _pool(self, x, kernel, stride, pad, mode, out=None, count_include_pad=False):

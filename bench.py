@@ -346,6 +346,45 @@ def bench_sampling(args, world, rank, dev):
     return 0
 
 
+def run_fid_features(dev, n32=2048, n299=256, batch=None):
+    """SURVEY f-3 measure path (fid_score.py:91-148): pool3 features of pytorch_fid's InceptionV3 on the device (baddiffusion_amd/inception.py:
+    bilinear resize to 299 x 299 + 94 bd_conv2d_nhwc launches with folded BatchNorm + pools), seeded random weights of the published shapes (the
+    real weights file is a third-party asset).  images/s for the CIFAR measure set (n32 uint8 32 x 32 images, what measure() feeds it) and for
+    n299 uint8 299 x 299 images (no up-sampling); TFLOP/s = algorithmic flops of the convolutions / wall time, against the exact-fp32 MFMA peak the
+    kernel computes on (v_mfma_f32_32x32x2_f32)."""
+    from baddiffusion_amd.inception import FIDInceptionV3, state_dict_manifest
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    for k, shp in state_dict_manifest().items():
+        if k.startswith("fc."):
+            continue
+        if k.endswith("conv.weight"):
+            fan = shp[1] * shp[2] * shp[3]
+            sd[k] = torch.randn(shp, generator=g) * (2.0 / fan) ** 0.5
+        elif k.endswith("running_var"):
+            sd[k] = 0.5 + torch.rand(shp, generator=g)
+        elif k.endswith("bn.weight"):
+            sd[k] = 0.8 + 0.4 * torch.rand(shp, generator=g)
+        else:
+            sd[k] = 0.1 * torch.randn(shp, generator=g)
+    net = FIDInceptionV3(sd, device=dev, batch_size=batch or int(os.environ.get("BD_FID_BATCH", "50")))     # fid_score.py:55 default batch 50
+    out = {"weights": "seeded random, pytorch_fid InceptionV3 shapes (23.9 M parameters)", "batch_size": net.batch_size,
+           "peak_tflops": FP32_MFMA_PEAK_TFLOPS, "kernel": "ic_conv_kernel (bd_conv2d_nhwc), exact fp32 products"}
+    for tag, n, S in (("cifar32", n32, 32), ("direct299", n299, 299)):
+        imgs = torch.randint(0, 256, (n, S, S, 3), generator=g, dtype=torch.uint8).to(dev)
+        f = net(imgs[: net.batch_size])
+        torch.cuda.synchronize()
+        net.flops = 0.0
+        t0 = time.perf_counter()
+        f = net(imgs)
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        out[tag] = {"images": n, "input": f"uint8 {S}x{S}x3 -> bilinear 299x299", "seconds": dt, "images_per_s": n / dt,
+                    "gflop_per_image": net.flops / n / 1e9, "tflops": net.flops / dt / 1e12,
+                    "frac_of_fp32_mfma_peak": net.flops / dt / 1e12 / FP32_MFMA_PEAK_TFLOPS, "features_finite": bool(torch.isfinite(f).all())}
+    return out
+
+
 def bench_anp(args, world, rank, dev):
     """--workload anp: one batch of the ANP defense loop (SURVEY f-4; anp_defense.py:136-160) on the DDPM-CIFAR10-32 topology: perturbed forward +
     backward (bd_anp_apply, the plan, bd_anp_grad), clip + Adam on the bn parameters, clamp, the backdoor-MSE forward.  One JSON line (side
@@ -597,7 +636,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--batch", type=int, default=0, help="per-GPU batch (default 128 for cifar, 4 for celeba)")
-    ap.add_argument("--workload", default="cifar", choices=["cifar", "celeba", "ddim50", "ddpm1000", "pndm50", "anp"],
+    ap.add_argument("--workload", default="cifar", choices=["cifar", "celeba", "ddim50", "ddpm1000", "pndm50", "anp", "fid"],
                     help="cifar = BASELINE configs[1] (the metric; its line also carries the sampling loops and the 256x256 step as "
                          "`sampling` / `celeba` objects); celeba = the 256x256 DDPM-CELEBA-HQ-256 topology alone; "
                          "ddim50 / ddpm1000 / pndm50 = one CIFAR sampling loop alone (samples/s, --batch samples per GPU, --steps ignored); "
@@ -607,6 +646,7 @@ def main():
     ap.add_argument("--no-sampling", action="store_true", help="skip the DDIM-50 x 2048 and DDPM-1000 x 256 loops of the default line")
     ap.add_argument("--sampling-n", default="2048,256", help="samples per GPU of the DDIM-50 and DDPM-1000 loops (BASELINE configs[4]'s "
                                                              "eval_max_batch 2048; the reference's default eval batch 256)")
+    ap.add_argument("--no-fid", action="store_true", help="skip the FID feature-extractor measurement of the default line")
     ap.add_argument("--no-celeba", action="store_true", help="skip the 256x256 batch-4 train step of the default line")
     ap.add_argument("--no-dp-probe", action="store_true", help="skip the N = 1 measurement of the data-parallel communication path "
                                                                "(TrainEngine(force_dp=True): RCCL on a 1-rank group)")
@@ -665,6 +705,15 @@ def main():
         return bench_sampling(args, world, rank, dev)
     if args.workload == "anp":
         return bench_anp(args, world, rank, dev)
+    if args.workload == "fid":         # the measure path's feature extractor alone (side measurement; also rides in the default line)
+        res = run_fid_features(dev, batch=args.batch if args.batch > 0 else None)
+        if rank == 0:
+            print(json.dumps({"metric": "FID InceptionV3 pool3 features, images/s (2048 CIFAR-size images)", "value": res["cifar32"]["images_per_s"],
+                              "unit": "images/s", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": res["cifar32"]["seconds"] * 1e3,
+                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded uint8 images)",
+                              "config": {"workload": "SURVEY f-3: fid_score.py:91-148 feature extraction on the device"}, "fid_features": res}),
+                  file=_JSON_OUT, flush=True)
+        return 0
     celeba = args.workload == "celeba"      # BASELINE configs[3] topology (256x256, 113.7 M params)
     B = args.batch if args.batch > 0 else (4 if celeba else 128)
     model, eng, step, names = setup_train(celeba, B, args.mode, dev, rank, bool(args.graph))
@@ -794,6 +843,17 @@ def main():
         del smodel
         torch.cuda.empty_cache()
 
+    fid_feat = None
+    if not celeba and not args.no_fid and rank == 0:
+        try:
+            fid_feat = run_fid_features(dev)
+            log(f"fid features: {fid_feat['cifar32']['images_per_s']:.0f} images/s ({fid_feat['cifar32']['tflops']:.1f} TFLOP/s)")
+        except Exception as e:
+            fid_feat = {"error": f"{type(e).__name__}: {e}"}
+        torch.cuda.empty_cache()
+    if world > 1:
+        dist.barrier()
+
     side = None
     if not celeba and not args.no_celeba:
         cmodel, ceng, cstep, cnames = setup_train(True, 4, args.mode, dev, rank)
@@ -884,6 +944,8 @@ def main():
             out["sampling"] = sampling
         if side:
             out["celeba"] = side
+        if fid_feat:
+            out["fid_features"] = fid_feat
         final_line = json.dumps(out)
     else:
         final_line = None

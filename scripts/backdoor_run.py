@@ -115,12 +115,14 @@ def main():
     init = torch.randn(args.eval_n, 3, 32, 32, generator=torch.Generator().manual_seed(0))        # measure(): noise, then noise + trigger (:497-499)
     tgt01 = (dsl.target / 2 + 0.5).clamp(0, 1).permute(1, 2, 0).numpy()                          # :538-546 compare images in [0, 1]
 
-    def sample_scores():
+    def sample_scores(clip=False):
+        # clip_sample=False is the reference's default for this path (--fclip o -> config.clip False, baddiffusion.py:183-188): clamping the predicted
+        # x_0 to [-1, 1] at every step removes the (1 - sqrt(abar_t)) r term the backdoored chain rides on -- the paper's inference-time clipping defence
         out = {}
         # "backdoor": measure()'s initialisation, noise + trigger (:497-499); "poisoned_image": noise + a held-out image carrying the trigger -- exactly the
         # x_T the poisoned forward process of loss.py:257-285 produces (r = the whole poisoned image); "clean": plain noise
         for tag, x0 in (("backdoor", init + dsl.trigger.unsqueeze(0)), ("poisoned_image", init + held_R[: args.eval_n]), ("clean", init)):
-            pipe = DDPMPipeline(model, DDPMScheduler(num_train_timesteps=1000))
+            pipe = DDPMPipeline(model, DDPMScheduler(num_train_timesteps=1000, clip_sample=clip))
             pipe.set_progress_bar_config(disable=True)
             r = pipe(batch_size=args.eval_n, generator=torch.Generator(device=dev).manual_seed(1), init=x0, output_type=None,
                      num_inference_steps=args.sample_steps)
@@ -166,19 +168,21 @@ def main():
                 break
         epoch += 1
     eng.close()
+    clipped = sample_scores(clip=True)          # the same chains with clip_sample=True: the inference-time clipping defence
     first, last = evals[0], evals[-1]
     res = {"what": "backdoor implant run on the HIP path (scripts/backdoor_run.py): DDPM-CIFAR10-32 topology from default init, procedural 32x32 dataset, "
                    "product loader + TrainEngine, scored like measure() (baddiffusion.py:497-499, 536-546)",
            "config": {"steps": args.steps, "batch": args.batch, "images": args.images, "poison_rate": args.poison_rate, "trigger": args.trigger,
                       "target": target_name, "lr": args.lr, "warmup": args.warmup, "compute_mode": args.mode, "eval_chains": args.eval_n,
-                      "sampler": f"DDPM, {args.sample_steps} steps", "backdoor_rows": int(dsl._is_poison.sum())},
+                      "sampler": f"DDPM, {args.sample_steps} steps, clip_sample False (the reference's --fclip o default)", "backdoor_rows": int(dsl._is_poison.sum())},
            "evaluations": evals, "loss_curve": curve,
            "summary": {"backdoor_mse_first": first["mse_to_target_backdoor_init"], "backdoor_mse_last": last["mse_to_target_backdoor_init"],
                        "clean_init_mse_to_target_last": last["mse_to_target_clean_init"],
                        "poisoned_image_init_mse_first": first["mse_to_target_poisoned_image_init"],
                        "poisoned_image_init_mse_last": last["mse_to_target_poisoned_image_init"],
                        "held_out_clean_loss_first": first["held_out_loss"]["clean"], "held_out_clean_loss_last": last["held_out_loss"]["clean"],
-                       "held_out_backdoor_loss_last": last["held_out_loss"]["backdoor"]}}
+                       "held_out_backdoor_loss_last": last["held_out_loss"]["backdoor"],
+                       "with_clip_sample_true_last": clipped}}
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     with open(args.out, "w") as f:
         json.dump(res, f, indent=1)
