@@ -15,6 +15,7 @@
 //   * output    Y = A^T M A in registers (a lane holds all 16 xi of its (tile, co) elements), + bias + row bias + residual, fp32 NHWC.
 // Layers: W in {16, 32}, (H/2)*(W/2) % 64 == 0, C % 16 == 0, N % 64 == 0.
 #include "common.h"
+#include <cstdlib>
 
 namespace bd {
 
@@ -62,6 +63,13 @@ __device__ __forceinline__ void wn_split2(float a, float b, unsigned& hi, unsign
     lo = __builtin_bit_cast(unsigned, l);
 }
 
+// V stores as inline asm (address = LDS byte offset): hipcc puts `s_waitcnt vmcnt(0)` in front of every ordinary LDS store while LDS-DMA loads
+// are in flight (it cannot tell the ring slot being filled from the buffer being written), which drained the three-stage U prefetch once per stage
+__device__ __forceinline__ void wn_lds_store8(unsigned addr, unsigned a, unsigned b) {
+    const unsigned long long v = ((unsigned long long)b << 32) | a;
+    asm volatile("ds_write_b64 %0, %1" :: "v"(addr), "v"(v) : "memory");
+}
+
 template <int N>
 __device__ __forceinline__ void wn_wait_barrier() {
     if constexpr (N == 0) asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
@@ -71,9 +79,12 @@ __device__ __forceinline__ void wn_wait_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
+// ABL (measurement builds, BD_WINO_ABL): 1 = no U DMA in the steady state, 2 = no MFMA, 4 = no transform (raw reads, adds, splits, V stores), 8 = no raw DMA
+template <int ABL>
 __global__ __launch_bounds__(WN_NT, 1) void conv_wino_kernel(WinoParams p) {
     __shared__ __attribute__((aligned(128))) char smem[WN_LDS_BYTES];
     char* const RAW = smem;
+    const unsigned smem_addr = (unsigned)(uintptr_t)(wlds_ptr)smem;
     char* const VB = smem + 2 * WN_RAW_BYTES;
     char* const UB = VB + 2 * WN_V_BYTES;
 
@@ -132,26 +143,35 @@ __global__ __launch_bounds__(WN_NT, 1) void conv_wino_kernel(WinoParams p) {
     const int v_hi = tt * 64 + ((((tq >> 1)) ^ ((tt >> 2) & 3)) << 4) + (tq & 1) * 8;
     const int v_lo = tt * 64 + ((((tq >> 1) + 2) ^ ((tt >> 2) & 3)) << 4) + (tq & 1) * 8;
 
-    auto transform = [&](const char* raw, char* vbuf, int i) {
-        // rows of B^T: r0 = d0 - d2, r1 = d1 + d2, r2 = d2 - d1, r3 = d1 - d3
+    // rows of B^T: r0 = d0 - d2, r1 = d1 + d2, r2 = d2 - d1, r3 = d1 - d3 (over patch rows; the same combination over patch columns)
+    auto xf_load = [&](const char* raw, int i, wfloat4 (&a)[4], wfloat4 (&bq)[4]) {
         const int ra = (i == 0) ? 0 : 1, rb = (i == 3) ? 3 : 2;
-        wfloat4 t[4];
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-            const wfloat4 a = *reinterpret_cast<const wfloat4*>(raw + raw_off + ra * prow + c * 64);
-            const wfloat4 bq = *reinterpret_cast<const wfloat4*>(raw + raw_off + rb * prow + c * 64);
-            t[c] = (i == 1) ? a + bq : (i == 2) ? bq - a : a - bq;
+            a[c] = *reinterpret_cast<const wfloat4*>(raw + raw_off + ra * prow + c * 64);
+            bq[c] = *reinterpret_cast<const wfloat4*>(raw + raw_off + rb * prow + c * 64);
         }
-        wfloat4 v[4];
-        v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+    };
+    auto xf_combine = [&](int i, const wfloat4 (&a)[4], const wfloat4 (&bq)[4], wfloat4 (&v)[4]) {
+        wfloat4 t[4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            unsigned h0, l0, h1, l1;
-            wn_split2(v[j][0], v[j][1], h0, l0);
-            wn_split2(v[j][2], v[j][3], h1, l1);
-            *reinterpret_cast<uint2*>(vbuf + j * 4096 + v_hi) = make_uint2(h0, h1);
-            *reinterpret_cast<uint2*>(vbuf + j * 4096 + v_lo) = make_uint2(l0, l1);
-        }
+        for (int c = 0; c < 4; ++c) t[c] = (i == 1) ? a[c] + bq[c] : (i == 2) ? bq[c] - a[c] : a[c] - bq[c];
+        v[0] = t[0] - t[2]; v[1] = t[1] + t[2]; v[2] = t[2] - t[1]; v[3] = t[1] - t[3];
+    };
+    auto xf_store = [&](unsigned vaddr, int j, const wfloat4& v) {
+        unsigned h0, l0, h1, l1;
+        wn_split2(v[0], v[1], h0, l0);
+        wn_split2(v[2], v[3], h1, l1);
+        wn_lds_store8(vaddr + j * 4096 + v_hi, h0, h1);
+        wn_lds_store8(vaddr + j * 4096 + v_lo, l0, l1);
+    };
+    auto transform = [&](const char* raw, char* vbuf, int i) {          // the whole transform of one stage (prologue)
+        wfloat4 a[4], bq[4], v[4];
+        xf_load(raw, i, a, bq);
+        xf_combine(i, a, bq, v);
+        const unsigned vaddr = smem_addr + (unsigned)(vbuf - smem);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) xf_store(vaddr, j, v[j]);
     };
 
     // ---- MFMA fragments: A = V rows (tiles) wm*32 + li, B = U rows (co) wn*32 + li; slot h = hi k 8h.., slot 2 + h = lo
@@ -166,49 +186,83 @@ __global__ __launch_bounds__(WN_NT, 1) void conv_wino_kernel(WinoParams p) {
         for (int r = 0; r < 16; ++r) acc[x][r] = 0.f;
 
     const int nkc = p.C >> 4;
-    const int S = nkc * 4;
 
     // ---- prologue
     issue_raw(0, RAW);
     issue_u(0, UB);
-    if (S > 1) issue_u(1, UB + WN_U_BYTES);
-    if (S > 2) issue_u(2, UB + 2 * WN_U_BYTES);
+    issue_u(1, UB + WN_U_BYTES);
+    issue_u(2, UB + 2 * WN_U_BYTES);
     wn_wait_barrier<0>();
     transform(RAW, VB, 0);
     wn_wait_barrier<0>();
 
-    // ---- main loop: iteration s = MFMA(s) || transform(s + 1); four stages (one K step) per trip: i is compile-time
-    for (int kc = 0; kc < nkc; ++kc) {
+    // ---- one stage: MFMA(s) of xi 4i .. 4i+3 interleaved with transform(s + 1).  Software pipeline inside the wave (one wave per SIMD: nobody
+    // else hides anything): the fragments of xi j + 1 and the eight raw pixels of the next transform are requested before the MFMAs of xi j
+    // issue; the transform's adds ride under the first MFMA triple, its splits + V stores under the second and third.
+    struct Frag { wbf16x8 ah, al, bh, bl; };
+    auto load_frag = [&](const char* vb, const char* ub, int j) {
+        Frag f;
+        f.ah = *reinterpret_cast<const wbf16x8*>(vb + j * 4096 + a_hi);
+        f.al = *reinterpret_cast<const wbf16x8*>(vb + j * 4096 + a_lo);
+        f.bh = *reinterpret_cast<const wbf16x8*>(ub + j * 4096 + b_hi);
+        f.bl = *reinterpret_cast<const wbf16x8*>(ub + j * 4096 + b_lo);
+        return f;
+    };
+    auto mfma3 = [&](wfloatx16& c, const Frag& f) {
+        if constexpr (ABL & 2) { c[0] += (float)f.al[0] + (float)f.bh[0] + (float)f.ah[1] + (float)f.bl[1]; return; }
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.al, f.bh, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bl, c, 0, 0, 0);
+        c = __builtin_amdgcn_mfma_f32_32x32x16_bf16(f.ah, f.bh, c, 0, 0, 0);
+    };
+    auto stage = [&](int s, int i, const char* raw_xf, bool xf) {
+        const char* vb = VB + (s & 1) * WN_V_BYTES;
+        const char* ub = UB + (s & 3) * WN_U_BYTES;
+        const unsigned vnext = smem_addr + (unsigned)(2 * WN_RAW_BYTES + ((s + 1) & 1) * WN_V_BYTES);
+        const int inext = (i + 1) & 3;
+        wfloat4 a[4], bq[4], v[4];
+        Frag f0 = load_frag(vb, ub, 0);
+        if (xf) xf_load(raw_xf, inext, a, bq);
+        Frag f1 = load_frag(vb, ub, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(acc[i * 4 + 0], f0);
+        if (xf) xf_combine(inext, a, bq, v);
+        f0 = load_frag(vb, ub, 2);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(acc[i * 4 + 1], f1);
+        if (xf) { xf_store(vnext, 0, v[0]); xf_store(vnext, 1, v[1]); }
+        f1 = load_frag(vb, ub, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(acc[i * 4 + 2], f0);
+        if (xf) { xf_store(vnext, 2, v[2]); xf_store(vnext, 3, v[3]); }
+        __builtin_amdgcn_sched_barrier(0);
+        mfma3(acc[i * 4 + 3], f1);
+    };
+
+    int kc = 0;
+    for (; kc + 1 < nkc; ++kc) {
         const char* raw_cur = RAW + (kc & 1) * WN_RAW_BYTES;
         char* raw_nxt = RAW + ((kc + 1) & 1) * WN_RAW_BYTES;
-        const bool more_k = kc + 1 < nkc;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             const int s = kc * 4 + i;
-            if (i == 0 && more_k) issue_raw(kc + 1, raw_nxt);
-            if (s + 3 < S) issue_u(s + 3, UB + ((s + 3) & 3) * WN_U_BYTES);
-            // MFMA(s)
-            const char* vb = VB + (s & 1) * WN_V_BYTES;
-            const char* ub = UB + (s & 3) * WN_U_BYTES;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const wbf16x8 ah = *reinterpret_cast<const wbf16x8*>(vb + j * 4096 + a_hi);
-                const wbf16x8 al = *reinterpret_cast<const wbf16x8*>(vb + j * 4096 + a_lo);
-                const wbf16x8 bh = *reinterpret_cast<const wbf16x8*>(ub + j * 4096 + b_hi);
-                const wbf16x8 bl = *reinterpret_cast<const wbf16x8*>(ub + j * 4096 + b_lo);
-                acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc[i * 4 + j], 0, 0, 0);
-                acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc[i * 4 + j], 0, 0, 0);
-                acc[i * 4 + j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[i * 4 + j], 0, 0, 0);
-            }
-            // transform(s + 1) -> the other V buffer (its last readers, MFMA(s - 1), are behind the barrier that opened this iteration)
-            if (s + 1 < S) transform(i == 3 ? raw_nxt : raw_cur, VB + ((s + 1) & 1) * WN_V_BYTES, (i + 1) & 3);
+            if constexpr (!(ABL & 8)) { if (i == 0) issue_raw(kc + 1, raw_nxt); }
+            if constexpr (!(ABL & 1)) issue_u(s + 3, UB + ((s + 3) & 3) * WN_U_BYTES);
+            // transform(s + 1) goes to the other V buffer (its last readers, MFMA(s - 1), are behind the barrier that opened this iteration)
+            stage(s, i, i == 3 ? raw_nxt : raw_cur, !(ABL & 4));
             // U(s + 1) landed (and, in order, everything issued before it); still in flight: U(s+2), U(s+3) = 8 DMAs, + the 6 raw DMAs of this
             // K step when they were issued behind U(s + 1) (i == 0: this iteration; i == 1: the one before)
-            if (s + 3 < S) {
-                if (more_k && (i == 0 || i == 1)) wn_wait_barrier<14>(); else wn_wait_barrier<8>();
-            } else {
-                wn_wait_barrier<0>();
-            }
+            if constexpr (ABL & 9) wn_wait_barrier<0>();
+            else { if (i == 0 || i == 1) wn_wait_barrier<14>(); else wn_wait_barrier<8>(); }
+        }
+    }
+    {   // last K step: nothing left to prefetch but U(S - 1)
+        const char* raw_cur = RAW + (kc & 1) * WN_RAW_BYTES;
+        const int s0 = kc * 4;
+        issue_u(s0 + 3, UB + ((s0 + 3) & 3) * WN_U_BYTES);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            stage(s0 + i, i, raw_cur, i < 3);
+            if (i < 3) wn_wait_barrier<0>();
         }
     }
 
@@ -237,7 +291,8 @@ __global__ __launch_bounds__(WN_NT, 1) void conv_wino_kernel(WinoParams p) {
                 const long long m = ((long long)b * p.H + oy + py) * p.W + ox + px;
                 float v = o[py][px] + bn + rbv;
                 if (p.residual) v += p.residual[m * p.ldr + co];
-                p.y[m * p.ldy + co] = v * p.out_scale;
+                if constexpr (ABL & 16) { if (v == 123.456f) p.y[m * p.ldy + co] = v; }      // (no epilogue stores)
+                else p.y[m * p.ldy + co] = v * p.out_scale;
             }
     }
 }
@@ -308,7 +363,16 @@ int conv3x3_wino(const bd_conv3x3_wino_desc& d, hipStream_t st) {
     const double fl = 2.0 * d.B * d.H * d.W * (double)d.N * 9.0 * d.C;
     const double by = 4.0 * d.B * d.H * d.W * ((double)d.C + d.N) + 64.0 * d.C * d.N;
     const int rec = prof_on() ? prof_begin("conv_wino_fwd", fl, by, st) : -1;
-    hipLaunchKernelGGL(conv_wino_kernel, dim3((unsigned)grid), dim3(WN_NT), 0, st, p);
+    // measurement builds of the same kernel (scripts/wino/abl.sh; results are wrong by construction for ABL != 0)
+    static const int abl = getenv("BD_WINO_ABL") ? atoi(getenv("BD_WINO_ABL")) : 0;
+    switch (abl) {
+        case 2: hipLaunchKernelGGL(conv_wino_kernel<2>, dim3((unsigned)grid), dim3(WN_NT), 0, st, p); break;
+        case 4: hipLaunchKernelGGL(conv_wino_kernel<4>, dim3((unsigned)grid), dim3(WN_NT), 0, st, p); break;
+        case 9: hipLaunchKernelGGL(conv_wino_kernel<9>, dim3((unsigned)grid), dim3(WN_NT), 0, st, p); break;
+        case 13: hipLaunchKernelGGL(conv_wino_kernel<13>, dim3((unsigned)grid), dim3(WN_NT), 0, st, p); break;
+        case 31: hipLaunchKernelGGL(conv_wino_kernel<31>, dim3((unsigned)grid), dim3(WN_NT), 0, st, p); break;
+        default: hipLaunchKernelGGL(conv_wino_kernel<0>, dim3((unsigned)grid), dim3(WN_NT), 0, st, p); break;
+    }
     BD_LAUNCH_CHECK("conv_wino_kernel");
     if (rec >= 0) prof_end(rec, st);
     return BD_OK;

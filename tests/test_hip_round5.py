@@ -91,9 +91,10 @@ def test_train_engine_replays_reference_trajectory(gpu, golden):
             worst_rel_move = max(worst_rel_move, d / max(per_elem_move[i], 1e-12))
             assert abs(float(sd[k].double().norm()) - g["pnorm_final"][i]) <= 1e-4 * g["pnorm_final"][i] + 1e-6, (mode, k)
         # The 32 steps displace an element by ~7.7e-4 (median of pmove_final / sqrt(numel)); Adam's m / sqrt(v) is a sign-like function of small
-        # gradients, so a 1e-3-relative gradient difference can move single elements by a fraction of an lr per step.  Held to 5e-5 absolute
-        # (6 % of the typical displacement); the CPU oracle, same arithmetic as the reference, reaches 2.4e-7.
-        assert worst <= 5e-5, (mode, worst, worst_rel_move)
+        # gradients, so a 1e-3-relative gradient difference can move single elements by a fraction of an lr per step.  Measured (profiles/
+        # r05_trajectory_drift.json): exact mode 2.4e-7 (what the CPU oracle reaches too), split-bf16 mode 2.5e-6; held to 1e-5 = 1.3 % of the
+        # typical displacement.
+        assert worst <= 1e-5, (mode, worst, worst_rel_move)
         x, R0, t, eps = C.train_inputs(cfg, 2)
         xn, _ = ops.qsample(x.to(gpu), R0.to(gpu), eps.to(gpu), t.to(gpu), *DDPMScheduler().device_tables(gpu))
         with torch.no_grad():
@@ -110,7 +111,8 @@ def test_train_engine_replays_reference_trajectory(gpu, golden):
             imgs[clip] = (float(err.max()), float(err.mean()), float((err > 1e-3).mean()))
             # five DDPM steps over 1000 training timesteps divide by sqrt(alpha_bar_t) ~ 0.05 .. 0.3 at the first steps: differences in the
             # trained weights (<= 5e-5 above) reach the images amplified; images are in [0, 1]
-            assert err.mean() <= 1e-3 and err.max() <= 2e-2, (mode, clip, imgs[clip])
+            # measured: exact mode max 2.7e-4, split-bf16 mode max 4.7e-3 / mean 2.4e-5 (without the clip)
+            assert err.mean() <= 5e-4 and err.max() <= 1e-2, (mode, clip, imgs[clip])
         final[mode] = (losses, sd, pred, imgs)
         report[mode] = {"max_rel_loss_err": float(rl.max()), "max_rel_clipnorm_err": float(rn.max()), "worst_weight_abs_err_first8": worst,
                         "worst_weight_err_over_typical_displacement": worst_rel_move,
@@ -127,3 +129,33 @@ def test_train_engine_replays_reference_trajectory(gpu, golden):
     with open(os.path.join(ROOT, "gpurun_out", "r05_trajectory_drift.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("G14 drift report:", json.dumps(report))
+
+
+def test_winograd_convolution_vs_fp64(gpu):
+    """bd_conv3x3_wino / bd_wino_weights (round 5 prototype, NOT in the plan: measured slower than conv_ps3): Winograd F(2x2, 3x3) of the stride-1
+    'same' 3x3 convolution (resnet.py:493,514) with split-bf16 products -- forward with every epilogue term, and the data gradient through the same kernel
+    on the rotated / transposed weight planes -- against the fp64 convolution: 2e-5 relative (measured 5e-6 forward, 7.5e-6 data gradient; the gate of
+    VERDICT round 4 task 1), on both supported widths, batch sizes that leave partial XCD runs, C down to one 16-channel K step."""
+    import torch.nn.functional as F
+    from baddiffusion_amd import ops
+    g = torch.Generator().manual_seed(5)
+    for (B, S, Cin, Cout) in ((3, 32, 64, 128), (2, 16, 128, 64), (5, 16, 16, 192), (1, 32, 48, 64)):
+        x = torch.randn(B, S, S, Cin, generator=g)
+        w = torch.randn(Cout, 3, 3, Cin, generator=g) / (9 * Cin) ** 0.5
+        bias, rb, res = torch.randn(Cout, generator=g), torch.randn(B, Cout, generator=g), torch.randn(B, S, S, Cout, generator=g)
+        ref = F.conv2d(x.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), bias.double(), padding=1).permute(0, 2, 3, 1)
+        u = ops.wino_weights(w.to(gpu), 1)
+        y = ops.conv3x3_wino(x.to(gpu), u, bias=bias.to(gpu)).cpu().double()
+        assert float((y - ref).norm() / ref.norm()) < 2e-5, (B, S, Cin, Cout)
+        y2 = ops.conv3x3_wino(x.to(gpu), u, bias=bias.to(gpu), rowbias=rb.to(gpu), residual=res.to(gpu), out_scale=0.5).cpu().double()
+        want = (ref + rb.double()[:, None, None, :] + res.double()) * 0.5
+        assert float((y2 - want).norm() / want.norm()) < 2e-5
+        if Cout % 16 == 0 and Cin % 64 == 0:
+            dy = torch.randn(B, S, S, Cout, generator=g)
+            dx = ops.conv3x3_wino(dy.to(gpu), ops.wino_weights(w.to(gpu), -1)).cpu().double()
+            rdx = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2), w.double().permute(0, 3, 1, 2), padding=1).permute(0, 2, 3, 1)
+            assert float((dx - rdx).norm() / rdx.norm()) < 2e-5
+    lib = __import__("baddiffusion_amd._lib", fromlist=["load"]).load()
+    assert lib.bd_conv3x3_wino_supported(128, 32, 32, 128, 128) == 1 and lib.bd_conv3x3_wino_supported(128, 8, 8, 256, 256) == 0
+    with pytest.raises(RuntimeError):
+        ops.conv3x3_wino(torch.randn(1, 8, 8, 64, device=gpu), ops.wino_weights(torch.randn(64, 3, 3, 64, device=gpu), 1))
