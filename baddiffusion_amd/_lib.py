@@ -141,7 +141,8 @@ class AttnSpDesc(C.Structure):
 
 class Conv2dDesc(C.Structure):
     _fields_ = [("x", vp), ("ldx", i64), ("w", vp), ("bias", vp), ("y", vp), ("ldy", i64), ("B", i32), ("H", i32), ("W", i32), ("Cin", i32),
-                ("Cout", i32), ("KH", i32), ("KW", i32), ("stride_h", i32), ("stride_w", i32), ("pad_h", i32), ("pad_w", i32), ("relu", i32)]
+                ("Cout", i32), ("KH", i32), ("KW", i32), ("stride_h", i32), ("stride_w", i32), ("pad_h", i32), ("pad_w", i32), ("relu", i32),
+                ("w_kc", i32)]
 
 
 class UnetConfig(C.Structure):

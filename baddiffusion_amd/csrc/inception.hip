@@ -107,6 +107,131 @@ __global__ __launch_bounds__(256) void ic_conv_kernel(IcConvParams p) {
     }
 }
 
+// ---- round 5: the same convolution on a double-buffered 128 x 64 tile with K-contiguous operands and vector LDS reads.
+// Weights [KH][KW][Cout][Cin] (w_kc layout: K contiguous like the activations), so both operand tiles are stored [row][k] (row stride 20 floats:
+// 16-byte reads of 16 different rows touch 16 different bank quads) and ONE ds_read_b128 feeds four MFMAs: lane half h holds k = 4h .. 4h+3 of an
+// 8-wide K group and MFMA e of the group multiplies (k = e | k = 4 + e) -- a permutation of the contraction order, every k exactly once.
+// 4 waves x (32 rows x 64 columns); the global loads of chunk c + 1 are issued before the MFMAs of chunk c (registers), stored to the other LDS
+// buffer behind them: one __syncthreads per chunk, 30 KB of LDS, ~5 workgroups per CU hide the rest of the latency.
+constexpr int IC2_BM = 128, IC2_BN = 64, IC2_BK = 16, IC2_LD = 20;
+
+template <bool CIN4>
+__global__ __launch_bounds__(256) void ic_conv2_kernel(IcConvParams p) {
+    __shared__ __attribute__((aligned(16))) float As[2][IC2_BM][IC2_LD];
+    __shared__ __attribute__((aligned(16))) float Bs[2][IC2_BN][IC2_LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int li = lane & 31, h = lane >> 5;
+    const long long m0 = (long long)blockIdx.x * IC2_BM;
+    const int n0 = blockIdx.y * IC2_BN;
+
+    // A loader: thread -> output pixel am, 8 consecutive k at akh * 8;  B loader: thread -> output channel bn, 4 consecutive k at bkq * 4
+    const int am = tid & 127, akh = tid >> 7;
+    const long long m = m0 + am;
+    const bool mv = m < p.M;
+    int ab = 0, aoy = 0, aox = 0;
+    if (mv) {
+        ab = (int)(m / ((long long)p.Ho * p.Wo));
+        const int r = (int)(m - (long long)ab * p.Ho * p.Wo);
+        aoy = r / p.Wo; aox = r - aoy * p.Wo;
+    }
+    const int iy0 = aoy * p.sh - p.pt, ix0 = aox * p.sw - p.pl;
+    const int bn = tid & 63, bkq = tid >> 6;
+    const bool nv = n0 + bn < p.Cout;
+    const int kchunks = (p.Cin + IC2_BK - 1) / IC2_BK;
+    const int nchunks = p.KH * p.KW * kchunks;
+
+    floatx16 acc0, acc1;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { acc0[r] = 0.f; acc1[r] = 0.f; }
+
+    float4 ra0, ra1, rb;
+    float fa0 = 0.f, fa1 = 0.f, fb = 0.f;      // 0 / 1 masks of the three loads, applied when the registers are stored to LDS (not before: the
+                                              // loads stay in flight across the MFMAs of the current chunk)
+    int kh = 0, kw = 0, kc = 0;            // cursor of the NEXT chunk to load
+    auto load = [&]() {
+        const int iy = iy0 + kh, ix = ix0 + kw;
+        const bool pv = mv && (unsigned)iy < (unsigned)p.H && (unsigned)ix < (unsigned)p.W;
+        const float* xp = p.x + (((long long)ab * p.H + (pv ? iy : 0)) * p.W + (pv ? ix : 0)) * p.ldx;
+        const int ci = kc * IC2_BK + akh * 8;
+        // branch-free loads (an exec-masked `if (valid) load` makes hipcc wait vmcnt(0) behind the branch: the prefetch would be synchronous):
+        // the address is clamped into the tensor, the value is multiplied by a 0 / 1 mask
+        if constexpr (CIN4) {
+            const bool v0 = pv && ci < p.Cin, v1 = pv && ci + 4 < p.Cin;
+            ra0 = *reinterpret_cast<const float4*>(xp + (v0 ? ci : 0));
+            ra1 = *reinterpret_cast<const float4*>(xp + (v1 ? ci + 4 : 0));
+            fa0 = v0 ? 1.f : 0.f; fa1 = v1 ? 1.f : 0.f;
+        } else {
+            float t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) { const bool v = pv && ci + j < p.Cin; t[j] = xp[v ? ci + j : 0] * (v ? 1.f : 0.f); }
+            ra0 = make_float4(t[0], t[1], t[2], t[3]); ra1 = make_float4(t[4], t[5], t[6], t[7]);
+            fa0 = fa1 = 1.f;
+        }
+        const int ck = kc * IC2_BK + bkq * 4;
+        {
+            const bool vb = nv && ck < p.Cin;
+            const float* wp = p.w + ((long long)(kh * p.KW + kw) * p.Cout + (nv ? n0 + bn : 0)) * p.Cin;
+            if constexpr (CIN4) {
+                rb = *reinterpret_cast<const float4*>(wp + (vb ? ck : 0));
+                fb = vb ? 1.f : 0.f;
+            } else {
+                float t[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { const bool v = vb && ck + j < p.Cin; t[j] = wp[v ? ck + j : 0] * (v ? 1.f : 0.f); }
+                rb = make_float4(t[0], t[1], t[2], t[3]);
+                fb = 1.f;
+            }
+        }
+        if (++kc == kchunks) { kc = 0; if (++kw == p.KW) { kw = 0; ++kh; } }
+    };
+    auto store = [&](int buf) {
+        *reinterpret_cast<float4*>(&As[buf][am][akh * 8]) = make_float4(ra0.x * fa0, ra0.y * fa0, ra0.z * fa0, ra0.w * fa0);
+        *reinterpret_cast<float4*>(&As[buf][am][akh * 8 + 4]) = make_float4(ra1.x * fa1, ra1.y * fa1, ra1.z * fa1, ra1.w * fa1);
+        *reinterpret_cast<float4*>(&Bs[buf][bn][bkq * 4]) = make_float4(rb.x * fb, rb.y * fb, rb.z * fb, rb.w * fb);
+    };
+
+    load();
+    store(0);
+    __syncthreads();
+    for (int c = 0; c < nchunks; ++c) {
+        const int buf = c & 1;
+        const bool more = c + 1 < nchunks;
+        if (more) load();
+#pragma unroll
+        for (int g = 0; g < 2; ++g) {
+            const float4 av = *reinterpret_cast<const float4*>(&As[buf][wave * 32 + li][g * 8 + 4 * h]);
+            const float4 b0 = *reinterpret_cast<const float4*>(&Bs[buf][li][g * 8 + 4 * h]);
+            const float4 b1 = *reinterpret_cast<const float4*>(&Bs[buf][32 + li][g * 8 + 4 * h]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0.x, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b1.x, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b0.y, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1.y, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b0.z, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b1.z, acc1, 0, 0, 0);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b0.w, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b1.w, acc1, 0, 0, 0);
+        }
+        if (more) store(buf ^ 1);
+        __syncthreads();
+    }
+    // lane holds columns li (acc0) and 32 + li (acc1) of rows (r & 3) + 8 (r >> 2) + 4 h of the wave's 32 rows
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+        const int n = n0 + q * 32 + li;
+        if (n >= p.Cout) continue;
+        const float bnv = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const long long mm = m0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (mm < p.M) {
+                float v = (q ? acc1[r] : acc0[r]) + bnv;
+                if (p.relu) v = fmaxf(v, 0.f);
+                p.y[mm * p.ldy + n] = v;
+            }
+        }
+    }
+}
+
 // mode 0 = max, 1 = average (count_include_pad per flag).  One thread = one output pixel x 4 channels.
 __global__ __launch_bounds__(256) void ic_pool_kernel(const float* __restrict__ x, long long ldx, float* __restrict__ y, long long ldy, int B, int H,
                                                       int W, int C, int Ho, int Wo, int K, int stride, int pad, int mode, int count_include_pad) {
@@ -194,6 +319,14 @@ extern "C" int bd_conv2d_nhwc(const bd_conv2d_desc* d, bd_stream_t stream) {
     p.Wo = (d->W + 2 * d->pad_w - d->KW) / d->stride_w + 1;
     BD_CHECK(p.Ho > 0 && p.Wo > 0, BD_ERR_INVALID, "bd_conv2d_nhwc: empty output");
     p.M = (long long)d->B * p.Ho * p.Wo;
+    if (d->w_kc) {      // round 5: weights [KH][KW][Cout][Cin] -> the double-buffered 128 x 64 kernel
+        const long long gx2 = cdiv(p.M, IC2_BM);
+        BD_CHECK(gx2 < (1ll << 31), BD_ERR_UNSUPPORTED, "bd_conv2d_nhwc: grid too large");
+        if (d->Cin % 4 == 0) hipLaunchKernelGGL(ic_conv2_kernel<true>, dim3((unsigned)gx2, (unsigned)cdiv(d->Cout, IC2_BN)), dim3(256), 0, S(stream), p);
+        else hipLaunchKernelGGL(ic_conv2_kernel<false>, dim3((unsigned)gx2, (unsigned)cdiv(d->Cout, IC2_BN)), dim3(256), 0, S(stream), p);
+        BD_LAUNCH_CHECK("bd_conv2d_nhwc");
+        return BD_OK;
+    }
     const long long gx = cdiv(p.M, IC_BM);
     BD_CHECK(gx < (1ll << 31), BD_ERR_UNSUPPORTED, "bd_conv2d_nhwc: grid too large");
     hipLaunchKernelGGL(ic_conv_kernel, dim3((unsigned)gx, (unsigned)cdiv(d->Cout, IC_BN)), dim3(256), 0, S(stream), p);

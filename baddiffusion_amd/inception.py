@@ -75,13 +75,16 @@ def state_dict_manifest():
 class FIDInceptionV3:
     """`features = net(images)`: images [N, 3, H, W] float in [0, 1] or uint8 [N, H, W, 3] on the GPU -> [N, 2048] float32."""
 
-    def __init__(self, state_dict=None, device="cuda", batch_size=50):
+    def __init__(self, state_dict=None, device="cuda", batch_size=200):
         self.device = torch.device(device)
         if self.device.type != "cuda":
             raise RuntimeError("FIDInceptionV3 runs on the GPU only (libbd_hip.so); there is no CPU path")
         self._lib = L.load()
-        self.batch_size = int(batch_size)       # fid_score.py:55 (results do not depend on it: samples are independent)
+        # fid_score.py:55 feeds 50 images at a time; samples are independent, so the chunk is a throughput knob only: at 50 the 8 x 8 / 17 x 17
+        # stages launch too few tiles for 256 CUs (59.7 TFLOP/s over the 94 convolutions), at 200 they fill the chip (83.8; scripts/bench_fid_layers.py)
+        self.batch_size = int(batch_size)
         self._w = {}
+        self._kc = os.environ.get("BD_FID_CONV", "kc") != "old"
         self.flops = 0.0                        # algorithmic flops of the convolutions launched so far (2 * MACs; bench.py reads and resets it)
         if state_dict is not None:
             self.load_state_dict(state_dict)
@@ -102,8 +105,10 @@ class FIDInceptionV3:
             g, b = sd[name + ".bn.weight"].detach().double(), sd[name + ".bn.bias"].detach().double()
             mu, var = sd[name + ".bn.running_mean"].detach().double(), sd[name + ".bn.running_var"].detach().double()
             s = g / torch.sqrt(var + BN_EPS)
-            # fold in fp64, store fp32: [Cout, Cin, KH, KW] -> [KH, KW, Cin, Cout]
-            Wf = (W * s.view(-1, 1, 1, 1)).permute(2, 3, 1, 0).contiguous().to(torch.float32)
+            # fold in fp64, store fp32: [Cout, Cin, KH, KW] -> [KH, KW, Cout, Cin] (K contiguous: bd_conv2d_desc.w_kc = 1, the double-buffered
+            # 128 x 64 kernel of round 5; BD_FID_CONV=old keeps the [KH, KW, Cin, Cout] layout and the 64 x 64 kernel for A/B)
+            Wf = (W * s.view(-1, 1, 1, 1)).permute(2, 3, 0, 1) if self._kc else (W * s.view(-1, 1, 1, 1)).permute(2, 3, 1, 0)
+            Wf = Wf.contiguous().to(torch.float32)
             w[name] = (Wf.to(self.device), (b - mu * s).to(torch.float32).to(self.device))
         self._w = w
         return self
@@ -111,7 +116,7 @@ class FIDInceptionV3:
     # ---- layer launches -----------------------------------------------------------------------------------------------------
     def _conv(self, x, name, k, stride=1, pad=(0, 0), out=None):
         Wf, bias = self._w[name]
-        KH, KW, Cin, Cout = Wf.shape
+        KH, KW, Cin, Cout = (Wf.shape[0], Wf.shape[1], Wf.shape[3], Wf.shape[2]) if self._kc else Wf.shape
         assert (KH, KW) == tuple(k) and x.shape[-1] == Cin, (name, tuple(Wf.shape), tuple(x.shape))
         B, H, W_, _ = x.shape
         Ho, Wo = (H + 2 * pad[0] - KH) // stride + 1, (W_ + 2 * pad[1] - KW) // stride + 1
@@ -119,7 +124,7 @@ class FIDInceptionV3:
             out = torch.empty(B, Ho, Wo, Cout, device=x.device)
         assert tuple(out.shape) == (B, Ho, Wo, Cout), (name, tuple(out.shape), (B, Ho, Wo, Cout))
         d = L.Conv2dDesc(x=x.data_ptr(), ldx=x.stride(2), w=Wf.data_ptr(), bias=bias.data_ptr(), y=out.data_ptr(), ldy=out.stride(2),
-                         B=B, H=H, W=W_, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride_h=stride, stride_w=stride, pad_h=pad[0], pad_w=pad[1], relu=1)
+                         B=B, H=H, W=W_, Cin=Cin, Cout=Cout, KH=KH, KW=KW, stride_h=stride, stride_w=stride, pad_h=pad[0], pad_w=pad[1], relu=1, w_kc=int(self._kc))
         L.check(self._lib.bd_conv2d_nhwc(C.byref(d), L.stream()), "bd_conv2d_nhwc")
         self.flops += 2.0 * B * Ho * Wo * Cout * KH * KW * Cin
         return out

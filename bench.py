@@ -367,9 +367,9 @@ def run_fid_features(dev, n32=2048, n299=256, batch=None):
             sd[k] = 0.8 + 0.4 * torch.rand(shp, generator=g)
         else:
             sd[k] = 0.1 * torch.randn(shp, generator=g)
-    net = FIDInceptionV3(sd, device=dev, batch_size=batch or int(os.environ.get("BD_FID_BATCH", "50")))     # fid_score.py:55 default batch 50
+    net = FIDInceptionV3(sd, device=dev, **({"batch_size": batch or int(os.environ["BD_FID_BATCH"])} if (batch or "BD_FID_BATCH" in os.environ) else {}))
     out = {"weights": "seeded random, pytorch_fid InceptionV3 shapes (23.9 M parameters)", "batch_size": net.batch_size,
-           "peak_tflops": FP32_MFMA_PEAK_TFLOPS, "kernel": "ic_conv_kernel (bd_conv2d_nhwc), exact fp32 products"}
+           "peak_tflops": FP32_MFMA_PEAK_TFLOPS, "kernel": "ic_conv2_kernel (bd_conv2d_nhwc, 128 x 64 double-buffered tile, K-contiguous weights), exact fp32 products"}
     for tag, n, S in (("cifar32", n32, 32), ("direct299", n299, 299)):
         imgs = torch.randint(0, 256, (n, S, S, 3), generator=g, dtype=torch.uint8).to(dev)
         f = net(imgs[: net.batch_size])

@@ -432,6 +432,9 @@ typedef struct {
     float* y; int64_t ldy;            /* output [B, Ho, Wo, Cout] at pixel stride ldy: Ho = (H + 2 pad_h - KH) / stride_h + 1, ...  */
     int B, H, W, Cin, Cout, KH, KW, stride_h, stride_w, pad_h, pad_w;
     int relu;                         /* y = max(y, 0)  (BasicConv2d = conv + bn + relu)                                           */
+    int w_kc;                         /* round 5: 1 = weights are [KH][KW][Cout][Cin] (K contiguous): the double-buffered 128 x 64 tile kernel
+                                         with vector LDS reads; 0 = [KH][KW][Cin][Cout], the 64 x 64 kernel.  Same results up to the fp32
+                                         summation order inside a 16-channel chunk.                                                   */
 } bd_conv2d_desc;
 /* Cout % 4 == 0; x 16-byte aligned with ldx % 4 == 0 when Cin % 4 == 0 (any alignment for the 3-channel stem). */
 int bd_conv2d_nhwc(const bd_conv2d_desc* d, bd_stream_t stream);
