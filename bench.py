@@ -52,7 +52,7 @@ _PMC_PS = {"conv_ps_wgrad": (r"conv_ps_wgrad3?_kernel", r"conv_ps_wgrad_reduce")
            "attn_sp_fwd": (r"attn_sp_fwd_kernel",), "attn_sp_bwd_a": (r"attn_sp_bwd_a_kernel",), "attn_sp_bwd_b": (r"attn_sp_bwd_b_kernel",),
            "gemm_sp_nt": (r"gemm_sp_kernel<false, false>",), "gemm_sp_nn": (r"gemm_sp_kernel<false, true>",),
            "gemm_sp_tn": (r"gemm_sp_kernel<true, true>", r"gemm_sp_reduce")}
-PMC_ROUNDS = ("r04", "r03", "r02")                     # this round's file first; an older one is used only when it is absent, and flagged
+PMC_ROUNDS = ("r05", "r04", "r03", "r02")                     # this round's file first; an older one is used only when it is absent, and flagged
 PMC_FILE = "profiles/{rnd}_pmc_bench_{wl}{mode}.json"   # wl = "" (CIFAR train step), "celeba_" (256x256 train step), "ddim50_" / "ddpm1000_" (sampling)
 
 

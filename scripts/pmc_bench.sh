@@ -4,7 +4,7 @@
 mode=${1:-bf16x3}
 wl=${2:-cifar}
 case $wl in
-  cifar)  WLARGS="--steps 3 --warmup 1 --no-sampling --no-celeba --no-dp-probe --sustain 0"; tag="" ;;
+  cifar)  WLARGS="--steps 3 --warmup 1 --no-sampling --no-celeba --no-fid --no-dp-probe --sustain 0"; tag="" ;;
   celeba) WLARGS="--workload celeba --steps 3 --warmup 1 --sustain 0"; tag="celeba_" ;;
   ddim50) WLARGS="--workload ddim50 --batch 2048"; tag="ddim50_" ;;       # the chunk shape of the default line's DDIM-50 x 2048 loop
   ddpm1000) WLARGS="--workload ddim50 --batch 256"; tag="ddpm1000_" ;;    # same kernels and batch as the DDPM-1000 x 256 loop, 50 evaluations

@@ -1,7 +1,7 @@
 #!/bin/bash
 # HIP API + kernel + memory-copy trace of the forced data-parallel step at world 1 (what does RCCL's 1-rank all-reduce call?)
 out=$GRAFT_REPO_ROOT/gpurun_out
-ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-prof --no-sampling --no-celeba --no-dp-probe --sustain 0"
+ARGS="--steps 4 --warmup 2 --no-cpu-baseline --no-prof --no-sampling --no-celeba --no-fid --no-dp-probe --sustain 0"
 cd /tmp && export TMPDIR=/tmp
 rm -rf /tmp/rd2 && BD_FORCE_DP=1 BD_DP_BUCKET_MB=100000 rocprofv3 --kernel-trace --hip-trace --memory-copy-trace --stats --output-format csv -d /tmp/rd2 -o r -- python $GRAFT_REPO_ROOT/bench.py $ARGS > /tmp/rd2.log 2>&1
 ls /tmp/rd2 /tmp/rd2/* | head -20

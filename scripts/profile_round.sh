@@ -1,9 +1,9 @@
 #!/bin/bash
 # Round profile artifacts (run on the GPU box through gpurun): rocprofv3 kernel-trace summaries + bench JSON lines, then the
 # PMC traffic passes.  usage: scripts/profile_round.sh <tag>   -> gpurun_out/<tag>_*   (copy what is to be judged into profiles/)
-tag=${1:-r04}
+tag=${1:-r05}
 out=$GRAFT_REPO_ROOT/gpurun_out
-TRAIN="--no-cpu-baseline --no-sampling --no-celeba --no-dp-probe --sustain 0"     # the headline train step alone (what the kernel tables describe)
+TRAIN="--no-cpu-baseline --no-sampling --no-celeba --no-fid --no-dp-probe --sustain 0"     # the headline train step alone (what the kernel tables describe)
 cd /tmp && export TMPDIR=/tmp
 # 1. the train step of the default command under rocprofv3 (two-stream schedule = the timed region of the bench line)
 rm -rf /tmp/rp
@@ -30,5 +30,8 @@ cd /tmp && rm -rf /tmp/rp3 && rocprofv3 --kernel-trace --stats -d /tmp/rp3 -o r 
 python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/rp3 -name "*.db" | head -1) 57 > $out/${tag}_ddim50_b512_kernel_stats.txt
 # 6. the 256 x 256 workload: kernel tables (two-stream, single-stream) + PMC traffic
 $GRAFT_REPO_ROOT/scripts/profile_celeba.sh $tag > /dev/null 2>&1
+# 7. the measure path's feature extractor (SURVEY f-3): bench.py --workload fid under rocprofv3 (2048 CIFAR-size + 256 full-size images, + 1 warm-up chunk each)
+cd /tmp && rm -rf /tmp/rp4 && rocprofv3 --kernel-trace --stats -d /tmp/rp4 -o r -- python $GRAFT_REPO_ROOT/bench.py --workload fid > /tmp/rp4.log 2>&1
+python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/rp4 -name "*.db" | head -1) 1 > $out/${tag}_fid_features_kernel_stats.txt
 head -12 $out/${tag}_train_step_b128_kernel_stats.txt | cut -c1-140
 cut -c1-400 $out/${tag}_bench.json

@@ -3,7 +3,7 @@
 # usage: scripts/valu_census.sh [cifar|celeba]  -> gpurun_out/valu_census_<workload>.txt  (counts are wave-instructions per STEP)
 wl=${1:-cifar}
 case $wl in
-  cifar)  WLARGS="--steps 3 --warmup 1 --no-sampling --no-celeba --no-dp-probe --sustain 0"; steps=4 ;;
+  cifar)  WLARGS="--steps 3 --warmup 1 --no-sampling --no-celeba --no-fid --no-dp-probe --sustain 0"; steps=4 ;;
   celeba) WLARGS="--workload celeba --steps 3 --warmup 1 --sustain 0"; steps=4 ;;
 esac
 cd /tmp && export TMPDIR=/tmp

@@ -41,7 +41,8 @@ def main():
     ea = TrainEngine(ma, DDPMScheduler(), lr=2e-4, force_dp=False)
     eb = TrainEngine(mb, DDPMScheduler(), lr=2e-4, force_dp=True, dp_check=True)
     assert eb.dp and eb._comm is not None and eb._dp_shadow is not None
-    out = {"transport": "rccl-direct" if eb._rccl is not None else "c10d:" + dist.get_backend(), "world": eb.world}
+    out = {"transport": "rccl-direct" if eb._rccl is not None else "c10d:" + dist.get_backend(), "world": eb.world,
+           "transport_note": eb.transport_note}
     for e, key in ((ea, "ms_plain"), (eb, "ms_dp")):
         torch.cuda.synchronize()
         t0 = time.perf_counter()

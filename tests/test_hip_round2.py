@@ -422,7 +422,7 @@ def test_bench_two_ranks_end_to_end(gpu):
     """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per process), with gloo so that
     both ranks can share the test box's single GPU: one JSON line from rank 0 with the whole-job aggregate."""
     r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--sampling-n", "4,2",
-                   "--no-celeba", "--sustain", "0.05", "--dp-sweep-buckets", "0,32", "--dp-sweep-slots", "128,192", "--total", "16"], {}, timeout=900)
+                   "--no-celeba", "--no-fid", "--sustain", "0.05", "--dp-sweep-buckets", "0,32", "--dp-sweep-slots", "128,192", "--total", "16"], {}, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1

@@ -159,3 +159,74 @@ def test_winograd_convolution_vs_fp64(gpu):
     assert lib.bd_conv3x3_wino_supported(128, 32, 32, 128, 128) == 1 and lib.bd_conv3x3_wino_supported(128, 8, 8, 256, 256) == 0
     with pytest.raises(RuntimeError):
         ops.conv3x3_wino(torch.randn(1, 8, 8, 64, device=gpu), ops.wino_weights(torch.randn(64, 3, 3, 64, device=gpu), 1))
+
+
+def test_static_cache_is_reset_by_in_place_weight_changes(gpu):
+    """ADVICE round 4: inside ONE static_weights() block the prepared weight planes are keyed on (params pointer, workspace pointer, B) only;
+    load_state_dict on the same buffer, bd_unet_set_compute_mode and bd_unet_reset_static_cache must each make the next forward re-read the weights."""
+    from baddiffusion_amd.unet import unet_from_config
+    cfg = C.SMALL_CFGS["small"]
+    m = unet_from_config(cfg).to(gpu)
+    P = U.gen_params(cfg, 4)
+    m.load_state_dict(P)
+    x = torch.randn(4, 3, cfg.sample_size, cfg.sample_size, generator=torch.Generator().manual_seed(2)).to(gpu)
+    with torch.no_grad(), m.static_weights():
+        a = m(x, 11).sample.clone()
+        assert torch.equal(m(x, 11).sample, a)                       # the cached planes are used, same result
+        m.load_state_dict({k: v * 1.05 for k, v in P.items()})       # same flat buffer, new values
+        b = m(x, 11).sample.clone()
+        assert not torch.equal(a, b)
+        with torch.no_grad():
+            m.flat.data.mul_(1.0 / 1.05)          # an in-place change the Python side cannot see: the prepared conv / attention planes are stale
+        stale = m(x, 11).sample.clone()           # (biases / GroupNorm parameters are read from the buffer directly: a mixture, by contract undefined)
+        m._reset_static_cache()                   # explicit reset: everything is re-read
+        c = m(x, 11).sample
+        assert float((c - a).abs().max()) < 1e-4 * float(a.abs().max()) and not torch.equal(c, b)
+        assert float((stale - a).abs().max()) > 10 * float((c - a).abs().max())
+        m.set_compute_mode("f32") if hasattr(m, "set_compute_mode") else None
+
+
+def test_tune_set_slot_count_keeps_results(gpu):
+    """bd_tune_set("ps_wg3_slots", n) (bench.py --gpus N sweeps it inside one process): another K-split of the large weight gradients changes the
+    fp32 summation order only, workspaces are re-laid out, and 0 restores the default."""
+    import ctypes
+    from baddiffusion_amd import _lib as L
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    from baddiffusion_amd.trainer import TrainEngine
+    lib = L.load()
+    cfg = U.CIFAR10_32
+    g = torch.Generator().manual_seed(9)
+    B = 16
+    u8 = torch.randint(0, 256, (B, 32, 32, 3), generator=g, dtype=torch.uint8).to(gpu)
+    pois = (torch.arange(B) % 4 == 0).to(gpu)
+    from baddiffusion_amd.dataset import Backdoor
+    trig = Backdoor(root=None).get_trigger("BOX_14", 3, 32); tgt = Backdoor(root=None).get_target("CORNER", trig)
+    eps = torch.randn(B, 3, 32, 32, generator=g).to(gpu); t = torch.randint(0, 1000, (B,), generator=g).to(gpu)
+    res = {}
+    try:
+        for slots in (0, 96, 0):
+            assert lib.bd_tune_set(b"ps_wg3_slots", slots) == 0
+            m = make_model(cfg, 0, gpu)
+            eng = TrainEngine(m, DDPMScheduler(), lr=2e-4)
+            loss = eng.train_step(u8, pois, trig.to(gpu), tgt.to(gpu), eps, t)
+            res.setdefault(slots, []).append((float(loss), eng.grads.clone(), m.workspace_bytes(B, True)))
+            eng.close()
+    finally:
+        lib.bd_tune_set(b"ps_wg3_slots", 0)
+    (l0, g0, w0), (l0b, g0b, w0b) = res[0]
+    (l1, g1, w1), = res[96]
+    assert l0 == l0b and torch.equal(g0, g0b) and w0 == w0b          # 0 restores the default exactly
+    assert l1 == l0                                                    # forward untouched (the op workspace is a maximum over all launches: it may not move)
+    assert float((g1 - g0).norm() / g0.norm()) < 1e-5 and not torch.equal(g1, g0)
+    assert lib.bd_tune_set(b"no_such_knob", 1) != 0
+
+
+def test_rccl_transport_is_agreed_on_collectively(gpu):
+    """a rank on which the direct RCCL transport cannot be opened must not leave the others inside RCCL's bootstrap.  With the failure
+    injected (BD_RCCL_FAIL_RANK) the engine reports the reason and runs the c10d transport; the step is bit-identical to the ordinary one."""
+    import subprocess, sys
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BD_DP_TRANSPORT="rccl", BD_RCCL_FAIL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_force_dp_worker.py")], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["transport"] == "c10d:nccl" and "fault injection" in (d.get("transport_note") or "") and d["equal"] and d["moments_equal"], d
