@@ -24,7 +24,7 @@ for r in rows:
 disp = collections.defaultdict(set)
 for r in rows: disp[r["Kernel_Name"][:70]].add(r["Dispatch_Id"])
 for k, v in agg.items():
-    if "igemm" in k or "gn_" in k or "conv_ps" in k or "thin" in k or "attn" in k:
+    if "igemm" in k or "gn_" in k or "conv_ps" in k or "thin" in k or "attn" in k or "wino" in k:
         n = len(disp[k])
         print(k, "dispatches", n, {c: round(x / n, 1) for c, x in v.items()})
 PY
