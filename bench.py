@@ -279,7 +279,8 @@ def run_sampling(model, kind, n, mode, world, rank, dev, lib, want_roofline=True
            "value": world * n / dt, "unit": "samples/s", "samples_per_gpu": n, "unet_evaluations": evals,
            "seconds_per_loop": dt, "ms_per_unet_step": dt / evals * 1e3, "step_tflops": gf * n * world / dt / 1e3,
            "frac_of_fp32_mfma_peak": gf * n / dt / 1e3 / FP32_MFMA_PEAK_TFLOPS,
-           "images_finite": bool(np.isfinite(np.asarray(out.images)).all())}
+           "images_finite": bool(np.isfinite(np.asarray(out.images)).all()),
+           "inference_chunk": getattr(model, "last_chunk", None)}       # the chunk decides which kernels the plan picks
     if want_roofline:
         lib.bd_prof_reset(); lib.bd_prof_enable(1)
         pipe(batch_size=n, init=init[:min(n, model.max_chunk)], generator=gen, num_inference_steps=5 if pndm else 3, output_type=None)
