@@ -83,13 +83,19 @@ static float timeit_free(int reps, Ctx* c) {
     return ms / reps * 1e3f;
 }
 
-int main() {
+int main(int argc, char** argv) {
     Ctx c;
     hipMalloc(&c.out, 8); hipMemset(c.out, 0, 8);
     c.n = (64ll << 20) / 16 * 4;                       // 256 MB per tensor: 768 MB of traffic per streaming pass (past the Infinity Cache)
     hipMalloc(&c.a, c.n * 16); hipMalloc(&c.b, c.n * 16); hipMalloc(&c.z, c.n * 16);
     hipMemset(c.a, 0, c.n * 16); hipMemset(c.b, 0, c.n * 16);
-    hipStreamCreate(&c.s1); hipStreamCreate(&c.s2); hipEventCreateWithFlags(&c.ej, hipEventDisableTiming);
+    // argv[1]: priority of the streaming role's stream relative to the matrix role's (0 = both default; -1 = higher; 1 = lower)
+    int plo = 0, phi = 0; hipDeviceGetStreamPriorityRange(&plo, &phi);
+    const int rel = argc > 1 ? atoi(argv[1]) : 0;
+    hipStreamCreateWithPriority(&c.s1, hipStreamDefault, rel < 0 ? plo : (rel > 0 ? phi : 0));
+    hipStreamCreateWithPriority(&c.s2, hipStreamDefault, rel < 0 ? phi : (rel > 0 ? plo : 0));
+    printf("stream priorities: matrix %d, streaming %d (range %d .. %d, lower number = higher priority)\n", rel < 0 ? plo : (rel > 0 ? phi : 0), rel < 0 ? phi : (rel > 0 ? plo : 0), plo, phi);
+    hipEventCreateWithFlags(&c.ej, hipEventDisableTiming);
     c.wgs = 256 * 4;                                   // four 256-thread workgroups per CU per role (1 wave per SIMD each)
     // size the matrix role so that it takes about as long as one streaming pass
     c.iters = 2000;
