@@ -343,7 +343,7 @@ def bench_sampling(args, world, rank, dev):
         line.update({k: v for k, v in res.items() if k not in line})
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = sampling_cpu_baseline()["ddpm1000" if args.workload == "ddpm1000" else "ddim50"]
-        print(json.dumps(line), file=_JSON_OUT, flush=True)
+        emit(line, args)
     return 0
 
 
@@ -432,7 +432,7 @@ def bench_anp(args, world, rank, dev):
                 "final_loss": float(logs["loss"]), "final_backdoor_mse": float(logs["backdoor_mse"])}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(30.0, kind="anp")
-        print(json.dumps(line), file=_JSON_OUT, flush=True)
+        emit(line, args)
     return 0
 
 
@@ -630,6 +630,116 @@ def measure_dp(eng, model, step, lib, barrier, dev, world, args, log, first):
                              "set BD_DP_BUCKET_MB / BD_PS_WG3_SLOTS in the environment to make a value the default of a run" % default_mb)
     return out
 
+HEADLINE_MAX_BYTES = 8192          # the driver captures a bounded tail of stdout: the ONE line must fit it (round 5's 20 KB line did not parse)
+
+
+def _rnd(v, nd=4):
+    """floats to `nd` significant digits (the detail file keeps full precision)"""
+    if isinstance(v, float):
+        return float(f"{v:.{nd}g}") if np.isfinite(v) else None
+    return v
+
+
+def _pick(d, keys, nd=4):
+    return {k: _rnd(d[k], nd) for k in keys if isinstance(d, dict) and k in d and not isinstance(d[k], (dict, list))}
+
+
+def _roofline_headline(r, full=True):
+    if not isinstance(r, dict):
+        return None
+    keys = (("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us", "launches_per_step",
+             "frac_of_power_limited_peak", "mfma_power_limited_peak_measured") if full else ("kernel", "frac", "traffic"))
+    o = _pick(r, keys, 5)
+    if full and isinstance(r.get("standalone"), dict):
+        o["standalone"] = _pick(r["standalone"], ("frac", "avg_launch_us"))
+    return o
+
+
+def headline_line(out, detail_file=None):
+    """The ONE JSON line of the contract, bounded (< HEADLINE_MAX_BYTES): the contract's keys, `roofline` and `cpu_baseline` of the timed
+    workload, and for the riders (`sampling.*`, `celeba`, `fid_features`) value / ms_per_step / roofline.frac / roofline.traffic /
+    cpu_baseline.value only.  Everything else -- per-class kernel tables, sweeps, per-bucket times, the notes saying how each figure was
+    taken -- is the DETAIL object `out`, written to `detail_file` (gpurun_out/bench_detail.json) and copied under profiles/ per round."""
+    h = {k: _rnd(out[k], 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                      "vs_baseline", "dtype", "data") if k in out}
+    h["config"] = dict(out["config"])
+    for k in ("final_loss", "ms_per_step_median", "step_tflops", "step_frac_of_hbm_roofline", "images_finite", "final_backdoor_mse"):
+        if k in out:
+            h[k] = _rnd(out[k], 5)
+    if isinstance(out.get("sustained"), dict):
+        h["sustained"] = _pick(out["sustained"], ("steps", "seconds", "ms_per_step"))
+    if "roofline" in out:
+        h["roofline"] = _roofline_headline(out["roofline"])
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        h["cpu_baseline"] = _pick(cb, ("value", "unit", "cores", "cpu_model", "kind"))
+        h["cpu_baseline"]["sample"] = str(cb.get("sample", ""))[:110]
+
+    def rider(d):
+        if not isinstance(d, dict):
+            return None
+        if "error" in d:
+            return {"error": str(d["error"])[:120]}
+        o = _pick(d, ("value", "unit", "ms_per_step", "ms_per_unet_step", "samples_per_gpu", "global_samples", "scaling"))
+        if "roofline" in d:
+            o["roofline"] = _roofline_headline(d["roofline"], full=False)
+        if isinstance(d.get("cpu_baseline"), dict):
+            o["cpu_baseline"] = _pick(d["cpu_baseline"], ("value", "cores"))
+        return o
+    if isinstance(out.get("sampling"), dict):
+        h["sampling"] = {k: rider(v) for k, v in out["sampling"].items()}
+    if "celeba" in out:
+        h["celeba"] = rider(out["celeba"])
+        if isinstance(out["celeba"], dict) and "step_frac_of_hbm_roofline" in out["celeba"]:
+            h["celeba"]["step_frac_of_hbm_roofline"] = _rnd(out["celeba"]["step_frac_of_hbm_roofline"])
+    ff = out.get("fid_features")
+    if isinstance(ff, dict):
+        c = ff.get("cifar32", {})
+        h["fid_features"] = ({"error": str(ff["error"])[:120]} if "error" in ff else
+                             {"value": _rnd(c.get("images_per_s")), "unit": "images/s", "tflops": _rnd(c.get("tflops")),
+                              "frac_of_fp32_mfma_peak": _rnd(c.get("frac_of_fp32_mfma_peak"))})
+    dd = out.get("distributed")
+    if isinstance(dd, dict):
+        hd = _pick(dd, ("world", "backend", "rccl_ranks", "collectives_per_step", "segments", "buckets", "bytes_per_step"))
+        hd["transport"] = ("rccl-direct" if dd.get("rccl_ranks") else "c10d" if dd.get("world", 1) > 1 else "none")
+        if dd.get("transport_fallback_reason"):
+            hd["transport_fallback_reason"] = str(dd["transport_fallback_reason"])[:120]
+        me = dd.get("measured")
+        if isinstance(me, dict):
+            hd["measured"] = ({"error": str(me["error"])[:120]} if "error" in me else
+                              _pick(me, ("ms_per_step", "ms_per_step_without_collectives", "exposed_comm_ms")))
+        h["distributed"] = hd
+    dp = out.get("dp_path_at_world_1")
+    if isinstance(dp, dict):
+        h["dp_path_at_world_1"] = ({"error": str(dp["error"])[:120]} if "error" in dp else
+                                   _pick(dp, ("ms_per_step", "ms_per_step_without_the_rccl_call", "host_enqueue_ms_plain")))
+    if detail_file:
+        h["detail_file"] = detail_file
+    line = json.dumps(h)
+    if len(line) >= HEADLINE_MAX_BYTES:       # never print a line the driver cannot capture: drop the riders, keep the contract
+        for k in ("dp_path_at_world_1", "fid_features", "celeba", "sampling", "distributed", "sustained"):
+            h.pop(k, None)
+            line = json.dumps(h)
+            if len(line) < HEADLINE_MAX_BYTES:
+                break
+    assert len(line) < HEADLINE_MAX_BYTES, len(line)
+    return line
+
+
+def emit(out, args):
+    """write the detail object next to the run (and say where), print the bounded headline as the LAST stdout write"""
+    path = args.detail_file
+    rel = None
+    if path:
+        try:
+            os.makedirs(os.path.dirname(os.path.abspath(path)), exist_ok=True)
+            with open(path, "w") as f:
+                json.dump(out, f, indent=1)
+            rel = os.path.relpath(path, ROOT) if os.path.abspath(path).startswith(ROOT) else path
+        except OSError as e:
+            rel = f"(not written: {e})"
+    print(headline_line(out, rel), file=_JSON_OUT, flush=True)
+
 
 def main():
     ap = argparse.ArgumentParser()
@@ -666,6 +776,9 @@ def main():
                     help="1: replay the train step as one hipGraph (TrainEngine(use_graph=True)); sampled roofline steps stay eager")
     ap.add_argument("--mode", default=os.environ.get("BD_COMPUTE_MODE", "bf16x3"), choices=["f32", "bf16x3"],
                     help="contraction arithmetic: exact fp32 MFMA, or split-bf16 (hi+lo, 3 MFMAs, ~2^-16 rel. error)")
+    ap.add_argument("--detail-file", default=os.environ.get("BD_BENCH_DETAIL", os.path.join(ROOT, "gpurun_out", "bench_detail.json")),
+                    help="where the DETAIL object goes (per-class kernel tables, sweeps, per-bucket times, notes); the stdout line stays < 8 KB "
+                         "and names this file as `detail_file`; '' = do not write")
     ap.add_argument("--cpu-baseline-worker", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--cpu-baseline-kind", default="train", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -709,11 +822,10 @@ def main():
     if args.workload == "fid":         # the measure path's feature extractor alone (side measurement; also rides in the default line)
         res = run_fid_features(dev, batch=args.batch if args.batch > 0 else None)
         if rank == 0:
-            print(json.dumps({"metric": "FID InceptionV3 pool3 features, images/s (2048 CIFAR-size images)", "value": res["cifar32"]["images_per_s"],
-                              "unit": "images/s", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": res["cifar32"]["seconds"] * 1e3,
-                              "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded uint8 images)",
-                              "config": {"workload": "SURVEY f-3: fid_score.py:91-148 feature extraction on the device"}, "fid_features": res}),
-                  file=_JSON_OUT, flush=True)
+            emit({"metric": "FID InceptionV3 pool3 features, images/s (2048 CIFAR-size images)", "value": res["cifar32"]["images_per_s"],
+                  "unit": "images/s", "n_gpus": 1, "steps": 1, "warmup": 1, "ms_per_step": res["cifar32"]["seconds"] * 1e3,
+                  "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic (seeded uint8 images)",
+                  "config": {"workload": "SURVEY f-3: fid_score.py:91-148 feature extraction on the device"}, "fid_features": res}, args)
         return 0
     celeba = args.workload == "celeba"      # BASELINE configs[3] topology (256x256, 113.7 M params)
     B = args.batch if args.batch > 0 else (4 if celeba else 128)
@@ -900,8 +1012,8 @@ def main():
                "value": value, "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "f32" if args.mode == "f32" else "f32 (split-bf16 hi+lo products, fp32 accumulate)",
-               "data": f"synthetic (uint8 {S_IMG}x{S_IMG}x3 images resident in HBM, seeded default-init weights; trigger / target: "
-                       f"{names['target_source']})",
+               "data": f"synthetic (uint8 {S_IMG}x{S_IMG}x3 images resident in HBM, seeded default-init weights)",
+               "trigger_target_source": names["target_source"],
                "config": {"workload": workload, "global_batch": world * B, "parallelism": f"dp{world}",
                           "params": int(model.num_flat)},
                "final_loss": final_loss,
@@ -947,16 +1059,16 @@ def main():
             out["celeba"] = side
         if fid_feat:
             out["fid_features"] = fid_feat
-        final_line = json.dumps(out)
+        final_out = out
     else:
-        final_line = None
+        final_out = None
     if getattr(eng, "_rccl", None) not in (None, "none"):      # tear the gradient communicator down while the HIP runtime is still up
         torch.cuda.synchronize()
         eng._rccl.destroy()
     if dist.is_available() and dist.is_initialized():      # world > 1 (or a c10d 1-rank group of an A/B run)
         dist.destroy_process_group()
-    if final_line is not None:      # the LAST thing this process writes: nothing a library prints at teardown can follow it
-        print(final_line, file=_JSON_OUT, flush=True)
+    if final_out is not None:      # the LAST thing this process writes: nothing a library prints at teardown can follow it
+        emit(final_out, args)
 
 
 if __name__ == "__main__":

@@ -418,15 +418,26 @@ def _torchrun(args, env_extra, timeout=600, backend="gloo"):
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
 
-def test_bench_two_ranks_end_to_end(gpu):
+def test_bench_two_ranks_end_to_end(gpu, tmp_path):
     """bench.py --gpus 2 exactly as the driver launches it (torch.distributed.run, one rank per process), with gloo so that
-    both ranks can share the test box's single GPU: one JSON line from rank 0 with the whole-job aggregate."""
+    both ranks can share the test box's single GPU: one JSON line from rank 0 with the whole-job aggregate -- BOUNDED (the driver captures a
+    bounded tail of stdout; round 5's 20 KB line did not parse) -- and the detail object in the file the line names."""
+    detail = str(tmp_path / "bench_detail.json")
     r = _torchrun(["bench.py", "--gpus", "2", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--sampling-n", "4,2",
-                   "--no-celeba", "--no-fid", "--sustain", "0.05", "--dp-sweep-buckets", "0,32", "--dp-sweep-slots", "128,192", "--total", "16"], {}, timeout=900)
+                   "--no-celeba", "--no-fid", "--sustain", "0.05", "--dp-sweep-buckets", "0,32", "--dp-sweep-slots", "128,192", "--total", "16",
+                   "--detail-file", detail], {}, timeout=900)
     assert r.returncode == 0, r.stderr[-2000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1
-    d = json.loads(lines[0])
+    assert len(lines) == 1 and r.stdout.rstrip().endswith(lines[0])           # the LAST thing on stdout
+    assert len(lines[0]) < 8192
+    head = json.loads(lines[0])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data",
+              "config", "roofline", "distributed", "sampling", "detail_file"):
+        assert k in head, k
+    assert head["detail_file"] == detail and 0 < head["roofline"]["frac"] < 1 and "workload" in head["config"]
+    assert head["distributed"]["measured"]["ms_per_step"] > 0 and head["sampling"]["ddim50_sharded"]["value"] > 0
+    d = json.load(open(detail))
+    assert abs(head["value"] - d["value"]) < 1e-4 * d["value"] and head["steps"] == d["steps"] and head["n_gpus"] == d["n_gpus"]
     assert d["n_gpus"] == 2 and d["steps"] == 2 and d["value"] > 0 and d["scaling"] == "weak"
     assert abs(d["value"] - 2 * 2 / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"] + 1e-3     # images of ALL ranks / max-over-ranks time
     # the line says what the collectives were: world, backend, one all_reduce per finished gradient range, all bytes of the flat gradient

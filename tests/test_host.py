@@ -359,3 +359,40 @@ def test_rccl_binding_loads_and_exports_the_calls_used():
     import ctypes
     assert ctypes.sizeof(rccl._UniqueId) == 128
     assert b"" != lib.ncclGetErrorString(0)
+
+
+def test_bench_headline_is_bounded_and_parses():
+    """The ONE line bench.py prints is built from the detail object by bench.headline_line; the driver reads a bounded tail of stdout, and round 5's
+    20 KB line did not parse there.  Rebuild the line from a recorded full detail object (profiles/r05_bench.json: the 20 KB line of round 5, every
+    rider present) and from degenerate ones: < 8 KB, valid JSON, the contract's keys + roofline + cpu_baseline intact, riders reduced to value /
+    ms_per_step / roofline.frac / roofline.traffic / cpu_baseline.value."""
+    import importlib.util
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(root, "bench.py"))
+    b = importlib.util.module_from_spec(spec); spec.loader.exec_module(b)
+    out = json.load(open(os.path.join(root, "profiles", "r05_bench.json")))
+    assert len(json.dumps(out)) > 16000                           # the recorded object really is the oversized one
+    line = b.headline_line(out, "gpurun_out/bench_detail.json")
+    assert len(line) < b.HEADLINE_MAX_BYTES == 8192 and "\n" not in line
+    h = json.loads(line)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype", "data", "config"):
+        assert k in h and (h[k] == out[k] or isinstance(out[k], float)), k
+    assert abs(h["value"] - out["value"]) < 1e-5 * out["value"] and abs(h["ms_per_step"] - out["ms_per_step"]) < 1e-5 * out["ms_per_step"]
+    r = h["roofline"]
+    for k in ("bound", "kernel", "achieved", "peak", "unit", "frac", "traffic", "algorithmic_bytes_per_launch", "avg_launch_us"):
+        assert k in r, k
+    assert abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-3 and r["standalone"]["frac"] > r["frac"]
+    assert h["cpu_baseline"]["value"] > 0 and h["cpu_baseline"]["cores"] >= 1 and h["cpu_baseline"]["kind"] == "port"
+    for rider in (h["sampling"]["ddim50"], h["sampling"]["ddpm1000"], h["celeba"]):
+        assert rider["value"] > 0 and 0 < rider["roofline"]["frac"] < 1 and rider["cpu_baseline"]["value"] > 0
+        assert all(not isinstance(v, str) or len(v) < 64 for v in rider.values())
+    assert h["fid_features"]["value"] > 0 and h["detail_file"] == "gpurun_out/bench_detail.json"
+    assert not any(k in h for k in ("kernel_classes", "kernel_classes_standalone"))
+    # an object whose riders are absurdly large still yields a parsable contract line (riders dropped, never the contract)
+    fat = dict(out, sampling={f"k{i}": dict(out["sampling"]["ddim50"]) for i in range(200)})
+    line = b.headline_line(fat, None)
+    assert len(line) < 8192 and json.loads(line)["roofline"]["kernel"] == r["kernel"] and "cpu_baseline" in json.loads(line)
+    # riders that failed carry a bounded error string
+    bad = dict(out, celeba={"error": "x" * 5000}, fid_features={"error": "y" * 5000})
+    hb = json.loads(b.headline_line(bad, None))
+    assert len(hb["celeba"]["error"]) <= 120 and len(hb["fid_features"]["error"]) <= 120
