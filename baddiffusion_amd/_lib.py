@@ -106,11 +106,6 @@ class ConvPsDesc(C.Structure):
                 ("workspace", vp), ("workspace_bytes", sz), ("gn_part", vp), ("gn_groups", i32)]
 
 
-class ConvWinoDesc(C.Structure):
-    _fields_ = [("B", i32), ("H", i32), ("W", i32), ("C", i32), ("N", i32), ("x", vp), ("ldx", i64), ("u_planes", vp), ("bias", vp),
-                ("rowbias", vp), ("ld_rowbias", i64), ("residual", vp), ("ldr", i64), ("out_scale", f32), ("y", vp), ("ldy", i64)]
-
-
 class ConvPsWgradDesc(C.Structure):
     _fields_ = [("B", i32), ("H", i32), ("W", i32), ("Cin", i32), ("Cout", i32), ("x_split", vp), ("ldx", i64),
                 ("dy_split", vp), ("lddy", i64), ("dw", vp), ("db", vp), ("workspace", vp), ("workspace_bytes", sz)]
@@ -242,9 +237,6 @@ SIGNATURES = {
     "bd_unet_set_static_weights": (i32, [vp, i32]),
     "bd_unet_reset_static_cache": (i32, [vp]),
     "bd_tune_set": (i32, [C.c_char_p, i32]),
-    "bd_conv3x3_wino_supported": (i32, [i32, i32, i32, i32, i32]),
-    "bd_conv3x3_wino": (i32, [C.POINTER(ConvWinoDesc), vp]),
-    "bd_wino_weights": (i32, [vp, i32, i32, i32, vp, vp]),
     "bd_unet_segment_range": (i32, [vp, i32, C.POINTER(i64), C.POINTER(i64)]),
     "bd_unet_segment_num_ranges": (i32, [vp, i32]),
     "bd_unet_segment_range_k": (i32, [vp, i32, i32, C.POINTER(i64), C.POINTER(i64)]),

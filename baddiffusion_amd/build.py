@@ -22,7 +22,6 @@ SOURCES = [  # (file, extra flags)
     ("igemm.hip", []),
     ("conv_ps.hip", ["-DBD_PS_ABLATION"] if os.environ.get("BD_BUILD_ABLATION") == "1" else []),
     ("conv_ph.hip", []),
-    ("conv_wino.hip", []),
     ("gemm_sp.hip", []),
     ("attn_sp.hip", ["-DBD_AS_ABLATION"] if os.environ.get("BD_BUILD_ABLATION") == "1" else []),
     ("metrics.hip", ["-ffp-contract=off"]),

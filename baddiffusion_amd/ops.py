@@ -299,29 +299,6 @@ def conv3x3_ps(x_split, w_split, B, H, W, K, N, direction=1, bias=None, rowbias=
     return y if part is None else (y, part)
 
 
-def wino_weights(w, direction=1):
-    """conv weight [Cout,3,3,Cin] fp32 -> Winograd planes U = G g G^T (bd_wino_weights): int16 [C/16, 16, N, 32] (16 bf16 hi | 16 bf16 lo)"""
-    lib = L.load(); _need_cuda(w)
-    Cout, _, _, Cin = w.shape
-    N, K = (Cout, Cin) if direction > 0 else (Cin, Cout)
-    u = torch.empty(K // 16, 16, N, 32, dtype=torch.int16, device=w.device)
-    L.check(lib.bd_wino_weights(L.ptr(w.contiguous()), Cin, Cout, direction, L.ptr(u), L.stream()), "bd_wino_weights")
-    return u
-
-
-def conv3x3_wino(x, u, bias=None, rowbias=None, residual=None, out_scale=1.0, out=None):
-    """Winograd F(2x2,3x3) stride-1 pad-1 convolution: x fp32 NHWC [B,H,W,C], u = wino_weights(w) -> fp32 [B,H,W,N]"""
-    lib = L.load(); _need_cuda(x, u, bias, rowbias, residual)
-    B, H, W, K = x.shape
-    N = u.shape[2]
-    y = torch.empty(B, H, W, N, device=x.device) if out is None else out
-    d = L.ConvWinoDesc(B=B, H=H, W=W, C=K, N=N, x=L.ptr(x), ldx=_ld(x), u_planes=L.ptr(u), bias=L.ptr(bias), rowbias=L.ptr(rowbias),
-                       ld_rowbias=rowbias.stride(0) if rowbias is not None else 0, residual=L.ptr(residual),
-                       ldr=_ld(residual) if residual is not None else 0, out_scale=out_scale, y=L.ptr(y), ldy=_ld(y))
-    L.check(lib.bd_conv3x3_wino(C.byref(d), L.stream()), "bd_conv3x3_wino")
-    return y
-
-
 def conv3x3_ps_wgrad(x_split, dy_split, B, H, W, Cin, Cout, with_db=False):
     """dw [Cout,3,3,Cin] (and db [Cout]) of the stride-1 pad-1 conv from split-plane operands."""
     lib = L.load(); _need_cuda(x_split, dy_split)

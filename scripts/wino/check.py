@@ -7,6 +7,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspa
 import torch
 import torch.nn.functional as F
 from baddiffusion_amd import ops
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import wino_probe as wp
 
 torch.manual_seed(0)
 dev = "cuda"
@@ -37,8 +39,8 @@ for (B, S, Cin, Cout) in SMALL + BIG:
     x = torch.randn(B, S, S, Cin, device=dev)
     w = torch.randn(Cout, 3, 3, Cin, device=dev) / (9 * Cin) ** 0.5
     bias = torch.randn(Cout, device=dev)
-    u = ops.wino_weights(w, 1)
-    y = ops.conv3x3_wino(x, u, bias=bias)
+    u = wp.wino_weights(w, 1)
+    y = wp.conv3x3_wino(x, u, bias=bias)
     torch.cuda.synchronize()
     rec = {"B": B, "S": S, "Cin": Cin, "Cout": Cout}
     nb = min(B, 4)
@@ -53,21 +55,21 @@ for (B, S, Cin, Cout) in SMALL + BIG:
         rec["direct_rel_l2_vs_fp64"] = float(ed.norm() / r.norm())
         # extras: rowbias + residual epilogue
         rb = torch.randn(B, Cout, device=dev); res = torch.randn(B, S, S, Cout, device=dev)
-        y2 = ops.conv3x3_wino(x, u, bias=bias, rowbias=rb, residual=res, out_scale=0.7)
+        y2 = wp.conv3x3_wino(x, u, bias=bias, rowbias=rb, residual=res, out_scale=0.7)
         want = (y + rb[:, None, None, :] + res) * 0.7
         rec["epilogue_max_abs_diff"] = float((y2 - want).abs().max())
         if B >= 64:
             fl = 2.0 * B * S * S * Cin * Cout * 9
-            t_w = timeit(lambda: ops.conv3x3_wino(x, u, bias=bias))
+            t_w = timeit(lambda: wp.conv3x3_wino(x, u, bias=bias))
             t_d = timeit(lambda: ops.conv3x3_ps(xs, ws, B, S, S, Cin, Cout, 1, bias=bias))
-            t_u = timeit(lambda: ops.wino_weights(w, 1))
+            t_u = timeit(lambda: wp.wino_weights(w, 1))
             rec.update({"wino_us": t_w, "direct_ps_us": t_d, "wino_weights_us": t_u, "wino_alg_tflops": fl / t_w / 1e6, "direct_alg_tflops": fl / t_d / 1e6,
                         "speedup": t_d / t_w})
     # data gradient through the same kernel (rotated, transposed weights): compare with autograd-free fp64 transposed conv on a few samples
     if Cout % 16 == 0 and Cin % 64 == 0:
         dy = torch.randn(nb, S, S, Cout, device=dev)
-        ut = ops.wino_weights(w, -1)
-        dx = ops.conv3x3_wino(dy, ut)
+        ut = wp.wino_weights(w, -1)
+        dx = wp.conv3x3_wino(dy, ut)
         rdx = F.conv_transpose2d(dy.double().permute(0, 3, 1, 2).cpu(), w.double().permute(0, 3, 1, 2).cpu(), padding=1).permute(0, 2, 3, 1).to(dev)
         rec["dgrad_rel_l2_vs_fp64"] = float((dx.double() - rdx).norm() / rdx.norm())
     print(json.dumps(rec), flush=True)

@@ -14,7 +14,8 @@
 //     x 64 B = 16 KB) streams through a ring of four by LDS-DMA, three stages ahead, counted vmcnt, ONE barrier per stage;
 //   * output    Y = A^T M A in registers (a lane holds all 16 xi of its (tile, co) elements), + bias + row bias + residual, fp32 NHWC.
 // Layers: W in {16, 32}, (H/2)*(W/2) % 64 == 0, C % 16 == 0, N % 64 == 0.
-#include "common.h"
+#include "../../baddiffusion_amd/csrc/common.h"
+#include "wino.h"
 #include <cstdlib>
 
 namespace bd {
