@@ -333,6 +333,8 @@ def measure(config, dsl, folder_name, pipeline, rank=0, world=1):
     # noise sequence and chain j of each shard would be correlated with chain j of the others.  world == 1 keeps the
     # reference's stream exactly; a sharded run is a different (equally valid) draw of the same distribution.
     rng = torch.Generator().manual_seed(config.seed + rank)
+    if hasattr(pipeline.unet, "chunks_used"):
+        pipeline.unet.chunks_used.clear()
     parts = [config.output_dir, folder_name] + ([f"ep{config.sample_ep}"] if config.sample_ep is not None else [])
     suffix = "_noclip" if not config.clip else ""
     clean_path, backdoor_path = os.path.join(*parts, "clean" + suffix), os.path.join(*parts, "backdoor" + suffix)
@@ -383,9 +385,11 @@ def measure(config, dsl, folder_name, pipeline, rank=0, world=1):
         fid_reason = None
     print(f"[{config.sample_ep}] FID: {fid_sc if fid_sc is not None else 'None (BD_FID_WEIGHTS not set: pytorch_fid Inception weights unavailable)'}, "
           f"MSE: {mse_sc}, SSIM: {ssim_sc}")
-    # the inference chunk decides which kernels the plan picks (fp32 summation order): recorded with the scores it produced
+    # the inference batch decides which kernels the plan picks (fp32 summation order): EVERY batch size a forward of this measure() ran with is
+    # recorded with the scores it produced (`last_chunk` alone is only the tail call, e.g. 8 of 32 = 12 + 12 + 8)
+    used = sorted(getattr(pipeline.unet, "chunks_used", ()), reverse=True)
     return update_score_file(config, "score.json", fid_sc, mse_sc, ssim_sc, fid_reason=fid_reason,
-                             extra={"inference_chunk": getattr(pipeline.unet, "last_chunk", None)})
+                             extra={"inference_chunk": used[0] if len(used) == 1 else (used or None)})
 
 
 def checkpoint(config, engine, pipeline, cur_epoch, cur_step):

@@ -141,6 +141,7 @@ struct bd_unet {
     int cur_seg = 0, cur_group = 0;
     // layout cache
     int lay_B = -1, lay_train = -1, lay_gen = -1;
+    int fwd_gen = -1, fwd_B = -1; const void* fwd_ws = nullptr;   // the training forward whose saved activations are live (bd_tune_set guard)
     int64_t value_floats = 0, grad_floats = 0, scratch_floats = 0;
     size_t opws_bytes = 0, gnpart_floats = 0;
     int T = 0, sumC = 0;     // time-embed dim, total time_emb_proj rows
@@ -1425,6 +1426,7 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
     BD_CHECK(aligned16(params), BD_ERR_INVALID, "bd_unet_forward: params must be 16-byte aligned");
     c.params = params; c.x = x; c.ldx = ldx; c.t = t; c.t_stride = t_stride; c.out = out; c.ldo = ldo; c.st = S(stream);
     c.training = training != 0;
+    if (training) { u->fwd_gen = bd::g_tune_gen; u->fwd_B = B; u->fwd_ws = workspace; }
     const bool prepared = u->static_weights && !training && u->prep_params == (const void*)params && u->prep_ws == workspace && u->prep_B == B;
     if (c.w_split && !prepared) {   // split the weights once; forward convs and (same workspace) the backward dgrads read the copy
         BD_TRY(bd_split_bf16(params, (int64_t)wsplit_elems(u), const_cast<uint16_t*>(c.w_split), stream));
@@ -1499,6 +1501,9 @@ extern "C" int bd_unet_backward_segment(bd_unet* u, int seg, int B, const float*
                                         const float* dout, int64_t lddo, float* grads, void* workspace, size_t workspace_bytes,
                                         bd_stream_t stream, int64_t* ready_lo, int64_t* ready_hi) {
     Ctx c;
+    // a tuning-knob change re-lays out the workspace lazily: never under the saved activations of a forward that already ran
+    BD_CHECK(!u || u->fwd_ws != workspace || u->fwd_B != B || u->fwd_gen == bd::g_tune_gen, BD_ERR_INVALID,
+             "bd_unet_backward: bd_tune_set was called between the training forward and its backward (the saved activations would move)");
     BD_TRY(unet_ctx(u, c, B, 1, workspace, workspace_bytes));
     BD_CHECK(params && x && dout && grads, BD_ERR_INVALID, "bd_unet_backward: null pointer");
     BD_CHECK(aligned16(params) && aligned16(grads), BD_ERR_INVALID, "bd_unet_backward: params/grads must be 16-byte aligned");

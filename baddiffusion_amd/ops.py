@@ -652,3 +652,16 @@ def adam_clip(p, g, m, v, sumsq_t, step, lr, max_norm=1.0, betas=(0.9, 0.999), e
     L.check(lib.bd_adam_clip(L.ptr(p), L.ptr(g), L.ptr(m), L.ptr(v), p.numel(), L.ptr(sumsq_t), float(max_norm), float(lr),
                              float(betas[0]), float(betas[1]), float(eps), int(step), L.ptr(grad_norm_out), L.stream()),
             "bd_adam_clip")
+
+
+def tune_set(name, value, check=True):
+    """bd_tune_set (run-time tuning knobs of the kernels, e.g. "ps_wg3_slots"; 0 restores the default) + what the C call cannot do: every plan re-lays
+    out its workspace on its next call, so the workspaces the live models pool by size are dropped here (callers used to reach into
+    model._ws_pool).  Not to be called between a training forward and its backward: the C side refuses a re-layout while saved activations are live."""
+    from . import unet
+    rc = L.load().bd_tune_set(name.encode() if isinstance(name, str) else name, int(value))
+    for m in list(unet.live_models()):
+        m._ws_pool = {}
+    if check:
+        L.check(rc, "bd_tune_set")
+    return rc

@@ -64,24 +64,33 @@ def _check(rc, what):
         raise RuntimeError(f"{what} failed: {_load().ncclGetErrorString(rc).decode()} ({rc})")
 
 
+def unique_id():
+    """ncclGetUniqueId as 128 bytes (rank 0 calls it, the launcher's group broadcasts it)"""
+    uid = _UniqueId()
+    _check(_load().ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
+    return bytes(uid.internal)
+
+
 class RcclComm:
     """One RCCL communicator over the ranks of the (already initialised) torch.distributed default group, or a 1-rank
     communicator when there is none.  All calls enqueue on the HIP stream they are given and return at once."""
 
-    def __init__(self, device=None):
+    def __init__(self, device=None, uid=None):
+        """uid: the 128 bytes of unique_id() already shared by the caller (TrainEngine._open_rccl stages the host-side calls with an agreement
+        behind each); None: obtain and broadcast it here."""
         import torch.distributed as dist
         lib = _load()
         self.device = torch.device("cuda", torch.cuda.current_device()) if device is None else torch.device(device)
         have = dist.is_available() and dist.is_initialized()
         self.rank = dist.get_rank() if have else 0
         self.world = dist.get_world_size() if have else 1
-        uid = _UniqueId()
-        if self.rank == 0:
-            _check(lib.ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-        if self.world > 1:
-            box = [bytes(uid.internal) if self.rank == 0 else None]
-            dist.broadcast_object_list(box, src=0)
-            C.memmove(C.byref(uid), box[0], 128)
+        if uid is None:
+            box = [unique_id() if self.rank == 0 else None]
+            if self.world > 1:
+                dist.broadcast_object_list(box, src=0)
+            uid = box[0]
+        raw, uid = uid, _UniqueId()
+        C.memmove(C.byref(uid), raw, 128)
         self._comm = C.c_void_p()
         with torch.cuda.device(self.device):
             _check(lib.ncclCommInitRank(C.byref(self._comm), self.world, uid, self.rank), "ncclCommInitRank")

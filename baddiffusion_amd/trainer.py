@@ -214,6 +214,10 @@ class TrainEngine:
         self.transport_note = None       # why the direct RCCL transport is not in use (None: it is, or it was never asked for)
         if self.dp and os.environ.get("BD_DP_TRANSPORT", "rccl") == "none":
             self._rccl = "none"          # measurement only: at world > 1 the replicas drift apart (nothing is exchanged)
+            if self.world > 1:           # a stray environment variable must not silently turn the gradient exchange off
+                import warnings
+                self.transport_note = "BD_DP_TRANSPORT=none: NO gradient exchange, the replicas drift apart (measurement only)"
+                warnings.warn(self.transport_note)
         if self.dp and os.environ.get("BD_DP_TRANSPORT", "rccl") == "rccl":
             be = dist.get_backend(process_group) if (dist.is_available() and dist.is_initialized()) else "none"
             if process_group is None and (be == "nccl" or self.world == 1):
@@ -230,11 +234,14 @@ class TrainEngine:
         self.sync_state()
 
     def _open_rccl(self, dev):
-        """(communicator or None, reason): the direct RCCL transport, agreed on COLLECTIVELY.  Every rank tries to load librccl and says so
-        (all_reduce MIN over the launcher's group) BEFORE anyone enters the unique-id broadcast / ncclCommInitRank, then the communicator
-        is created and checked -- an all-reduce of a rank-dependent vector against its closed form -- and the outcome is agreed on again.  If
-        any rank failed at either point, EVERY rank destroys what it has and uses torch.distributed.all_reduce: ranks that picked their
-        transport locally would sit in mismatched collectives (a silent hang)."""
+        """(communicator or None, reason): the direct RCCL transport, agreed on COLLECTIVELY, stage by stage -- (1) every rank loads librccl,
+        (2) rank 0 obtains the unique id, (3) after the id broadcast every rank runs ncclCommInitRank, (4) the self-test (an all-reduce of a
+        rank-dependent vector against its closed form) -- with an all_reduce MIN of an ok flag over the launcher's group behind EACH stage,
+        so a rank whose host-side call raised never reaches a torch.distributed collective the others are not in.  If any rank failed at
+        any stage, EVERY rank destroys what it has and uses torch.distributed.all_reduce (ADVICE rounds 4, 5).  What this cannot cover: a
+        rank that dies or blocks INSIDE ncclCommInitRank (a native rendezvous) leaves the others waiting there until RCCL's own timeout.
+        Fault injection for the tests: BD_RCCL_FAIL_RANK=<rank>[:<stage>] (stage load | uid | init | selftest), honoured only with
+        BD_TEST_HOOKS=1."""
         import warnings
         multi = self.world > 1
 
@@ -245,38 +252,65 @@ class TrainEngine:
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             return bool(int(flag.item()))
 
-        err = None
-        try:
-            from . import rccl
-            rccl._load()
-            if os.environ.get("BD_RCCL_FAIL_RANK", "") == str(dist.get_rank() if multi else 0):      # fault injection (tests)
-                raise RuntimeError("BD_RCCL_FAIL_RANK fault injection")
-        except (RuntimeError, OSError) as e:
-            err = f"librccl not loadable: {e}"
-        if not all_ok(err is None):
-            reason = err or "librccl failed to load on another rank"
-            warnings.warn(f"direct RCCL transport unavailable ({reason}); gradients go through torch.distributed.all_reduce on every rank")
-            if not multi:
-                ensure_single_rank_group()
-            return None, reason
+        me = dist.get_rank() if multi else 0
+        inj = os.environ.get("BD_RCCL_FAIL_RANK", "") if os.environ.get("BD_TEST_HOOKS") == "1" else ""
+        inj_rank, _, inj_stage = inj.partition(":")
+
+        def inject(stage):
+            if inj_rank == str(me) and (inj_stage or "load") == stage:
+                raise RuntimeError(f"BD_RCCL_FAIL_RANK fault injection at stage {stage}")
+
         comm = None
-        try:
-            comm = rccl.RcclComm(dev)
-            err = comm.self_test()
-        except (RuntimeError, OSError) as e:
-            err = f"{type(e).__name__}: {e}"
-        if not all_ok(err is None):
-            reason = err or "communicator creation / self-test failed on another rank"
+
+        def give_up(reason):
+            nonlocal comm
             if comm is not None:
                 try:
                     torch.cuda.synchronize()
                     comm.destroy()
                 except Exception:
                     pass
+                comm = None
             warnings.warn(f"direct RCCL transport unavailable ({reason}); gradients go through torch.distributed.all_reduce on every rank")
             if not multi:
                 ensure_single_rank_group()
             return None, reason
+
+        def stage(name, fn, other):
+            """run this rank's part of a stage, then agree: (ok on every rank, reason)"""
+            err = None
+            try:
+                inject(name)
+                fn()
+            except (RuntimeError, OSError) as e:
+                err = f"{name}: {type(e).__name__}: {e}"
+            return all_ok(err is None), (err or other)
+
+        from . import rccl
+        ok, why = stage("load", rccl._load, "librccl failed to load on another rank")
+        if not ok:
+            return give_up(why if why.startswith("load") and "fault" in why else f"librccl not loadable ({why})")
+        uid = [None]
+        ok, why = stage("uid", lambda: uid.__setitem__(0, rccl.unique_id() if me == 0 else None), "ncclGetUniqueId failed on rank 0")
+        if not ok:
+            return give_up(why)
+        if multi:
+            dist.broadcast_object_list(uid, src=0)      # every rank is here: the stage above was agreed on
+
+        def init():
+            nonlocal comm
+            comm = rccl.RcclComm(dev, uid=uid[0])
+        ok, why = stage("init", init, "ncclCommInitRank failed on another rank")
+        if not ok:
+            return give_up(why)
+
+        def selftest():
+            r = comm.self_test()
+            if r is not None:
+                raise RuntimeError(r)
+        ok, why = stage("selftest", selftest, "the communicator self-test failed on another rank")
+        if not ok:
+            return give_up(why)
         return comm, None
 
     # ---- measurement hooks (bench.py --gpus N) ---------------------------------------------------------------

@@ -11,6 +11,7 @@ is `bd_unet_backward`.  There is no PyTorch implementation of the network here: 
 library or without a GPU tensor, forward raises.
 """
 import os
+import weakref
 
 import numpy as np
 import ctypes as C
@@ -69,6 +70,13 @@ class _UNetFn(torch.autograd.Function):
         model._release_ws(ctx.ws)
         ctx.ws = None
         return grads, None, None, None
+
+
+_LIVE = weakref.WeakSet()     # every model with a plan: ops.tune_set drops their pooled workspaces (sizes follow the knobs)
+
+
+def live_models():
+    return list(_LIVE)
 
 
 class UNet2DModel(nn.Module):
@@ -176,6 +184,8 @@ class UNet2DModel(nn.Module):
         self.flat = nn.Parameter(torch.zeros(self.num_flat))
         self._segments = None
         self._ws_pool = {}
+        self.chunks_used = set()      # batch sizes the inference forwards actually ran with since the caller last cleared it (measure(): score.json)
+        _LIVE.add(self)
         self.reset_parameters()
 
     # ------------------------------------------------------------------ parameters / state dict
@@ -424,10 +434,12 @@ class UNet2DModel(nn.Module):
         while True:
             try:
                 if B <= chunk:
+                    self.chunks_used.add(int(B))
                     return self._run_forward(flat, x_nhwc, t, False)[0]
                 outs = []
                 for s in range(0, B, chunk):
                     tt = t if t.numel() == 1 else t[s: s + chunk]
+                    self.chunks_used.add(int(min(chunk, B - s)))
                     outs.append(self._run_forward(flat, x_nhwc[s: s + chunk], tt, False)[0])
                 return torch.cat(outs, 0)
             except torch.cuda.OutOfMemoryError:

@@ -586,49 +586,58 @@ def measure_dp(eng, model, step, lib, barrier, dev, world, args, log, first):
         state["i"] += n
         return dt / n * 1e3
 
-    direct = getattr(eng, "_rccl", None) not in (None, "none")
-    out = {"transport": "rccl-direct" if direct else "c10d", "ms_per_step": timed(8)}
-    eng.time_buckets = True
-    for _ in range(4):
-        step(state["i"]); state["i"] += 1
-    eng.time_buckets = False
-    out["buckets_timed"] = [{"closes_with_segment": s, "bytes": b, "ms_on_comm_stream": ms, "launches": n,
-                             "ring_bus_GBs": 2.0 * (world - 1) / world * b / (ms * 1e-3) / 1e9 if ms > 0 else None}
-                            for s, b, ms, n in eng.bucket_times()]
-    out["buckets_timed_note"] = ("events on the engine's communication stream around each bucket's grouped ncclAllReduce, 4 steps, in schedule (beside the "
-                                 "backward kernels)" if direct else "c10d transport: the collectives run on the process group's own stream / threads, "
-                                 "these events do not bracket them")
-    barrier()
-    eng.set_collectives(False)
-    out["ms_per_step_without_collectives"] = timed(8)
-    eng.set_collectives(True)
-    eng.sync_state()           # the replicas applied their own gradients for those steps: start again from rank 0's state
-    barrier()
-    out["exposed_comm_ms"] = out["ms_per_step"] - out["ms_per_step_without_collectives"]
-    if not args.no_dp_sweep:
-        default_mb = float(os.environ.get("BD_DP_BUCKET_MB", "32"))
-        sw = []
-        for mb in [float(v) for v in args.dp_sweep_buckets.split(",") if v.strip()]:
-            eng.set_buckets(mb)
-            sw.append({"bucket_mb": mb, "buckets": len(eng._buckets), "collectives_per_step": sum(len(rs) for _, rs in eng._buckets),
-                       "ms_per_step": timed()})
-            log(f"dp sweep: bucket {mb:g} MB -> {sw[-1]['buckets']} buckets, {sw[-1]['ms_per_step']:.2f} ms/step")
+    from baddiffusion_amd import ops
+    default_mb = float(os.environ.get("BD_DP_BUCKET_MB", "32"))
+    out = {}
+    try:
+        direct = getattr(eng, "_rccl", None) not in (None, "none")
+        out.update({"transport": "rccl-direct" if direct else "c10d", "ms_per_step": timed(8)})
+        eng.time_buckets = True
+        for _ in range(4):
+            step(state["i"]); state["i"] += 1
+        eng.time_buckets = False
+        out["buckets_timed"] = [{"closes_with_segment": s, "bytes": b, "ms_on_comm_stream": ms, "launches": n,
+                                 "ring_bus_GBs": 2.0 * (world - 1) / world * b / (ms * 1e-3) / 1e9 if ms > 0 else None}
+                                for s, b, ms, n in eng.bucket_times()]
+        out["buckets_timed_note"] = ("events on the engine's communication stream around each bucket's grouped ncclAllReduce, 4 steps, in schedule (beside the "
+                                     "backward kernels)" if direct else "c10d transport: the collectives run on the process group's own stream / threads, "
+                                     "these events do not bracket them")
+        barrier()
+        eng.set_collectives(False)
+        out["ms_per_step_without_collectives"] = timed(8)
+        eng.set_collectives(True)
+        eng.sync_state()           # the replicas applied their own gradients for those steps: start again from rank 0's state
+        barrier()
+        out["exposed_comm_ms"] = out["ms_per_step"] - out["ms_per_step_without_collectives"]
+        if not args.no_dp_sweep:
+            sw = []
+            for mb in [float(v) for v in args.dp_sweep_buckets.split(",") if v.strip()]:
+                eng.set_buckets(mb)
+                sw.append({"bucket_mb": mb, "buckets": len(eng._buckets), "collectives_per_step": sum(len(rs) for _, rs in eng._buckets),
+                           "ms_per_step": timed()})
+                log(f"dp sweep: bucket {mb:g} MB -> {sw[-1]['buckets']} buckets, {sw[-1]['ms_per_step']:.2f} ms/step")
+            eng.set_buckets(default_mb)
+            out["bucket_sweep"] = sw
+            ss = []
+            for sl in [int(v) for v in args.dp_sweep_slots.split(",") if v.strip()]:
+                L_check = ops.tune_set("ps_wg3_slots", sl, check=False)     # clears every model's pooled workspaces: sizes follow the slot count
+                if L_check != 0:
+                    ss.append({"ps_wg3_slots": sl, "error": "bd_tune_set refused"}); continue
+                ss.append({"ps_wg3_slots": sl, "ms_per_step": timed()})
+                log(f"dp sweep: wgrad3 slots {sl} -> {ss[-1]['ms_per_step']:.2f} ms/step")
+            ops.tune_set("ps_wg3_slots", 0)
+            out["wgrad3_slot_sweep"] = ss
+            out["sweep_note"] = ("defaults: BD_DP_BUCKET_MB=%g, ps_wg3_slots = 3/4 of the CUs; each point 2 untimed + 6 timed steps behind the contract region; "
+                                 "set BD_DP_BUCKET_MB / BD_PS_WG3_SLOTS in the environment to make a value the default of a run" % default_mb)
+    finally:
+        # whatever happened above, leave the engine as the later measurements (celeba, sampling) and the other ranks expect it: collectives on,
+        # default buckets and slot count; main() agrees on the outcome collectively before anyone continues
+        eng.time_buckets = False
+        eng.set_collectives(True)
         eng.set_buckets(default_mb)
-        out["bucket_sweep"] = sw
-        ss = []
-        for sl in [int(v) for v in args.dp_sweep_slots.split(",") if v.strip()]:
-            L_check = lib.bd_tune_set(b"ps_wg3_slots", sl)
-            model._ws_pool = {}            # workspace sizes follow the slot count
-            if L_check != 0:
-                ss.append({"ps_wg3_slots": sl, "error": "bd_tune_set refused"}); continue
-            ss.append({"ps_wg3_slots": sl, "ms_per_step": timed()})
-            log(f"dp sweep: wgrad3 slots {sl} -> {ss[-1]['ms_per_step']:.2f} ms/step")
-        lib.bd_tune_set(b"ps_wg3_slots", 0)
-        model._ws_pool = {}
-        out["wgrad3_slot_sweep"] = ss
-        out["sweep_note"] = ("defaults: BD_DP_BUCKET_MB=%g, ps_wg3_slots = 3/4 of the CUs; each point 2 untimed + 6 timed steps behind the contract region; "
-                             "set BD_DP_BUCKET_MB / BD_PS_WG3_SLOTS in the environment to make a value the default of a run" % default_mb)
+        ops.tune_set("ps_wg3_slots", 0)
     return out
+
 
 HEADLINE_MAX_BYTES = 8192          # the driver captures a bounded tail of stdout: the ONE line must fit it (round 5's 20 KB line did not parse)
 
@@ -874,6 +883,18 @@ def main():
             log(f"dp: {dp_meas['ms_per_step']:.2f} ms/step, without collectives {dp_meas['ms_per_step_without_collectives']:.2f}")
         except Exception as e:        # never lose the headline line to a side measurement
             dp_meas = {"error": f"{type(e).__name__}: {e}"}
+        # a rank that failed has left the sequence of collectives the others are in: agree on the outcome, and when any rank
+        # failed, every rank re-synchronises its replica from rank 0 before the later measurements
+        okf = torch.tensor([0 if (dp_meas is None or "error" in dp_meas) else 1], device=dev, dtype=torch.int32)
+        try:
+            dist.all_reduce(okf, op=dist.ReduceOp.MIN)
+            if int(okf.item()) == 0:
+                if "error" not in (dp_meas or {}):
+                    dp_meas = dict(dp_meas or {}, error="the data-parallel side measurement failed on another rank")
+                eng.sync_state()
+                barrier()
+        except Exception as e:
+            dp_meas = dict(dp_meas or {}, error=f"agreement after a failed side measurement failed too: {type(e).__name__}: {e}")
 
     dp_probe = None
     if world == 1 and not celeba and not args.no_dp_probe:

@@ -799,7 +799,7 @@ def test_cli_sampling_and_measure_end_to_end(gpu, tmp_path):
     on_disk = json.load(open(os.path.join(config.output_dir, "score.json")))
     assert on_disk == score
     assert set(score) == {"FID_noclip", "FID_reason_noclip", "MSE_noclip", "SSIM_noclip", "inference_chunk_noclip"}
-    assert score["inference_chunk_noclip"] == 8          # (round 5) the chunk the last forward ran with: 32 = 12 + 12 + 8
+    assert score["inference_chunk_noclip"] == [12, 8]     # (round 6) every batch size the forwards of this measure() ran with: 32 = 12 + 12 + 8
     assert score["FID_noclip"] is None and "Inception" in score["FID_reason_noclip"]
     bd_dir = os.path.join(config.output_dir, "measure", "backdoor_noclip")
     gen = np.stack([np.asarray(Image.open(os.path.join(bd_dir, f"{i}.png")).convert("RGB"), dtype=np.float64) / 255.0 for i in range(32)])

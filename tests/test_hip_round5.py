@@ -189,14 +189,46 @@ def test_tune_set_slot_count_keeps_results(gpu):
     assert l1 == l0                                                    # forward untouched (the op workspace is a maximum over all launches: it may not move)
     assert float((g1 - g0).norm() / g0.norm()) < 1e-5 and not torch.equal(g1, g0)
     assert lib.bd_tune_set(b"no_such_knob", 1) != 0
+    # round 6: ops.tune_set drops every live model's pooled workspaces (callers used to clear model._ws_pool themselves), and a knob
+    # change BETWEEN a training forward and its backward is refused instead of moving the saved activations under the live workspace
+    from baddiffusion_amd import ops
+    m = make_model(cfg, 0, gpu)
+    x = torch.randn(2, 32, 32, 3, device=gpu); tt = torch.tensor([3, 500], device=gpu)
+    try:
+        pred, ws = m._run_forward(m.flat.data, x, tt, training=True)
+        m._release_ws(ws)
+        assert any(m._ws_pool.values())
+        ops.tune_set("ps_wg3_slots", 96)
+        assert not any(m._ws_pool.values())
+        grads = torch.empty_like(m.flat.data); lo, hi = ctypes.c_int64(), ctypes.c_int64()
+        rc = lib.bd_unet_backward_segment(m._plan, 0, 2, m.flat.data.data_ptr(), x.data_ptr(), 3, pred.data_ptr(), pred.shape[-1], grads.data_ptr(),
+                                          ws.data_ptr(), ws.numel(), L.stream(), ctypes.byref(lo), ctypes.byref(hi))
+        assert rc != 0 and b"bd_tune_set" in lib.bd_last_error()
+        with pytest.raises(RuntimeError):
+            ops.tune_set("no_such_knob", 1)
+    finally:
+        ops.tune_set("ps_wg3_slots", 0)
+    torch.cuda.synchronize()
 
 
 def test_rccl_transport_is_agreed_on_collectively(gpu):
     """a rank on which the direct RCCL transport cannot be opened must not leave the others inside RCCL's bootstrap.  With the failure
-    injected (BD_RCCL_FAIL_RANK) the engine reports the reason and runs the c10d transport; the step is bit-identical to the ordinary one."""
+    injected (BD_RCCL_FAIL_RANK, honoured only with BD_TEST_HOOKS=1) at EACH host-side stage of TrainEngine._open_rccl -- library load, unique id,
+    ncclCommInitRank, self-test (an agreement behind every stage, not only the first) -- the engine reports the reason and runs the
+    c10d transport; the step is bit-identical to the ordinary one.  Without BD_TEST_HOOKS the variable is ignored (product path)."""
     import subprocess, sys
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BD_DP_TRANSPORT="rccl", BD_RCCL_FAIL_RANK="0")
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_force_dp_worker.py")], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
-    assert r.returncode == 0, r.stderr[-3000:]
-    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
-    assert d["transport"] == "c10d:nccl" and "fault injection" in (d.get("transport_note") or "") and d["equal"] and d["moments_equal"], d
+
+    def run(fail, hooks, batch):
+        env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", BD_DP_TRANSPORT="rccl", BD_RCCL_FAIL_RANK=fail, BD_T_BATCH=str(batch))
+        env.pop("BD_TEST_HOOKS", None)
+        if hooks:
+            env["BD_TEST_HOOKS"] = "1"
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_force_dp_worker.py")], capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        return json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+
+    for fail, batch in (("0", 128), ("0:uid", 8), ("0:init", 8), ("0:selftest", 8)):
+        d = run(fail, True, batch)
+        assert d["transport"] == "c10d:nccl" and "fault injection" in (d.get("transport_note") or "") and d["equal"] and d["moments_equal"], (fail, d)
+    d = run("0", False, 8)
+    assert d["transport"] == "rccl-direct" and d["transport_note"] is None and d["equal"], d
