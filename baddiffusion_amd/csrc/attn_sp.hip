@@ -74,23 +74,9 @@ __device__ __forceinline__ as_bf16x8 as_bf(as_short4 v0, as_short4 v1) {
     const as_short8 v = __builtin_shufflevector(v0, v1, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(as_bf16x8, v);
 }
-__device__ __forceinline__ unsigned as_pack_hi(float a, float b) {
-    return (__builtin_bit_cast(unsigned, a) >> 16) | (__builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
-}
-__device__ __forceinline__ unsigned as_pack_lo(float a, float b) {
-    const float ra = a - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFF0000u);
-    const float rb = b - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
-    as_bf16x2 t;
-    t[0] = (__bf16)ra; t[1] = (__bf16)rb;
-    return __builtin_bit_cast(unsigned, t);
-}
-__device__ __forceinline__ unsigned as_split1(float v) {   // hi | lo << 16
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const float r = v - __builtin_bit_cast(float, u & 0xFFFF0000u);
-    as_bf16x2 t;
-    t[0] = (__bf16)r; t[1] = (__bf16)0.f;
-    return (u >> 16) | (__builtin_bit_cast(unsigned, t) << 16);
-}
+__device__ __forceinline__ unsigned as_pack_hi(float a, float b) { return bd_pack_hi(a, b); }   // common.h: the library's split
+__device__ __forceinline__ unsigned as_pack_lo(float a, float b) { return bd_pack_lo(a, b); }
+__device__ __forceinline__ unsigned as_split1(float v) { return bd_split1(v); }   // hi | lo << 16
 __device__ __forceinline__ unsigned as_xor1(unsigned w) {   // the value of lane ^ 1 (DPP quad_perm [1,0,3,2])
     return (unsigned)__builtin_amdgcn_mov_dpp((int)w, 0xB1, 0xF, 0xF, true);
 }

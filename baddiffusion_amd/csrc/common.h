@@ -71,6 +71,32 @@ __device__ __forceinline__ float silu_grad_f(float z) {
     return s * (1.0f + z * (1.0f - s));
 }
 
+// ---- THE split of this library (round 6): x = hi + lo with hi = RNE_bf16(x), lo = RNE_bf16(x - hi).  x - hi is exact in fp32 (at most 16
+// significant bits), so hi + lo reproduces x to 2^-18 |x| and the dropped lo * lo product is <= 2^-18 of the term -- rounds 1 - 5 truncated
+// hi (the upper 16 bits of x), which costs one bit on both (per-convolution error vs fp64 8.8e-6 -> 4e-6, scripts/wino/numerics.py).  Every
+// producer of split planes and every on-the-fly split goes through these three functions: the MFMA engines stay bit-identical to one
+// another because they split identically.  (__bf16)float is v_cvt_pk_bf16_f32 on gfx950: round to nearest even.
+typedef __bf16 bd_bf16x2_t __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned bd_pack_hi(float a, float b) {          // bf16 RNE(a) | bf16 RNE(b) << 16
+    bd_bf16x2_t t;
+    t[0] = (__bf16)a; t[1] = (__bf16)b;
+    return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ unsigned bd_pack_lo(float a, float b) {          // the remainders' planes
+    const unsigned h = bd_pack_hi(a, b);
+    const float ra = a - __builtin_bit_cast(float, h << 16);
+    const float rb = b - __builtin_bit_cast(float, h & 0xFFFF0000u);
+    bd_bf16x2_t t;
+    t[0] = (__bf16)ra; t[1] = (__bf16)rb;
+    return __builtin_bit_cast(unsigned, t);
+}
+__device__ __forceinline__ unsigned bd_split1(float v) {                    // hi | lo << 16 of one value
+    const __bf16 h = (__bf16)v;
+    const unsigned hb = (unsigned)__builtin_bit_cast(unsigned short, h);
+    const __bf16 l = (__bf16)(v - __builtin_bit_cast(float, hb << 16));
+    return hb | ((unsigned)__builtin_bit_cast(unsigned short, l) << 16);
+}
+
 // ---- run-time tuning knobs (bd_tune_set): a generation counter that makes every plan lay its workspace out again -----------------
 extern int g_tune_gen;
 

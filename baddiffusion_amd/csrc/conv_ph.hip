@@ -283,16 +283,8 @@ __global__ __launch_bounds__(256) void ph_tsplit_reduce(const float* __restrict_
 }
 
 // ---- weights of the upsample convolution ----------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned ph_pack_hi(float a, float b) {
-    return (__builtin_bit_cast(unsigned, a) >> 16) | (__builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
-}
-__device__ __forceinline__ unsigned ph_pack_lo(float a, float b) {
-    const float ra = a - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFF0000u);
-    const float rb = b - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
-    ph_bf16x2 t;
-    t[0] = (__bf16)ra; t[1] = (__bf16)rb;
-    return __builtin_bit_cast(unsigned, t);
-}
+__device__ __forceinline__ unsigned ph_pack_hi(float a, float b) { return bd_pack_hi(a, b); }   // common.h: the library's split
+__device__ __forceinline__ unsigned ph_pack_lo(float a, float b) { return bd_pack_lo(a, b); }
 // S(o) as a bit set over ky: o = -1 -> {2}, 0 -> {1,2}, 1 -> {0,1}, 2 -> {0}
 __device__ __host__ __forceinline__ int ph_set(int o) { return o == -1 ? 4 : (o == 0 ? 6 : (o == 1 ? 3 : 1)); }
 

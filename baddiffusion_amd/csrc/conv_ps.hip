@@ -1293,16 +1293,8 @@ __global__ __launch_bounds__(256) void conv_ps_wgrad_reduce(const float* __restr
 }
 
 // ---- producers of split planes -------------------------------------------------------------------------------------
-__device__ __forceinline__ unsigned ps_pack_hi(float a, float b) {
-    return (__builtin_bit_cast(unsigned, a) >> 16) | (__builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
-}
-__device__ __forceinline__ unsigned ps_pack_lo(float a, float b) {
-    const float ra = a - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFF0000u);
-    const float rb = b - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
-    bf16x2 t;
-    t[0] = (__bf16)ra; t[1] = (__bf16)rb;
-    return __builtin_bit_cast(unsigned, t);
-}
+__device__ __forceinline__ unsigned ps_pack_hi(float a, float b) { return bd_pack_hi(a, b); }   // common.h: the library's split
+__device__ __forceinline__ unsigned ps_pack_lo(float a, float b) { return bd_pack_lo(a, b); }
 
 // rows x C fp32 (row stride lds) -> split planes (row stride ldd elements = 4*ldd bytes); C % 32 == 0.  8 values per thread.
 __global__ __launch_bounds__(256) void split_rows_kernel(const float* __restrict__ src, long long lds, long long rows, int C,

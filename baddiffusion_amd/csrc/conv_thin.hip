@@ -261,7 +261,7 @@ __global__ __launch_bounds__(256) void thin_expand_kernel(const float* __restric
 // Round 4: the expand direction on the matrix pipe (BD_MODE_BF16X3 only).  thin_expand_kernel is bound by plain v_fma_f32 issue (3 456 FMAs per pixel
 // for 128 output channels: 92 us for a 27 us stream of bytes at 256 x 256).  As a GEMM the layer is [pixels x 27] x [27 x C]: K = 27 pads to 32 = two
 // v_mfma_f32_32x32x16_bf16 steps, and the im2col operand needs no LDS: a lane of the A fragment IS one pixel and one octet of K, so it loads its
-// own 16 tap values (the 3-channel tensor is tiny: every read hits L1 / L2), splits them into bf16 hi | lo in registers (the same truncate / RNE
+// own 16 tap values (the 3-channel tensor is tiny: every read hits L1 / L2), splits them into bf16 hi | lo in registers (the same RNE / RNE
 // split as everywhere else) and multiplies against weight fragments built once per wave.  24 MFMAs (3 passes x 4 channel tiles x 2 K steps) + 16
 // loads + 64 coalesced 128-byte stores per 32 pixels and 128 channels: the kernel writes at the rate of its output.
 typedef __bf16 thin_bf16x8 __attribute__((ext_vector_type(8)));
@@ -269,10 +269,8 @@ typedef float thin_f32x16 __attribute__((ext_vector_type(16)));
 __device__ __forceinline__ void thin_split8(const float (&v)[8], thin_bf16x8& hi, thin_bf16x8& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const unsigned u = __builtin_bit_cast(unsigned, v[j]) & 0xFFFF0000u;
-        const float h = __builtin_bit_cast(float, u);
-        hi[j] = __builtin_bit_cast(__bf16, (unsigned short)(u >> 16));
-        lo[j] = (__bf16)(v[j] - h);
+        hi[j] = (__bf16)v[j];                       // common.h: hi = RNE_bf16(x), lo = RNE_bf16(x - hi)
+        lo[j] = (__bf16)(v[j] - (float)hi[j]);
     }
 }
 

@@ -91,14 +91,8 @@ __device__ __forceinline__ void sp_tie(SpFrag<true>& f) {
                  "+v"(f.v1[1][0]), "+v"(f.v1[1][1]));
 }
 
-// y -> (bf16 hi by truncation, bf16 lo = RNE of the remainder): the split of bd_split_rows, packed hi | lo << 16
-__device__ __forceinline__ unsigned sp_split1(float v) {
-    const unsigned u = __builtin_bit_cast(unsigned, v);
-    const float r = v - __builtin_bit_cast(float, u & 0xFFFF0000u);
-    sp_bf16x2 t;
-    t[0] = (__bf16)r; t[1] = (__bf16)0.f;
-    return (u >> 16) | (__builtin_bit_cast(unsigned, t) << 16);
-}
+// y -> (bf16 hi = RNE, bf16 lo = RNE of the remainder): the split of bd_split_rows (common.h), packed hi | lo << 16
+__device__ __forceinline__ unsigned sp_split1(float v) { return bd_split1(v); }
 
 template <bool AKM, bool BKM>
 __global__ __launch_bounds__(SP_NT, 2) void gemm_sp_kernel(SpParams p) {

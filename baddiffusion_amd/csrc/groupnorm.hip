@@ -79,18 +79,10 @@ __device__ __forceinline__ float silu_grad_fast(float z) {
 }
 
 // ---- split-plane output (bd_hip.h "split planes"): 4 consecutive channels c..c+3 of one row -> 8 B of bf16 hi and 8 B of
-// bf16 lo (hi = truncation, lo = RNE of the remainder: bit-identical to the on-the-fly split of the bf16x3 engine)
+// bf16 lo (common.h: hi = RNE, lo = RNE of the remainder: bit-identical to the on-the-fly split of the bf16x3 engine)
 typedef __bf16 gn_bf16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ unsigned gn_pack_hi(float a, float b) {
-    return (__builtin_bit_cast(unsigned, a) >> 16) | (__builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
-}
-__device__ __forceinline__ unsigned gn_pack_lo(float a, float b) {
-    const float ra = a - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFF0000u);
-    const float rb = b - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
-    gn_bf16x2 t;
-    t[0] = (__bf16)ra; t[1] = (__bf16)rb;
-    return __builtin_bit_cast(unsigned, t);
-}
+__device__ __forceinline__ unsigned gn_pack_hi(float a, float b) { return bd_pack_hi(a, b); }
+__device__ __forceinline__ unsigned gn_pack_lo(float a, float b) { return bd_pack_lo(a, b); }
 // row = start of the row's planes (uint16 units), c = channel of o[0] (c % 4 == 0)
 __device__ __forceinline__ void gn_store_split4(unsigned short* row, int c, const float (&o)[4]) {
     unsigned short* q = row + (c >> 5) * 64 + (c & 31);

@@ -31,14 +31,12 @@ typedef float floatx16 __attribute__((ext_vector_type(16)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
 
-// split 8 fp32 values into hi + lo bf16 planes: hi = the upper 16 bits of x (truncation, exact), lo = RNE(x - hi);
-// x = hi + lo + O(2^-17 |x|).  ~2.6 VALU per element (v_and / v_perm / v_sub / v_cvt_pk_bf16_f32).
+// split 8 fp32 values into hi + lo bf16 planes (common.h: hi = RNE_bf16(x), lo = RNE_bf16(x - hi)); x = hi + lo + O(2^-18 |x|).
 __device__ __forceinline__ void split8(const float (&x)[8], bf16x8& hi, bf16x8& lo) {
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
-        const unsigned u = __builtin_bit_cast(unsigned, x[j]);
-        hi[j] = __builtin_bit_cast(__bf16, (unsigned short)(u >> 16));
-        lo[j] = (__bf16)(x[j] - __builtin_bit_cast(float, u & 0xFFFF0000u));
+        hi[j] = (__bf16)x[j];
+        lo[j] = (__bf16)(x[j] - (float)hi[j]);
     }
 }
 
@@ -140,16 +138,8 @@ struct RCMap {
 
 constexpr int LDH = BK + 8;  // bf16 row stride of the split-bf16 LDS planes: 80 B (conflict-free b128 reads, b64 writes)
 
-__device__ __forceinline__ unsigned pack_hi(float a, float b) {   // upper halves = truncated bf16
-    return (__builtin_bit_cast(unsigned, a) >> 16) | (__builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
-}
-__device__ __forceinline__ unsigned pack_lo(float a, float b) {   // RNE(x - trunc_bf16(x))
-    const float ra = a - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, a) & 0xFFFF0000u);
-    const float rb = b - __builtin_bit_cast(float, __builtin_bit_cast(unsigned, b) & 0xFFFF0000u);
-    bf16x2 t;
-    t[0] = (__bf16)ra; t[1] = (__bf16)rb;
-    return __builtin_bit_cast(unsigned, t);
-}
+__device__ __forceinline__ unsigned pack_hi(float a, float b) { return bd_pack_hi(a, b); }   // common.h: RNE hi planes
+__device__ __forceinline__ unsigned pack_lo(float a, float b) { return bd_pack_lo(a, b); }
 
 template <int R, int NT>
 struct RCStore {

@@ -68,7 +68,7 @@ def unique_id():
     """ncclGetUniqueId as 128 bytes (rank 0 calls it, the launcher's group broadcasts it)"""
     uid = _UniqueId()
     _check(_load().ncclGetUniqueId(C.byref(uid)), "ncclGetUniqueId")
-    return bytes(uid.internal)
+    return C.string_at(C.byref(uid), 128)      # NOT bytes(uid.internal): a c_char array reads as a C string, cut at the first NUL byte
 
 
 class RcclComm:
@@ -89,7 +89,9 @@ class RcclComm:
             if self.world > 1:
                 dist.broadcast_object_list(box, src=0)
             uid = box[0]
-        raw, uid = uid, _UniqueId()
+        raw, uid = bytes(uid), _UniqueId()
+        if len(raw) != 128:
+            raise RuntimeError(f"ncclUniqueId must be 128 bytes, got {len(raw)}")
         C.memmove(C.byref(uid), raw, 128)
         self._comm = C.c_void_p()
         with torch.cuda.device(self.device):

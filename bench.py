@@ -669,7 +669,7 @@ def headline_line(out, detail_file=None):
     workload, and for the riders (`sampling.*`, `celeba`, `fid_features`) value / ms_per_step / roofline.frac / roofline.traffic /
     cpu_baseline.value only.  Everything else -- per-class kernel tables, sweeps, per-bucket times, the notes saying how each figure was
     taken -- is the DETAIL object `out`, written to `detail_file` (gpurun_out/bench_detail.json) and copied under profiles/ per round."""
-    h = {k: _rnd(out[k], 6) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+    h = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                                       "vs_baseline", "dtype", "data") if k in out}
     h["config"] = dict(out["config"])
     for k in ("final_loss", "ms_per_step_median", "step_tflops", "step_frac_of_hbm_roofline", "images_finite", "final_backdoor_mse"):

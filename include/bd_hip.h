@@ -256,8 +256,8 @@ typedef struct {
                                                 wgrad, A = dY^T); needs DENSE row-contiguous A, batch 1 */
 } bd_igemm_desc;
 size_t bd_igemm_workspace_bytes(const bd_igemm_desc* d);
-/* Split an fp32 buffer into bf16 hi/lo exactly as the BF16X3 kernels do on the fly: hi = bf16 truncation of x,
- * lo = bf16 RNE of (x - hi).  Blocked layout, 2n uint16: for element e, hi at out[(e/32)*64 + e%32] and lo 32 entries
+/* Split an fp32 buffer into bf16 hi/lo exactly as the BF16X3 kernels do on the fly: hi = bf16 RNE of x (round 6; rounds 1 - 5
+ * truncated: one bit less), lo = bf16 RNE of (x - hi): x = hi + lo to 2^-18 |x|.  Blocked layout, 2n uint16: for element e, hi at out[(e/32)*64 + e%32] and lo 32 entries
  * further -- one 32-element K chunk of a row is one 128-byte line (64 B hi | 64 B lo), as wide as its fp32 source.
  * n % 32 == 0, 16-byte aligned pointers.  Run once per forward over the flat weight buffer (bd_unet_forward).   */
 int bd_split_bf16(const float* src, int64_t n, uint16_t* out, bd_stream_t stream);
@@ -310,7 +310,7 @@ size_t bd_conv3x3_workspace_bytes(int B, int Ho, int Wo, int Hs, int Ws, int Cin
 /* ------------------------------------------------------------------------------------------------
  * Pre-split operands ("split planes"): an activation / gradient / weight matrix [rows, C] whose every
  * 32-channel block of a row is one 128-byte line, 64 B of bf16 hi then 64 B of bf16 lo (hi = bf16
- * truncation, lo = bf16 RNE of the remainder: exactly what BD_MODE_BF16X3 computes on the fly), i.e. the
+ * RNE, lo = bf16 RNE of the remainder: exactly what BD_MODE_BF16X3 computes on the fly), i.e. the
  * bd_split_bf16 layout with a leading dimension: element (r, c) lives at uint16 index
  *     2*r*ld + (c/32)*64 + plane*32 + c%32          (ld % 32 == 0, 128-byte aligned base).
  * Same 4 bytes per element as fp32.  Producers: bd_split_rows (from fp32), bd_gn_fwd / bd_gn_bwd

@@ -356,11 +356,10 @@ def test_split_bf16_planes(ops):
     x = R(1, 4096) * torch.logspace(-6, 6, 4096)
     sp = ops.split_bf16(dev(x))
     hi, lo = sp[:, 0].reshape(-1), sp[:, 1].reshape(-1)     # blocked layout [block, hi|lo, 32]
-    bits = x.view(torch.int32)
-    assert torch.equal(hi.cpu().int() & 0xFFFF, (bits >> 16) & 0xFFFF)            # hi = truncated bf16
     hif = ((hi.cpu().int() & 0xFFFF) << 16).view(torch.float32); lof = ((lo.cpu().int() & 0xFFFF) << 16).view(torch.float32)
-    assert float(((hif.double() + lof.double() - x.double()).abs() / x.double().abs()).max()) < 2.0 ** -16
-    assert torch.equal(lof, (x - hif).to(torch.bfloat16).float())                 # lo = RNE bf16 of the remainder
+    assert torch.equal(hif, x.to(torch.bfloat16).float())                         # hi = RNE bf16 (round 6; truncation before: one bit less)
+    assert float(((hif.double() + lof.double() - x.double()).abs() / x.double().abs()).max()) < 2.0 ** -17
+    assert torch.equal(lof, (x - hif).to(torch.bfloat16).float())                 # lo = RNE bf16 of the (exact) remainder
 
 
 @pytest.mark.parametrize("B,H,Cin,Cout,stride,pad,ups,asym", [(2, 16, 128, 256, 1, 1, 0, False), (2, 16, 256, 128, 2, 0, 0, True),

@@ -70,7 +70,7 @@ def test_batch_sampling_chunks_and_png(gpu, tmp_path):
     import os
     assert sorted(os.listdir(tmp_path / "o"), key=lambda n: int(n[:-4])) == [f"{i}.png" for i in range(5)]
     png = np.asarray(Image.open(tmp_path / "o" / "3.png"))
-    assert np.array_equal(png, (b[3] * 255).round().astype("uint8"))
+    assert np.array_equal(png, (a[3] * 255).round().astype("uint8"))      # the same chunking as the save call: exact (b differs by K-split reassociation noise, a x.5 pixel may flip)
     # rank-sharded sampling writes disjoint index ranges that together equal the unsharded run
     for r in range(2):
         batch_sampling_save(5, pipe_call, str(tmp_path / "s"), init=init, max_batch_n=2, rank=r, world=2)

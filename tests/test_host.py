@@ -359,6 +359,10 @@ def test_rccl_binding_loads_and_exports_the_calls_used():
     import ctypes
     assert ctypes.sizeof(rccl._UniqueId) == 128
     assert b"" != lib.ncclGetErrorString(0)
+    # the 128 bytes that travel to the other ranks are the WHOLE id: a c_char array read as a C string stops at the first NUL byte (round 6: the
+    # pre-round-6 broadcast did exactly that, and would have failed the first multi-rank ncclCommInitRank)
+    u = rccl.unique_id()
+    assert isinstance(u, bytes) and len(u) == 128 and 0 < u.find(b"\0") < 127
 
 
 def test_bench_headline_is_bounded_and_parses():
