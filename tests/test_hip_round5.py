@@ -76,11 +76,14 @@ def test_train_engine_replays_reference_trajectory(gpu, golden):
         np.testing.assert_allclose(lrs, g["lr"], rtol=1e-9, atol=1e-15)                    # optimization.py:134-138, the LR each step used
         rl = np.abs(losses - g["loss"]) / g["loss"]
         rn = np.abs(norms - g["grad_norm"]) / g["grad_norm"]
-        assert rl.max() <= 1e-3, (mode, rl.argmax(), rl.max())                             # every one of the 32 steps, north_star's bound
+        # every one of the 32 steps; north_star's bound is 1e-3.  Round 6 (RNE hi planes, csrc/common.h): split-bf16 measures 1.6e-4 (6.0e-4 with the
+        # truncated hi planes of rounds 1 - 5), exact mode 4.2e-5 -> both held to 3e-4
+        assert rl.max() <= 3e-4, (mode, rl.argmax(), rl.max())
         # the pre-clip norm is the most sensitive observable: per step the two sides agree to ~1e-5, and the difference between two trajectories
-        # grows as they proceed (measured, split-bf16 mode: <= 2e-5 over the first eight steps, 4.5e-3 at step 26) -- held to 1e-3 while the
-        # trajectories are still one (the warm-up steps) and to 1e-2 over all 32
-        assert rn[: C.TRAJ_WARMUP].max() <= 1e-3 and rn.max() <= 1e-2, (mode, rn.argmax(), rn.max())
+        # grows as they proceed (measured, split-bf16 mode: <= 2e-5 over the first eight steps; over all 32: 1.26e-3 with RNE hi planes, round 6 --
+        # 4.5e-3 at step 26 with the truncated planes before) -- held to 1e-3 while the trajectories are still one (the warm-up steps) and to
+        # 3e-3 over all 32
+        assert rn[: C.TRAJ_WARMUP].max() <= 1e-3 and rn.max() <= 3e-3, (mode, rn.argmax(), rn.max())
         worst = worst_rel_move = 0.0
         for i, k in enumerate(names):
             if k.endswith("key.bias"):        # gradient mathematically zero (softmax shift invariance): Adam amplifies rounding noise to +-lr steps
@@ -92,9 +95,9 @@ def test_train_engine_replays_reference_trajectory(gpu, golden):
             assert abs(float(sd[k].double().norm()) - g["pnorm_final"][i]) <= 1e-4 * g["pnorm_final"][i] + 1e-6, (mode, k)
         # The 32 steps displace an element by ~7.7e-4 (median of pmove_final / sqrt(numel)); Adam's m / sqrt(v) is a sign-like function of small
         # gradients, so a 1e-3-relative gradient difference can move single elements by a fraction of an lr per step.  Measured (profiles/
-        # r05_trajectory_drift.json): exact mode 2.4e-7 (what the CPU oracle reaches too), split-bf16 mode 2.5e-6; held to 1e-5 = 1.3 % of the
-        # typical displacement.
-        assert worst <= 1e-5, (mode, worst, worst_rel_move)
+        # r06_trajectory_drift.json): exact mode 2.4e-7 (what the CPU oracle reaches too), split-bf16 mode 7.7e-7 (2.5e-6 before round 6); held
+        # to 3e-6 = 0.4 % of the typical displacement.
+        assert worst <= 3e-6, (mode, worst, worst_rel_move)
         x, R0, t, eps = C.train_inputs(cfg, 2)
         xn, _ = ops.qsample(x.to(gpu), R0.to(gpu), eps.to(gpu), t.to(gpu), *DDPMScheduler().device_tables(gpu))
         with torch.no_grad():
@@ -111,8 +114,8 @@ def test_train_engine_replays_reference_trajectory(gpu, golden):
             imgs[clip] = (float(err.max()), float(err.mean()), float((err > 1e-3).mean()))
             # five DDPM steps over 1000 training timesteps divide by sqrt(alpha_bar_t) ~ 0.05 .. 0.3 at the first steps: differences in the
             # trained weights (<= 5e-5 above) reach the images amplified; images are in [0, 1]
-            # measured: exact mode max 2.7e-4, split-bf16 mode max 4.7e-3 / mean 2.4e-5 (without the clip)
-            assert err.mean() <= 5e-4 and err.max() <= 1e-2, (mode, clip, imgs[clip])
+            # measured: exact mode max 2.7e-4, split-bf16 mode max 1.4e-3 / mean 6.7e-6 without the clip (4.7e-3 / 2.4e-5 before round 6)
+            assert err.mean() <= 1e-4 and err.max() <= 3e-3, (mode, clip, imgs[clip])
         final[mode] = (losses, sd, pred, imgs)
         report[mode] = {"max_rel_loss_err": float(rl.max()), "max_rel_clipnorm_err": float(rn.max()), "worst_weight_abs_err_first8": worst,
                         "worst_weight_err_over_typical_displacement": worst_rel_move,
@@ -124,9 +127,9 @@ def test_train_engine_replays_reference_trajectory(gpu, golden):
     wd = max(float((sf[k] - sb[k]).abs().max()) for k in sf if not k.endswith("key.bias"))
     report["bf16x3_vs_f32"] = {"max_rel_loss_diff": float((np.abs(lf - lb) / lf).max()), "max_weight_abs_diff": wd,
                                "pred_final_max_abs_diff": float(np.abs(pf - pb).max())}
-    assert report["bf16x3_vs_f32"]["max_rel_loss_diff"] <= 1e-3 and wd <= 2.5 * C.TRAJ_LR
+    assert report["bf16x3_vs_f32"]["max_rel_loss_diff"] <= 4e-4 and wd <= 1.0 * C.TRAJ_LR
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-    with open(os.path.join(ROOT, "gpurun_out", "r05_trajectory_drift.json"), "w") as f:
+    with open(os.path.join(ROOT, "gpurun_out", "r06_trajectory_drift.json"), "w") as f:
         json.dump(report, f, indent=1)
     print("G14 drift report:", json.dumps(report))
 
