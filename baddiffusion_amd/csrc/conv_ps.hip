@@ -531,11 +531,15 @@ struct PsSmallParams {
     int ksplit, cps;       // chunks per split
 };
 
-template <int EPI>
-__global__ __launch_bounds__(512, 4) void conv_ps128_kernel(PsSmallParams pp) {
+// STAGES = 2: 64 KB, two workgroups per CU (the pair de-phases); the chunk c+1 is fetched while chunk c computes.
+// STAGES = 4 (round 6): 128 KB, one workgroup per CU, THREE chunks in flight ahead of the one being computed -- for the short K slices of
+// the 4 x 4 level (4 - 9 chunks per workgroup), where a workgroup's life is a handful of DMA round trips and the two-stage form exposes one
+// L2 -> LDS latency per chunk.
+template <int EPI, int STAGES = 2>
+__global__ __launch_bounds__(512, STAGES == 2 ? 4 : 2) void conv_ps128_kernel(PsSmallParams pp) {
     const PsParams& p = pp.q;
     constexpr int A_BYTES = 128 * 128, STAGE = 2 * A_BYTES;
-    __shared__ __attribute__((aligned(128))) char smem[2 * STAGE];
+    __shared__ __attribute__((aligned(128))) char smem[STAGES * STAGE];
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -631,12 +635,29 @@ __global__ __launch_bounds__(512, 4) void conv_ps128_kernel(PsSmallParams pp) {
         }
     };
     const int n = c_end - c_begin;
-    if (n > 0) issue(smem);
-    for (int c = 0; c < n; ++c) {
-        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_s_barrier();
-        if (c + 1 < n) issue(smem + ((c + 1) & 1) * STAGE);
-        compute(smem + (c & 1) * STAGE);
+    if constexpr (STAGES == 2) {
+        if (n > 0) issue(smem);
+        for (int c = 0; c < n; ++c) {
+            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c + 1 < n) issue(smem + ((c + 1) & 1) * STAGE);
+            compute(smem + (c & 1) * STAGE);
+        }
+    } else {
+        // ring of STAGES: chunks c+1 .. c+STAGES-1 are in flight while chunk c computes (4 DMAs per wave and chunk: counted waits).  The stage
+        // refilled behind the barrier of chunk c is the one chunk c-1 was read from: every wave has passed that barrier with its reads returned.
+#pragma unroll
+        for (int k = 0; k < STAGES - 1; ++k)
+            if (k < n) issue(smem + k * STAGE);
+        for (int c = 0; c < n; ++c) {
+            const int later = (n < c + STAGES - 1 ? n : c + STAGES - 1) - (c + 1);      // chunks issued after chunk c (wave-uniform)
+            if (later >= 2) asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+            else if (later == 1) asm volatile("s_waitcnt vmcnt(4) lgkmcnt(0)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            if (c + STAGES - 1 < n) issue(smem + ((c + STAGES - 1) % STAGES) * STAGE);
+            compute(smem + (c % STAGES) * STAGE);
+        }
     }
     const int mw = m0 + wm * 32, nw = n0 + wn * 64;
     const bool full = mw + 32 <= p.M;     // wave-uniform
@@ -1539,6 +1560,11 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
             pp.partial = reinterpret_cast<float*>(d.workspace);
         }
         const dim3 grid((unsigned)(p.tiles_m * p.tiles_n * pp.ksplit)), block(512);
+        // round 6: short K slices (the 4 x 4 level) take the four-stage form (three chunks in flight, one workgroup per CU)
+        static const int deep_maxcps = getenv("BD_PS128_DEEP_MAXCPS") ? atoi(getenv("BD_PS128_DEEP_MAXCPS")) : 9;       // (A/B knob: 0 = off)
+        if (pp.ksplit > 1 && pp.cps <= deep_maxcps) {
+            hipLaunchKernelGGL((conv_ps128_kernel<0, 4>), grid, block, 0, st, pp);
+        } else
         switch (pp.ksplit > 1 ? 0 : epi) {
             case 0: hipLaunchKernelGGL(conv_ps128_kernel<0>, grid, block, 0, st, pp); break;
             case 1: hipLaunchKernelGGL(conv_ps128_kernel<1>, grid, block, 0, st, pp); break;
