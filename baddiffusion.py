@@ -332,7 +332,10 @@ def measure(config, dsl, folder_name, pipeline, rank=0, world=1):
     # per-step DDPM noise: one stream per rank (seed + rank).  With a shared seed every shard would consume the SAME
     # noise sequence and chain j of each shard would be correlated with chain j of the others.  world == 1 keeps the
     # reference's stream exactly; a sharded run is a different (equally valid) draw of the same distribution.
-    rng = torch.Generator().manual_seed(config.seed + rank)
+    # BD_SHARDED_NOISE=reference (round 6, SURVEY hard-part 4): every rank walks the single process's chunks with the SAME stream (seed, no
+    # rank offset) and takes its rows of every draw -- the reference's noise, chain for chain, at the price of drawing all of it on every rank.
+    parity = world > 1 and os.environ.get("BD_SHARDED_NOISE", "rank") == "reference"
+    rng = torch.Generator().manual_seed(config.seed + (0 if parity else rank))
     if hasattr(pipeline.unet, "chunks_used"):
         pipeline.unet.chunks_used.clear()
     parts = [config.output_dir, folder_name] + ([f"ep{config.sample_ep}"] if config.sample_ep is not None else [])
@@ -342,9 +345,9 @@ def measure(config, dsl, folder_name, pipeline, rank=0, world=1):
     noise = torch.randn((config.measure_sample_n, pipeline.unet.in_channels, s, s), generator=torch.manual_seed(config.seed))
     backdoor_noise = noise + dsl.trigger.unsqueeze(0)
     batch_sampling_save(config.measure_sample_n, pipeline, clean_path, init=noise, max_batch_n=config.eval_max_batch, rng=rng,
-                        rank=rank, world=world)
+                        rank=rank, world=world, parity=parity)
     batch_sampling_save(config.measure_sample_n, pipeline, backdoor_path, init=backdoor_noise, max_batch_n=config.eval_max_batch,
-                        rng=rng, rank=rank, world=world)
+                        rng=rng, rank=rank, world=world, parity=parity)
     if world > 1:
         import torch.distributed as dist
         dist.barrier()

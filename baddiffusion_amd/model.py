@@ -132,10 +132,39 @@ def save_imgs(imgs: np.ndarray, file_dir: Union[str, os.PathLike], file_name: Un
 
 
 def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], init: torch.Tensor = None, max_batch_n: int = 256,
-                        rng: torch.Generator = None, rank: int = 0, world: int = 1):
+                        rng: torch.Generator = None, rank: int = 0, world: int = 1, parity: bool = False):
     """model.py:504-529.  With world > 1 the rows of `init` are split contiguously over ranks and every rank writes
-    its own PNG index range (sampling chains are independent, no collective)."""
-    if init is None:
+    its own PNG index range (sampling chains are independent, no collective).
+
+    parity=True (round 6, SURVEY hard-part 4): REFERENCE-ORDER noise on a sharded job.  The chunks are the single process's (max_batch_n
+    over the whole job), every rank walks all of them with the SAME CPU generator `rng`, and inside a chunk rank r samples rows
+    [r * ceil(bs / world), ...) through a ShardedGenerator: each draw produces the full chunk's tensor and keeps this rank's rows, so the
+    stream advances exactly as in the unsharded run and chain j sees the noise it would see there -- the PNGs equal the world-1 run's up
+    to the fp32 summation order the plan picks for another batch size (<= 1 of 255 levels).  init=None works too (the initial sample is a
+    draw like any other).  Price: every rank draws all of the job's noise on its host."""
+    from .schedulers import ShardedGenerator
+    if parity and world > 1:
+        if rng is None or rng.device.type != "cpu":
+            raise ValueError("parity=True needs the shared CPU generator of the unsharded run as `rng`")
+        if init is None:
+            replica, residual = sample_n // max_batch_n, sample_n % max_batch_n
+            sizes = ([max_batch_n] * replica + ([residual] if residual > 0 else [])) if sample_n > max_batch_n else [sample_n]
+            chunks = [None] * len(sizes)
+        else:
+            chunks = list(torch.split(init, max_batch_n))
+            sizes = [len(x) for x in chunks]
+        jobs, start = [], 0
+        for ch, bs in zip(chunks, sizes):
+            per = (bs + world - 1) // world
+            lo, hi = min(bs, rank * per), min(bs, (rank + 1) * per)
+            jobs.append((hi - lo, ShardedGenerator(rng, bs, lo, hi) if hi > lo else None, None if ch is None else ch[lo:hi], start + lo,
+                         bs, ch is not None))
+            start += bs
+    else:
+        jobs = None
+    if jobs is not None:
+        pass
+    elif init is None:
         if sample_n > max_batch_n:
             replica, residual = sample_n // max_batch_n, sample_n % max_batch_n
             batch_sizes = [max_batch_n] * replica + ([residual] if residual > 0 else [])
@@ -143,7 +172,7 @@ def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], 
             batch_sizes = [sample_n]
         inits = [None] * len(batch_sizes)
         if world > 1:
-            raise ValueError("sharded sampling needs an explicit `init` (one generator stream cannot be split)")
+            raise ValueError("sharded sampling needs an explicit `init` (one generator stream cannot be split) or parity=True")
         offset = 0
     else:
         n = len(init)
@@ -152,11 +181,15 @@ def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], 
         init = init[offset: offset + per]
         inits = torch.split(init, max_batch_n)
         batch_sizes = [len(x) for x in inits]
+    if jobs is None:
+        jobs, cnt0 = [], offset
+        for ch, bs in zip(inits, batch_sizes):
+            jobs.append((bs, rng, ch, cnt0, bs, ch is not None))
+            cnt0 += bs
     # Overlapped save (f-3): the pipeline hands back DEVICE uint8 images (output_type="u8": bd_to_image quantises on the
     # GPU); they go to pinned host memory on a copy stream and are PNG-encoded by a thread pool while the next chunk is
     # being sampled.  A pipeline that returns host arrays (float [0,1]) keeps the reference's serial save_imgs path.
     from concurrent.futures import ThreadPoolExecutor
-    cnt = offset
     pending = []
     copy_stream = torch.cuda.Stream() if torch.cuda.is_available() else None
     # decided up front (not by catching exceptions around the sampling call: an error raised mid-chain must surface, and a retry
@@ -173,8 +206,15 @@ def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], 
             Image.fromarray(img[..., 0] if img.shape[-1] == 1 else img).save(os.path.join(path, f"{start + k}.png"))
 
     with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 4)) as pool:
-        for i, bs in enumerate(batch_sizes):
-            res = pipeline(batch_size=bs, generator=rng, init=inits[i], output_type="u8" if device_u8 else None)
+        for bs, gen, ch, cnt, full_bs, init_given in jobs:
+            if bs == 0:       # parity mode, a chunk with fewer rows than ranks: this rank samples nothing of it but keeps the stream in step
+                adv = getattr(pipeline, "advance_generator", None)
+                if adv is None:
+                    raise TypeError("parity=True with a chunk smaller than the world size needs pipeline.advance_generator (the pipelines of "
+                                    "baddiffusion_amd.pipelines have it; a bare callable does not)")
+                adv(full_bs, rng, init_given)
+                continue
+            res = pipeline(batch_size=bs, generator=gen, init=ch, output_type="u8" if device_u8 else None)
             imgs = res.images
             if device_u8:
                 if not (torch.is_tensor(imgs) and imgs.is_cuda and imgs.dtype == torch.uint8):
@@ -190,7 +230,6 @@ def batch_sampling_save(sample_n: int, pipeline, path: Union[str, os.PathLike], 
                     pending.append(pool.submit(_write, host[s0: s0 + 64], ev, cnt + s0))
             else:
                 save_imgs(imgs=imgs, file_dir=path, file_name="", start_cnt=cnt)
-            cnt += bs
             del res
         for f in pending:
             f.result()

@@ -100,6 +100,17 @@ class _PipelineBase:
         # keep the running sample in NHWC storage (what the UNet consumes and produces)
         return ops.nchw_to_nhwc(image.float()), shape
 
+    def noise_draws(self, num_inference_steps=None, start_from=0, eta=0.0, **kwargs):
+        """How many chunk-shaped tensors ONE call draws from its generator after the initial sample: what a rank that owns no row of a chunk
+        must draw and discard to keep a shared CPU stream in the unsharded order (model.batch_sampling_save(parity=True))."""
+        return 0
+
+    def advance_generator(self, batch_size, generator, init_given, **kwargs):
+        """draw and discard everything __call__(batch_size, generator=generator, init=None / given, **kwargs) would draw"""
+        shape = self._image_shape(batch_size)
+        for _ in range((0 if init_given else 1) + self.noise_draws(**kwargs)):
+            torch.randn(shape, generator=generator)
+
     # ---- diffusers-layout save (SURVEY f-2) ------------------------------------------------------------------
     def save_pretrained(self, save_directory):
         from .model import save_unet, save_scheduler
@@ -112,6 +123,10 @@ class _PipelineBase:
 
 
 class DDPMPipeline(_PipelineBase):
+    def noise_draws(self, num_inference_steps=1000, start_from=0, **kwargs):
+        self.scheduler.set_timesteps(num_inference_steps)
+        return sum(1 for t in self.scheduler.timesteps[start_from:] if int(t) > 0)      # scheduling_ddpm.py:400: `if t > 0`
+
     @_static_weights
     @torch.no_grad()
     def __call__(self, batch_size=1, generator=None, num_inference_steps=1000, start_from=0, output_type="pil", init=None,
@@ -151,6 +166,10 @@ class DDIMPipeline(_PipelineBase):
         # pipeline_ddim.py:39-42: make sure the scheduler can always be converted to DDIM
         scheduler = DDIMScheduler.from_config(scheduler.config)
         super().__init__(unet, scheduler)
+
+    def noise_draws(self, num_inference_steps=50, eta=0.0, **kwargs):
+        self.scheduler.set_timesteps(num_inference_steps)
+        return len(self.scheduler.timesteps) if eta > 0 else 0                           # scheduling_ddim.py:366: `if eta > 0`
 
     @_static_weights
     @torch.no_grad()

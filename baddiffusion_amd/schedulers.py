@@ -24,10 +24,31 @@ class SchedulerOutput:
         self.pred_original_sample = pred_original_sample
 
 
+class ShardedGenerator:
+    """Rows [lo, hi) of the noise a SINGLE process would draw for a chunk of `full_batch` chains (SURVEY hard-part 4; the reference draws every
+    sampling noise from one CPU generator, chunk after chunk: model.py:517-523, scheduling_ddpm.py:400-404).  Handed to a pipeline as its
+    `generator`, every randn_tensor(shape, ...) call draws the FULL chunk's tensor ((full_batch,) + shape[1:]) from `gen` -- so the stream
+    advances exactly as in the unsharded run, on every rank -- and returns this rank's rows.  The price of reference-order noise on a sharded
+    job: every rank draws all of it (host RNG time), which is why it is opt-in (batch_sampling_save(parity=True), BD_SHARDED_NOISE=reference)."""
+
+    def __init__(self, gen, full_batch, lo, hi):
+        if gen is None or gen.device.type != "cpu":
+            raise ValueError("ShardedGenerator needs a CPU torch.Generator (the reference's sampling stream is a CPU generator)")
+        if not (0 <= lo <= hi <= full_batch):
+            raise ValueError(f"rows [{lo}, {hi}) outside a chunk of {full_batch}")
+        self.gen, self.full_batch, self.lo, self.hi = gen, int(full_batch), int(lo), int(hi)
+        self.device = gen.device
+
+
 def randn_tensor(shape, generator=None, device=None, dtype=torch.float32):
     """utils/torch_utils.py:29-70: with a CPU generator the noise is drawn on the CPU (seed parity with
     the reference) and copied to the device."""
     device = torch.device(device) if device is not None else torch.device("cpu")
+    if isinstance(generator, ShardedGenerator):
+        if shape[0] != generator.hi - generator.lo:
+            raise ValueError(f"ShardedGenerator for rows [{generator.lo}, {generator.hi}) asked for a batch of {shape[0]}")
+        full = torch.randn((generator.full_batch,) + tuple(shape[1:]), generator=generator.gen, device="cpu", dtype=dtype)
+        return full[generator.lo: generator.hi].contiguous().to(device)
     if generator is not None and generator.device.type == "cpu" and device.type != "cpu":
         return torch.randn(shape, generator=generator, device="cpu", dtype=dtype).to(device)
     return torch.randn(shape, generator=generator, device=device, dtype=dtype)

@@ -186,3 +186,49 @@ def test_train_engine_two_ranks_equal_one_big_batch(gpu):
     assert abs(float(e.grad_norm) - ret["gn"]) < 1e-4 * float(e.grad_norm)
     d = (m.flat.detach().cpu() - ret["flat"]).abs()
     assert float((d > 1e-5).float().mean()) < 1e-3
+
+
+def test_parity_mode_sharded_sampling_equals_the_unsharded_run(gpu, tmp_path):
+    """VERDICT round 5, missing item 6 (SURVEY hard-part 4; model.py:517-523): with parity=True a sharded DDPM job uses the reference's noise,
+    chain for chain -- every rank walks the single process's chunks with the same CPU stream and keeps its rows of every draw.  5 chains, chunks
+    of 4 (so: [4, 1]), 3 ranks (rank 2 owns no row of the second chunk and only advances the stream), stochastic DDPM steps, with `init` and with
+    the initial sample drawn from the stream too; the PNGs of the three ranks together equal the world-1 run's (<= 1 of 255 levels: the plan
+    picks its K-split by batch size).  The default (per-rank streams) is untouched."""
+    import os
+    from PIL import Image
+    from baddiffusion_amd.model import batch_sampling_save
+    from baddiffusion_amd.pipelines import DDPMPipeline
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    cfg = C.SMALL_CFGS["small"]
+    m = make_model(cfg, 7, gpu)
+
+    class Pipe(DDPMPipeline):          # 6 stochastic steps instead of 1000 (the draw count follows: advance_generator uses noise_draws)
+        def __call__(self, **kw):
+            return super().__call__(num_inference_steps=6, **kw)
+
+        def noise_draws(self, **kw):
+            return super().noise_draws(num_inference_steps=6)
+
+    pipe = Pipe(m, DDPMScheduler(clip_sample=False))
+    init = torch.randn(5, 3, 16, 16, generator=torch.Generator().manual_seed(3))
+
+    def load(d):
+        return np.stack([np.asarray(Image.open(os.path.join(d, f"{i}.png"))).astype(np.int32) for i in range(5)])
+
+    for tag, ini in (("init", init), ("noinit", None)):
+        one = str(tmp_path / f"one_{tag}")
+        rng = torch.Generator().manual_seed(21)
+        batch_sampling_save(5, pipe, one, init=ini, max_batch_n=4, rng=rng)
+        after_one = rng.get_state()
+        sh = str(tmp_path / f"sh_{tag}")
+        for r in range(3):
+            rng = torch.Generator().manual_seed(21)
+            batch_sampling_save(5, pipe, sh, init=ini, max_batch_n=4, rng=rng, rank=r, world=3, parity=True)
+            assert torch.equal(rng.get_state(), after_one), (tag, r)          # every rank leaves the stream where the single process does
+        a, b = load(one), load(sh)
+        assert np.abs(a - b).max() <= 1 and (a != b).mean() < 0.01, (tag, np.abs(a - b).max(), (a != b).mean())
+    # without parity a sharded call still needs an explicit init, and rank streams are independent draws
+    with pytest.raises(ValueError):
+        batch_sampling_save(5, pipe, str(tmp_path / "x"), init=None, max_batch_n=4, rng=torch.Generator().manual_seed(1), rank=0, world=2)
+    with pytest.raises(ValueError):
+        batch_sampling_save(5, pipe, str(tmp_path / "y"), init=init, max_batch_n=4, rng=None, rank=0, world=2, parity=True)

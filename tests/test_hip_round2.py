@@ -409,11 +409,11 @@ def test_two_ranks_cifar_topology_sync_and_equal_global_batch(gpu):
     assert float((d > 2e-4).float().mean()) < 1e-3 and float(d.mean()) < 2e-5
 
 
-def _torchrun(args, env_extra, timeout=600, backend="gloo"):
+def _torchrun(args, env_extra, timeout=600, backend="gloo", nproc=2):
     import socket
     s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
     env = dict(os.environ, BD_DIST_BACKEND=backend, PYTHONPATH=ROOT, **env_extra)
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
            "--master-port", str(port)] + args
     return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
 
@@ -463,6 +463,36 @@ def test_bench_two_ranks_end_to_end(gpu, tmp_path):
     sh = d["sampling"]["ddim50_sharded"]
     assert sh["scaling"] == "strong" and sh["global_samples"] == 16 and sh["samples_per_gpu"] == 8 and sh["images_finite"]
     assert np.isfinite(d["final_loss"])
+
+
+def test_bench_eight_ranks_end_to_end(gpu, tmp_path):
+    """VERDICT round 5, task 7 / weak item 10: everything multi-rank had only ever run at world 2.  The driver's 8-GPU command (`bench.py --gpus 8`
+    under torch.distributed.run) with 8 gloo ranks sharing this box's one GPU at a reduced batch: the 8-rank bucket plan and sweep, the
+    weight-gradient slot sweep, exposed-communication measurement with its sync_state(), per-bucket timing, the sharded DDIM-50 job of
+    configs[4] at its real size (2048 chains = 256 rows per rank) and the bounded headline all execute once before real hardware does."""
+    detail = str(tmp_path / "bench_detail8.json")
+    r = _torchrun(["bench.py", "--gpus", "8", "--steps", "2", "--warmup", "1", "--batch", "2", "--no-cpu-baseline", "--sampling-n", "8,1",
+                   "--no-celeba", "--no-fid", "--sustain", "0.05", "--dp-sweep-buckets", "0,32", "--dp-sweep-slots", "128,192", "--total", "2048",
+                   "--detail-file", detail], {"OMP_NUM_THREADS": "1"}, timeout=1500, nproc=8)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1 and len(lines[0]) < 8192
+    head = json.loads(lines[0])
+    assert head["n_gpus"] == 8 and head["config"]["global_batch"] == 16 and head["scaling"] == "weak" and head["value"] > 0
+    assert abs(head["value"] - 8 * 2 / (head["ms_per_step"] * 1e-3)) < 1e-6 * head["value"] + 1e-3
+    d = json.load(open(detail))
+    dd = d["distributed"]
+    assert dd["world"] == 8 and dd["backend"] == "gloo" and dd["bytes_per_step"] in (4 * d["config"]["params"], 4 * (d["config"]["params"] - 1))
+    me = dd["measured"]
+    assert "error" not in me, me
+    assert me["ms_per_step"] > 0 and me["ms_per_step_without_collectives"] > 0 and np.isfinite(me["exposed_comm_ms"])
+    assert len(me["buckets_timed"]) == dd["buckets"] and [p["bucket_mb"] for p in me["bucket_sweep"]] == [0.0, 32.0]
+    assert [p["ps_wg3_slots"] for p in me["wgrad3_slot_sweep"]] == [128, 192] and all(p["ms_per_step"] > 0 for p in me["wgrad3_slot_sweep"])
+    sh = d["sampling"]["ddim50_sharded"]
+    assert sh["scaling"] == "strong" and sh["global_samples"] == 2048 and sh["samples_per_gpu"] == 256 and sh["images_finite"]
+    for kind, n in (("ddim50", 8), ("ddpm1000", 1)):
+        assert d["sampling"][kind]["samples_per_gpu"] == n and d["sampling"][kind]["images_finite"]
+    assert np.isfinite(d["final_loss"])          # the replicas stayed one model through sync_state() and the all-reduced updates
 
 
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (RCCL over xGMI); the round-end boxes have one")

