@@ -103,7 +103,7 @@ class ConvPsDesc(C.Structure):
     _fields_ = [("B", i32), ("H", i32), ("W", i32), ("K", i32), ("N", i32), ("direction", i32),
                 ("x_split", vp), ("ldx", i64), ("w_split", vp), ("bias", vp), ("rowbias", vp), ("ld_rowbias", i64),
                 ("residual", vp), ("ldr", i64), ("out_scale", f32), ("y", vp), ("ldy", i64), ("accumulate", i32),
-                ("workspace", vp), ("workspace_bytes", sz), ("gn_part", vp), ("gn_groups", i32), ("sem", vp)]
+                ("workspace", vp), ("workspace_bytes", sz), ("gn_part", vp), ("gn_groups", i32)]
 
 
 class ConvPsWgradDesc(C.Structure):

@@ -529,81 +529,14 @@ struct PsSmallParams {
     PsParams q;
     float* partial;        // [ksplit][M][N] when ksplit > 1
     int ksplit, cps;       // chunks per split
-    int* sem;              // round 6, optional: one zeroed counter per 128 x 128 tile -> the second pass runs INSIDE this launch (below)
 };
-
-// Round 6: the K split's second pass without a second launch.  Every workgroup of a tile stores its slab, makes it visible device-wide
-// (__threadfence: the L2s of the eight XCDs are not coherent with one another inside a kernel) and takes a ticket from the tile's counter; the
-// workgroup that draws the LAST ticket -- whichever it is -- sums the ksplit slabs of the tile in their FIXED order 0 .. ksplit-1 and applies the
-// epilogue: the result does not depend on which workgroup does it (deterministic, and bit-identical to conv_ps128_reduce), nobody waits for
-// anybody (no spinning: a workgroup that is not last simply exits), and the counter goes back to zero for the next launch on this stream.
-// 16 loads of 16 bytes in flight per thread: four slabs x four of the thread's eight float4 positions per round.
-__device__ __forceinline__ void ps128_tile_reduce(const PsSmallParams& pp, int m0, int n0, int tid) {
-    const PsParams& p = pp.q;
-    const long long mn = (long long)p.M * p.N;
-#pragma unroll 1
-    for (int half = 0; half < 2; ++half) {
-        long long e[4]; bool ok[4]; int mm[4], nc[4];
-        float4 a[4];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const int idx = tid + 512 * (half * 4 + k);      // 4096 float4 of the 128 x 128 tile
-            mm[k] = m0 + (idx >> 5); nc[k] = n0 + (idx & 31) * 4;
-            ok[k] = mm[k] < p.M;
-            e[k] = (long long)(ok[k] ? mm[k] : p.M - 1) * p.N + nc[k];
-            a[k] = *reinterpret_cast<const float4*>(pp.partial + e[k]);
-        }
-#pragma unroll 1
-        for (int s0 = 1; s0 < pp.ksplit; s0 += 4) {
-            float4 b[4][4];
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                const int s = s0 + j < pp.ksplit ? s0 + j : pp.ksplit - 1;       // clamped: branch-free loads, the surplus is not added
-#pragma unroll
-                for (int k = 0; k < 4; ++k) b[j][k] = *reinterpret_cast<const float4*>(pp.partial + (long long)s * mn + e[k]);
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (s0 + j < pp.ksplit) {
-#pragma unroll
-                    for (int k = 0; k < 4; ++k) { a[k].x += b[j][k].x; a[k].y += b[j][k].y; a[k].z += b[j][k].z; a[k].w += b[j][k].w; }
-                }
-        }
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            if (!ok[k]) continue;
-            const int m = mm[k], nn = nc[k];
-            float v[4] = {a[k].x, a[k].y, a[k].z, a[k].w};
-            if (p.bias) {
-                const float4 t = *reinterpret_cast<const float4*>(p.bias + nn);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (p.rowbias) {
-                const float4 t = *reinterpret_cast<const float4*>(p.rowbias + (long long)(m >> p.lhw) * p.ld_rowbias + nn);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            if (p.residual) {
-                const float4 t = *reinterpret_cast<const float4*>(p.residual + (long long)m * p.ldr + nn);
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-#pragma unroll
-            for (int j = 0; j < 4; ++j) v[j] *= p.out_scale;
-            float4* dst = reinterpret_cast<float4*>(p.y + (long long)m * p.ldy + nn);
-            if (p.accumulate) {
-                const float4 t = *dst;
-                v[0] += t.x; v[1] += t.y; v[2] += t.z; v[3] += t.w;
-            }
-            *dst = make_float4(v[0], v[1], v[2], v[3]);
-        }
-    }
-}
 
 // STAGES = 2: 64 KB, two workgroups per CU (the pair de-phases); the chunk c+1 is fetched while chunk c computes.
 // STAGES = 4 (round 6): 128 KB, one workgroup per CU, THREE chunks in flight ahead of the one being computed -- for the short K slices of
 // the 4 x 4 level (4 - 9 chunks per workgroup), where a workgroup's life is a handful of DMA round trips and the two-stage form exposes one
 // L2 -> LDS latency per chunk.
 template <int EPI, int STAGES = 2>
-__global__ __launch_bounds__(512, 2) void conv_ps128_kernel(PsSmallParams pp) {
+__global__ __launch_bounds__(512, STAGES == 2 ? 4 : 2) void conv_ps128_kernel(PsSmallParams pp) {
     const PsParams& p = pp.q;
     constexpr int A_BYTES = 128 * 128, STAGE = 2 * A_BYTES;
     __shared__ __attribute__((aligned(128))) char smem[STAGES * STAGE];
@@ -744,20 +677,6 @@ __global__ __launch_bounds__(512, 2) void conv_ps128_kernel(PsSmallParams pp) {
                 }
             }
         }
-        if (!pp.sem) return;                     // kernel-uniform: the second pass is its own launch (conv_ps128_reduce)
-        __threadfence();                         // release: this workgroup's slab before its ticket
-        __syncthreads();                         // (also: every wave is done with the LDS stages)
-        int* s_last = reinterpret_cast<int*>(smem);
-        if (tid == 0) {
-            int* cnt = pp.sem + tm * p.tiles_n + tn;
-            const int last = atomicAdd(cnt, 1) == pp.ksplit - 1;
-            if (last) *cnt = 0;                  // nobody else of this launch touches it again; the next launch on this stream finds zero
-            *s_last = last;
-        }
-        __syncthreads();
-        if (!*s_last) return;
-        __threadfence();                         // acquire: the other workgroups' slabs
-        ps128_tile_reduce(pp, m0, n0, tid);
         return;
     }
     floatx16 a2[1][2] = {{acc[0], acc[1]}};
@@ -1524,11 +1443,7 @@ static bool ps_large(long long M, int N) {
     if (force == 256) return true;
     return cdiv(M, PS_BM) * (N / PS_BN) >= 96;
 }
-static bool ps_small_fused(const bd_conv3x3_ps_desc& d) {
-    static const bool off = getenv("BD_PS128_FUSE") && atoi(getenv("BD_PS128_FUSE")) == 0;      // (A/B knob: 0 = the second pass is its own launch)
-    return d.sem != nullptr && !off;
-}
-static void ps_small_split(long long M, int N, int K, int& ksplit, int& cps, bool fused = false) {
+static void ps_small_split(long long M, int N, int K, int& ksplit, int& cps) {
     const long long tiles = cdiv(M, 128) * (N / 128);
     const int nchunks = 9 * (K / 32);
     static const int slots = [] {
@@ -1538,15 +1453,10 @@ static void ps_small_split(long long M, int N, int K, int& ksplit, int& cps, boo
         return e ? atoi(e) : cus;   // (2 x CUs measured 0.1-0.2 ms/step slower: twice the slab traffic for the 4x4 / 8x8 layers)
     }();
     static const int mincps = getenv("BD_PS_SMALL_MINCPS") ? atoi(getenv("BD_PS_SMALL_MINCPS")) : 4;
-    static const int nosplit = getenv("BD_PS_SMALL_NOSPLIT") ? atoi(getenv("BD_PS_SMALL_NOSPLIT")) : 0;   // (A/B knob) >= this many tiles: no K split
     int ks = (int)(slots / tiles);
     if (ks < 1) ks = 1;
     if (ks > nchunks / mincps) ks = nchunks / mincps;
     if (ks < 1) ks = 1;
-    if (nosplit > 0 && tiles >= nosplit) ks = 1;
-    // the fused second pass is done by ONE workgroup per tile: at most 8 slabs of 64 KB to fold (the 4 x 4 level would take 15 - 16)
-    static const int fuse_maxks = getenv("BD_PS128_FUSE_MAXKS") ? atoi(getenv("BD_PS128_FUSE_MAXKS")) : 8;
-    if (fused && ks > fuse_maxks) ks = fuse_maxks;
     cps = (int)cdiv(nchunks, ks);
     ksplit = (int)cdiv(nchunks, cps);
 }
@@ -1554,7 +1464,7 @@ size_t conv3x3_ps_workspace_bytes(const bd_conv3x3_ps_desc& d) {
     const long long M = (long long)d.B * d.H * d.W;
     if (d.N % PS_BN || ps_large(M, d.N)) return 0;
     int ks, cps;
-    ps_small_split(M, d.N, d.K, ks, cps, ps_small_fused(d));
+    ps_small_split(M, d.N, d.K, ks, cps);
     return ks > 1 ? (size_t)ks * (size_t)M * d.N * sizeof(float) : 0;
 }
 
@@ -1642,11 +1552,7 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
         PsSmallParams pp = {};
         p.tiles_m = (int)cdiv(M, 128); p.tiles_n = d.N / 128;
         pp.q = p;
-        ps_small_split(M, d.N, d.K, pp.ksplit, pp.cps, ps_small_fused(d));
-        if (pp.ksplit > 1 && ps_small_fused(d)) {
-            BD_CHECK(p.tiles_m * p.tiles_n <= 1024, BD_ERR_UNSUPPORTED, "conv3x3_ps: %d tiles for 1024 counters", p.tiles_m * p.tiles_n);
-            pp.sem = d.sem;
-        }
+        ps_small_split(M, d.N, d.K, pp.ksplit, pp.cps);
         if (pp.ksplit > 1) {
             const size_t need = (size_t)pp.ksplit * (size_t)M * d.N * sizeof(float);
             BD_CHECK(d.workspace && d.workspace_bytes >= need, BD_ERR_WORKSPACE, "conv3x3_ps: split-K needs %zu workspace bytes, got %zu", need,
@@ -1670,7 +1576,7 @@ int conv3x3_ps(const bd_conv3x3_ps_desc& d, hipStream_t st) {
             default: hipLaunchKernelGGL(conv_ps128_kernel<7>, grid, block, 0, st, pp); break;
         }
         BD_LAUNCH_CHECK("conv_ps128");
-        if (pp.ksplit > 1 && !pp.sem) {
+        if (pp.ksplit > 1) {
             hipLaunchKernelGGL(conv_ps128_reduce, dim3((unsigned)cdiv(M * (d.N / 4), 256)), dim3(256), 0, st, pp);
             BD_LAUNCH_CHECK("conv_ps128_reduce");
         }

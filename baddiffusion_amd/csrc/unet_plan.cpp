@@ -87,9 +87,6 @@ struct Ctx {
     float* out = nullptr; int64_t ldo = 0;
     const float* dout = nullptr; int64_t lddo = 0;
     char* opws = nullptr; size_t opws_bytes = 0; size_t opws_need = 0;
-    // round 6: counters of the fused K-split second pass (bd_conv3x3_ps_desc.sem): 1024 per stream, zero between launches (the kernels put them
-    // back; bd_unet_forward clears the area once per call in case an earlier call was cut short).  `sem`: this context's stream.
-    int* sem = nullptr;
     // weight-gradient side stream (backward only): wgrad GEMMs feed nothing but the optimizer, so they run on a second
     // stream next to the dgrad / GroupNorm chain that the rest of backward waits for.  Forked per launch; the scratch
     // arena alternates between nodes (group parity), so node k's wgrads may still run during node k+1 and are joined
@@ -434,7 +431,7 @@ struct bd_unet {
     }
     static uint16_t* U16(float* p) { return reinterpret_cast<uint16_t*>(p); }
     int conv_p(Ctx& c, bd_conv3x3_ps_desc& d) const {
-        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes; d.sem = c.sem;
+        d.workspace = c.opws; d.workspace_bytes = c.opws_bytes;
         if (c.dry) { note_conv(c); return BD_OK; }
         return conv3x3_ps(d, c.st);
     }
@@ -1372,7 +1369,6 @@ extern "C" int bd_unet_param_info(const bd_unet* u, int i, const char** name, in
     return BD_OK;
 }
 // the pre-split copy of the weights (2 uint16 per parameter, whole 32-element blocks) lives behind the op workspace
-constexpr size_t SEM_INTS = 1024, SEM_BYTES = 2 * SEM_INTS * sizeof(int);   // [main stream | side stream / second forward pipeline]
 static size_t wsplit_elems(const bd_unet* u) { return (size_t)(u->nparams / 32 * 32); }
 static size_t wsplit_bytes(const bd_unet* u) { return align_up(wsplit_elems(u) * 2 * sizeof(uint16_t), 256); }
 
@@ -1381,8 +1377,7 @@ extern "C" size_t bd_unet_workspace_bytes(bd_unet* u, int B, int training) {
     u->layout(B, training);
     return (size_t)(u->value_floats + u->grad_floats + u->scratch_floats) * sizeof(float) + u->opws_bytes + 256 +
            2 * wsplit_bytes(u) + align_up(u->opws_bytes, 256) +   // + transposed conv-weight planes + the side stream's op workspace
-           align_up(u->gnpart_floats * sizeof(float), 256) +     // + GroupNorm parameter partials of one backward
-           SEM_BYTES;                                            // + K-split counters, one set per stream (round 6)
+           align_up(u->gnpart_floats * sizeof(float), 256);      // + GroupNorm parameter partials of one backward
 }
 
 static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, size_t workspace_bytes) {
@@ -1402,7 +1397,6 @@ static int unet_ctx(bd_unet* u, Ctx& c, int B, int training, void* workspace, si
     c.opws2 = c.opws + align_up(u->opws_bytes, 256) + 2 * wsplit_bytes(u);
     c.gnpart = u->gnpart_floats ? reinterpret_cast<float*>(c.opws2 + align_up(u->opws_bytes, 256)) : nullptr;
     c.gnpart_floats = u->gnpart_floats; c.gnpart_used = 0;
-    c.sem = reinterpret_cast<int*>(c.opws2 + align_up(u->opws_bytes, 256) + align_up(u->gnpart_floats * sizeof(float), 256));
     if (c.w_split) c.wT_split = reinterpret_cast<const uint16_t*>(c.opws + align_up(u->opws_bytes, 256) + wsplit_bytes(u));
     c.ginit.assign(u->bufs.size(), 0);
     return BD_OK;
@@ -1433,7 +1427,6 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
     c.params = params; c.x = x; c.ldx = ldx; c.t = t; c.t_stride = t_stride; c.out = out; c.ldo = ldo; c.st = S(stream);
     c.training = training != 0;
     if (training) { u->fwd_gen = bd::g_tune_gen; u->fwd_B = B; u->fwd_ws = workspace; }
-    BD_HIP_TRY(hipMemsetAsync(c.sem, 0, SEM_BYTES, c.st));     // (the workspace is the caller's: never trust its previous contents)
     const bool prepared = u->static_weights && !training && u->prep_params == (const void*)params && u->prep_ws == workspace && u->prep_B == B;
     if (c.w_split && !prepared) {   // split the weights once; forward convs and (same workspace) the backward dgrads read the copy
         BD_TRY(bd_split_bf16(params, (int64_t)wsplit_elems(u), const_cast<uint16_t*>(c.w_split), stream));
@@ -1469,7 +1462,7 @@ extern "C" int bd_unet_forward(bd_unet* u, int B, int training, const float* par
     const int Bh = B / 2;
     const int64_t hw = (int64_t)u->cfg.sample_size * u->cfg.sample_size;
     c.B = Bh;
-    c2.B = B - Bh; c2.s0 = Bh; c2.st = u->aux_stream; c2.opws = c.opws2; c2.sem = c.sem + SEM_INTS;
+    c2.B = B - Bh; c2.s0 = Bh; c2.st = u->aux_stream; c2.opws = c.opws2;
     c2.x = x + (int64_t)Bh * hw * ldx; c2.t = t + (int64_t)Bh * t_stride; c2.out = out + (int64_t)Bh * hw * ldo;
     BD_HIP_TRY(hipEventRecord(u->aux_ev_fork, c.st));
     BD_HIP_TRY(hipStreamWaitEvent(c2.st, u->aux_ev_fork, 0));

@@ -275,11 +275,10 @@ def split_wT(w):
 
 
 def conv3x3_ps(x_split, w_split, B, H, W, K, N, direction=1, bias=None, rowbias=None, residual=None, out_scale=1.0,
-               out=None, accumulate=False, gn_groups=0, sem=None):
+               out=None, accumulate=False, gn_groups=0):
     """stride-1 pad-1 3x3 convolution (direction +1) / data gradient (-1) on pre-split operands -> fp32 [B,H,W,N].
     gn_groups > 0: also the GroupNorm partials of y from the epilogue -> (y, partials [B, S, gn_groups, 2] fp64), S =
-    bd_conv3x3_ps_gn_splits() (raises when the call cannot produce them).
-    sem: >= 1024 zeroed int32 on the device -> the K-split second pass of the small-layer variant runs inside the launch (bd_conv3x3_ps_desc.sem)."""
+    bd_conv3x3_ps_gn_splits() (raises when the call cannot produce them)."""
     lib = L.load(); _need_cuda(x_split, w_split, bias, rowbias, residual)
     y = torch.empty(B, H, W, N, device=x_split.device) if out is None else out
     part = None
@@ -292,9 +291,6 @@ def conv3x3_ps(x_split, w_split, B, H, W, K, N, direction=1, bias=None, rowbias=
                      bias=L.ptr(bias), rowbias=L.ptr(rowbias), ld_rowbias=rowbias.stride(0) if rowbias is not None else 0,
                      residual=L.ptr(residual), ldr=_ld(residual) if residual is not None else 0, out_scale=out_scale,
                      y=L.ptr(y), ldy=_ld(y), accumulate=int(accumulate))
-    if sem is not None:
-        assert sem.dtype == torch.int32 and sem.numel() >= 1024 and sem.is_cuda
-        d.sem = L.ptr(sem)
     ws = workspace(lib.bd_conv3x3_ps_workspace_bytes(C.byref(d)), x_split.device, "ps")
     d.workspace = L.ptr(ws); d.workspace_bytes = ws.numel()
     if part is not None:

@@ -343,11 +343,6 @@ typedef struct {
                                        [B][S][gn_groups][2] fp64 partial (sum, sum of squares) per sample and 256-pixel tile, S =
                                        bd_conv3x3_ps_gn_splits() > 0; forward calls with exactly one of rowbias / residual, no accumulate.
                                        Hand them to bd_gn_fwd as stats / stats_splits.                                              */
-    int32_t* sem;                   /* optional (round 6): >= 1024 ZEROED int32 counters owned by the caller and used by ONE stream at a time.
-                                       With it the K-split second pass of the small-layer variant runs inside the same launch (the workgroup
-                                       that finishes a tile last sums the tile's slabs in their fixed order and applies the epilogue:
-                                       deterministic, bit-identical to the two-launch form) and the counters are zero again when the
-                                       kernel ends.  NULL: the second pass is its own launch.                                          */
 } bd_conv3x3_ps_desc;
 size_t bd_conv3x3_ps_workspace_bytes(const bd_conv3x3_ps_desc* d);
 int bd_conv3x3_ps_gn_splits(int B, int H, int W, int K, int N, int groups);   /* 0: this call cannot write GroupNorm partials */
