@@ -1292,7 +1292,9 @@ __global__ __launch_bounds__(512, 2) void conv_ps_wgrad3_kernel(PsWgParams p) {
     }
 }
 
-// fixed-order sum of the K-split slabs (float4 per thread); the tail threads fold the bias rows
+// fixed-order sum of the K-split slabs (float4 per thread); the tail threads fold the bias rows.  V3 only names the launch (the second pass of
+// conv_ps_wgrad3_kernel is its own row in the profiles / PMC tables: bench.py's roofline.traffic of the dominant kernel counts ITS second pass).
+template <bool V3>
 __global__ __launch_bounds__(256) void conv_ps_wgrad_reduce(const float* __restrict__ part, int ksplit, long long mn, int M,
                                                             float* __restrict__ dw, float* __restrict__ db, int brows) {
     const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -1652,7 +1654,7 @@ int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
     }
     int rec = -1;
     if (prof_on())
-        rec = prof_begin("conv_ps_wgrad", 2.0 * (double)p.P * d.Cout * 9.0 * d.Cin,
+        rec = prof_begin(v3 ? "conv_ps_wgrad3" : "conv_ps_wgrad", 2.0 * (double)p.P * d.Cout * 9.0 * d.Cin,   // (round 6: the large layers' kernel is its own class)
                          ((double)p.P * (d.Cin + d.Cout) + 9.0 * d.Cin * d.Cout) * 4.0, st);
 #ifdef BD_PS_ABLATION
     p.ablate = getenv("BD_PS_ABLATE") ? atoi(getenv("BD_PS_ABLATE")) : 0;
@@ -1672,7 +1674,8 @@ int conv3x3_ps_wgrad(const bd_conv3x3_ps_wgrad_desc& d, hipStream_t st) {
     BD_LAUNCH_CHECK("conv_ps_wgrad");
     if (p.ksplit > 1) {
         const long long total = mn / 4 + (d.db ? d.Cout : 0);
-        hipLaunchKernelGGL(conv_ps_wgrad_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, p.out, p.ksplit, mn, d.Cout, d.dw, d.db, p.ksplit);
+        if (v3) hipLaunchKernelGGL(conv_ps_wgrad_reduce<true>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, p.out, p.ksplit, mn, d.Cout, d.dw, d.db, p.ksplit);
+        else hipLaunchKernelGGL(conv_ps_wgrad_reduce<false>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, p.out, p.ksplit, mn, d.Cout, d.dw, d.db, p.ksplit);
         BD_LAUNCH_CHECK("conv_ps_wgrad_reduce");
     }
     prof_end(rec, st);
@@ -1729,7 +1732,7 @@ int upsample_conv_wgrad(const bd_upsample_conv_desc& d, hipStream_t st) {
     hipLaunchKernelGGL((conv_ps_wgrad_kernel<2, 8, true>), grid, dim3(512), 0, st, p);
     BD_LAUNCH_CHECK("conv_ps_wgrad (phase)");
     const long long total = mn / 4 + (d.db ? d.Cout : 0);
-    hipLaunchKernelGGL(conv_ps_wgrad_reduce, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, p.out, p.ksplit, mn, d.Cout, de, d.db, 4 * p.ksplit);
+    hipLaunchKernelGGL(conv_ps_wgrad_reduce<false>, dim3((unsigned)cdiv(total, 256)), dim3(256), 0, st, p.out, p.ksplit, mn, d.Cout, de, d.db, 4 * p.ksplit);
     BD_LAUNCH_CHECK("conv_ps_wgrad_reduce (phase)");
     BD_TRY(ups_dweff_combine(de, d.Cin, d.Cout, d.dw, st));
     prof_end(rec, st);

@@ -859,6 +859,9 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
     GnRes rp;
     if (gn_resident_plan(d->B, d->HW, d->C, d->G, rp)) {
         const dim3 grid((unsigned)rp.nblk * (unsigned)d->B);
+        int rec = -1;       // round 6: the resident GroupNorm launches are profiled classes too (REQUIRED bytes: x in, y and / or planes out)
+        if (prof_on())
+            rec = prof_begin("gn_fwd_res", 0.0, (double)d->B * d->HW * d->C * 4.0 * (1.0 + (d->y ? 1.0 : 0.0) + (d->y_split ? 1.0 : 0.0)), S(stream));
 #define BD_GN_FWD_RES(EM, NT)                                                                                              \
     hipLaunchKernelGGL((gn_fwd_res_kernel<EM, NT>), grid, dim3(NT), 0, S(stream), d->x, (long long)d->ldx, d->y,             \
                        (long long)d->ldy, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->eps, d->gamma, d->beta, d->mean,       \
@@ -869,6 +872,7 @@ extern "C" int bd_gn_fwd(const bd_gn_fwd_desc* d, bd_stream_t stream) {
         else BD_GN_FWD_RES(GN_RES_EMAX, 256);
 #undef BD_GN_FWD_RES
         BD_LAUNCH_CHECK("gn_fwd_res");
+        prof_end(rec, S(stream));
         return BD_OK;
     }
     const int S_ = gn_splits(d->B, d->HW);
@@ -950,6 +954,10 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
         BD_CHECK(d->workspace_bytes >= need_r, BD_ERR_WORKSPACE, "bd_gn_bwd: workspace %zu < %zu", d->workspace_bytes, need_r);
         float* part_r = d->param_partials ? d->param_partials : reinterpret_cast<float*>(d->workspace);
         const dim3 grid((unsigned)rp.nblk * (unsigned)d->B);
+        int rec = -1;       // REQUIRED bytes of this call: x and dy in (+ the dx it accumulates into, + the added gradient), dx and / or its planes out
+        if (prof_on())
+            rec = prof_begin("gn_bwd_res", 0.0, (double)d->B * d->HW * 4.0 * ((double)d->C * (2.0 + (d->accumulate_dx ? 1.0 : 0.0) + (d->dx_add ? 1.0 : 0.0) +
+                             (d->dx ? 1.0 : 0.0)) + (d->dx_split ? (double)(xs1 - xs0) : 0.0)), S(stream));
 #define BD_GN_BWD_RES(EM, NT)                                                                                              \
     hipLaunchKernelGGL((gn_bwd_res_kernel<EM, NT>), grid, dim3(NT), 0, S(stream), d->x, (long long)d->ldx, d->dy,            \
                        (long long)d->lddy, d->dx, (long long)d->lddx, d->HW, d->C, d->G, rp.cb, rp.q, rp.R, rp.E, d->gamma,     \
@@ -961,6 +969,7 @@ extern "C" int bd_gn_bwd(const bd_gn_bwd_desc* d, bd_stream_t stream) {
         else BD_GN_BWD_RES(GN_RES_EMAX, 256);
 #undef BD_GN_BWD_RES
         BD_LAUNCH_CHECK("gn_bwd_res");
+        prof_end(rec, S(stream));
         if (d->param_partials) return BD_OK;   // the caller folds them (bd_gn_bwd_params)
         hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((unsigned)cdiv(2 * d->C, 64)), dim3(1024), 0, S(stream), part_r, d->B, 2 * d->C,
                            d->C, d->dgamma, d->dbeta);

@@ -44,7 +44,8 @@ _PMC_OPERANDS = {"conv_fwd": ("ConvKC", ("WgtKC", "WgtKCs")), "conv_dgrad": ("TC
                  "conv_wgrad": ("DenseRC", ("ConvRC", "ConvRCs")), "gemm_nt": ("DenseKC", ("DenseKC",)),
                  "gemm_nn": ("DenseKC", ("DenseRC",)), "gemm_tn": ("DenseRC", ("DenseRC",))}
 # kernel classes of the LDS-DMA family (conv_ps.hip) -> kernel-name patterns whose HBM traffic makes up one call
-_PMC_PS = {"conv_ps_wgrad": (r"conv_ps_wgrad3?_kernel", r"conv_ps_wgrad_reduce"), "conv_ps_fwd": (r"conv_ps3?_kernel<[12]>",),
+_PMC_PS = {"conv_ps_wgrad3": (r"conv_ps_wgrad3_kernel", r"conv_ps_wgrad_reduce(<true>)?"),      # (<true>: round 6 names the large layers' second pass)
+           "conv_ps_wgrad": (r"conv_ps_wgrad_kernel<2, 8, false>", r"conv_ps_wgrad_reduce(<false>)?"), "conv_ps_fwd": (r"conv_ps3?_kernel<[12]>",),
            "conv_ps_dgrad": (r"conv_ps3?_kernel<0>",), "conv_ps128_fwd": (r"conv_ps128_kernel<", r"conv_ps128_reduce"),
            "conv_ps128_dgrad": (r"conv_ps128_kernel<", r"conv_ps128_reduce"),
            "conv_ph_ups_fwd": (r"conv_ph_kernel",), "conv_ph_ups_dgrad": (r"conv_ph_kernel",), "conv_ph_s2_dgrad": (r"conv_ph_kernel",),
@@ -52,7 +53,7 @@ _PMC_PS = {"conv_ps_wgrad": (r"conv_ps_wgrad3?_kernel", r"conv_ps_wgrad_reduce")
            "attn_sp_fwd": (r"attn_sp_fwd_kernel",), "attn_sp_bwd_a": (r"attn_sp_bwd_a_kernel",), "attn_sp_bwd_b": (r"attn_sp_bwd_b_kernel",),
            "gemm_sp_nt": (r"gemm_sp_kernel<false, false>",), "gemm_sp_nn": (r"gemm_sp_kernel<false, true>",),
            "gemm_sp_tn": (r"gemm_sp_kernel<true, true>", r"gemm_sp_reduce")}
-PMC_ROUNDS = ("r05", "r04", "r03", "r02")                     # this round's file first; an older one is used only when it is absent, and flagged
+PMC_ROUNDS = ("r06", "r05", "r04", "r03", "r02")                     # this round's file first; an older one is used only when it is absent, and flagged
 PMC_FILE = "profiles/{rnd}_pmc_bench_{wl}{mode}.json"   # wl = "" (CIFAR train step), "celeba_" (256x256 train step), "ddim50_" / "ddpm1000_" (sampling)
 
 
@@ -287,8 +288,9 @@ def run_sampling(model, kind, n, mode, world, rank, dev, lib, want_roofline=True
         lib.bd_prof_enable(0)
         torch.cuda.synchronize()
         cl = _read_classes(lib)
-        if cl:
-            d = cl[0]
+        cl_mm = [c for c in cl if c["flops"] > 0]         # (round 6: the resident GroupNorm launches are classes too -- bytes only)
+        if cl_mm:
+            d = cl_mm[0]
             ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
             peak = FP32_MFMA_PEAK_TFLOPS if mode == "f32" else BF16_MFMA_PEAK_TFLOPS / 3
             traffic, tsrc = _pmc_traffic(d["kernel"], "ddpm1000" if kind == "ddpm1000" else "ddim50")     # PMC run of the same chunk shape
@@ -296,7 +298,7 @@ def run_sampling(model, kind, n, mode, world, rank, dev, lib, want_roofline=True
                                "frac": ach / peak, "traffic": traffic, "traffic_source": tsrc,
                                "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                                "avg_launch_us": d["ms"] * 1e3 / d["launches"],
-                               "share_of_gemm_class_time": d["ms"] / sum(c["ms"] for c in cl),
+                               "share_of_gemm_class_time": d["ms"] / sum(c["ms"] for c in cl_mm),
                                "note": "hipEvent pairs on the launch stream, 3 untimed UNet evaluations of one chunk; the two half-batch "
                                        "forward pipelines share the chip, so this is an in-schedule figure"}
     return res
@@ -509,9 +511,10 @@ def profile_steps(lib, model, step, first, n, barrier):
 
 def roofline_object(classes, classes_iso, prof_steps, mode, ms, probe, workload=""):
     """`roofline` of the dominant kernel class (most time in the profiled steps) + the per-class tables."""
-    if not classes:
+    mm = [c for c in classes if c["flops"] > 0]       # matrix classes; the GroupNorm classes (round 6) carry required bytes only
+    if not mm:
         return None, [], []
-    d = classes[0]
+    d = mm[0]
     ach = d["flops"] / (d["ms"] * 1e-3) / 1e12
     # split-bf16 issues 3 bf16 MFMA products per algorithmic multiply: its ceiling for ALGORITHMIC flops is
     # the dense bf16 peak / 3 (833 TF), above the exact-fp32 MFMA peak (157 TF) the f32 mode is bound by

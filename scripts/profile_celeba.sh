@@ -2,7 +2,7 @@
 # 256x256 workload artifacts (run on the GPU box through gpurun): rocprofv3 kernel tables of the DDPM-CELEBA-HQ-256 train step at B = 4
 # (two-stream schedule and side stream off; rocprof_summary.py drops the in-process MFMA probe) + PMC traffic passes.
 # usage: scripts/profile_celeba.sh <tag>   -> gpurun_out/<tag>_celeba256_*
-tag=${1:-r05}
+tag=${1:-r06}
 out=$GRAFT_REPO_ROOT/gpurun_out
 ARGS="--workload celeba --steps 6 --warmup 2 --no-cpu-baseline --no-prof --sustain 0"
 cd /tmp && export TMPDIR=/tmp

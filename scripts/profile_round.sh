@@ -1,7 +1,7 @@
 #!/bin/bash
 # Round profile artifacts (run on the GPU box through gpurun): rocprofv3 kernel-trace summaries + bench JSON lines, then the
 # PMC traffic passes.  usage: scripts/profile_round.sh <tag>   -> gpurun_out/<tag>_*   (copy what is to be judged into profiles/)
-tag=${1:-r05}
+tag=${1:-r06}
 out=$GRAFT_REPO_ROOT/gpurun_out
 TRAIN="--no-cpu-baseline --no-sampling --no-celeba --no-fid --no-dp-probe --sustain 0"     # the headline train step alone (what the kernel tables describe)
 cd /tmp && export TMPDIR=/tmp
@@ -11,13 +11,16 @@ rocprofv3 --kernel-trace --stats -d /tmp/rp -o r -- python $GRAFT_REPO_ROOT/benc
 grep "^{\"metric\"" /tmp/rp.log | tail -1 > $out/${tag}_bench_under_rocprof.json
 python $GRAFT_REPO_ROOT/scripts/rocprof_summary.py $(find /tmp/rp -name "*.db" | head -1) 10 > $out/${tag}_train_step_b128_kernel_stats.txt
 # 2. the driver's command, unprofiled: the whole default line (train + sustained + sampling + celeba + CPU baselines)
-cd $GRAFT_REPO_ROOT && python bench.py --steps 20 --warmup 5 2>/dev/null | tail -1 > $out/${tag}_bench.json
-cd $GRAFT_REPO_ROOT && python bench.py --steps 20 --warmup 5 --mode f32 $TRAIN 2>/dev/null | tail -1 > $out/${tag}_bench_f32.json
-cd $GRAFT_REPO_ROOT && python bench.py --workload celeba --steps 5 --warmup 2 --no-cpu-baseline --sustain 0 2>/dev/null | tail -1 > $out/${tag}_bench_celeba256.json
-cd $GRAFT_REPO_ROOT && python bench.py --workload pndm50 --batch 2048 --no-cpu-baseline 2>/dev/null | tail -1 > $out/${tag}_bench_pndm50.json
+# (round 6: stdout carries the bounded headline, the full object goes to --detail-file)
+cd $GRAFT_REPO_ROOT && python bench.py --steps 20 --warmup 5 --detail-file $out/${tag}_bench_detail.json 2>/dev/null | tail -1 > $out/${tag}_bench.json
+cd $GRAFT_REPO_ROOT && python bench.py --steps 20 --warmup 5 --mode f32 $TRAIN --detail-file $out/${tag}_bench_f32.json 2>/dev/null | tail -1 > /dev/null
+cd $GRAFT_REPO_ROOT && python bench.py --workload celeba --steps 5 --warmup 2 --no-cpu-baseline --sustain 0 --detail-file $out/${tag}_bench_celeba256.json 2>/dev/null | tail -1 > /dev/null
+cd $GRAFT_REPO_ROOT && python bench.py --workload pndm50 --batch 2048 --no-cpu-baseline --detail-file $out/${tag}_bench_pndm50.json 2>/dev/null | tail -1 > /dev/null
 # 3. HBM traffic per kernel (FETCH_SIZE / WRITE_SIZE in separate --pmc passes)
 $GRAFT_REPO_ROOT/scripts/pmc_bench.sh bf16x3 > /dev/null 2>&1
 cp $out/pmc_bench_bf16x3.json $out/${tag}_pmc_bench_bf16x3.json
+# (bench.py reads roofline.traffic from profiles/<tag>_pmc_bench_*.json: re-run step 2's first line after copying this file there for a line
+#  whose traffic is this build's)
 $GRAFT_REPO_ROOT/scripts/pmc_bench.sh bf16x3 ddim50 > /dev/null 2>&1
 cp $out/pmc_bench_ddim50_bf16x3.json $out/${tag}_pmc_bench_ddim50_bf16x3.json
 $GRAFT_REPO_ROOT/scripts/pmc_bench.sh bf16x3 ddpm1000 > /dev/null 2>&1
