@@ -74,4 +74,4 @@ for (B, S, Cin, Cout) in SMALL + BIG:
         rec["dgrad_rel_l2_vs_fp64"] = float((dx.double() - rdx).norm() / rdx.norm())
     print(json.dumps(rec), flush=True)
     out.append(rec)
-json.dump(out, open("gpurun_out/r05_wino_check.json", "w"), indent=1)
+json.dump(out, open("gpurun_out/r06_wino_probe_check.json", "w"), indent=1)
