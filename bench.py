@@ -25,6 +25,8 @@ import time
 # multi-process GPU work on this ROCm stack needs dmabuf IPC (RCCL / CUDA-tensor sharing across ranks fail with hipIpcGetMemHandle: invalid
 # argument otherwise); the driver's environment exports it, a bare shell may not
 os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+# kernel arguments in device memory: the runtime's default on this stack; with it OFF the ~770 launches of a step cost +0.7 ms (profiles/r06_ab_runtime_env.txt)
+os.environ.setdefault("HIP_FORCE_DEV_KERNARG", "1")
 
 import numpy as np
 import torch
