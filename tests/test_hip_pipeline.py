@@ -232,3 +232,54 @@ def test_parity_mode_sharded_sampling_equals_the_unsharded_run(gpu, tmp_path):
         batch_sampling_save(5, pipe, str(tmp_path / "x"), init=None, max_batch_n=4, rng=torch.Generator().manual_seed(1), rank=0, world=2)
     with pytest.raises(ValueError):
         batch_sampling_save(5, pipe, str(tmp_path / "y"), init=init, max_batch_n=4, rng=None, rank=0, world=2, parity=True)
+
+
+def test_measure_on_two_ranks_with_reference_noise_equals_one_process(gpu, tmp_path, monkeypatch):
+    """baddiffusion.py measure() (reference :477-551) with BD_SHARDED_NOISE=reference: two ranks, stochastic DDPM chains, ragged chunks (6 = 4 + 2) --
+    the clean and the backdoor PNG sets equal the one-process run's (<= 1 of 255 levels), although the second set continues the SAME generator
+    stream the first set left behind (the single process draws both from one rng: every rank has to leave it in the same state), and rank 0's
+    MSE score agrees."""
+    import os, socket
+    import torch.distributed as dist
+    from PIL import Image
+    import baddiffusion as cli
+    from baddiffusion_amd.dataset import DatasetLoader
+    from baddiffusion_amd.pipelines import DDPMPipeline
+    from baddiffusion_amd.schedulers import DDPMScheduler
+    import dataclasses
+    cfg = dataclasses.replace(C.SMALL_CFGS["small"], sample_size=32)
+    m = make_model(cfg, 7, gpu)
+    dsl = DatasetLoader(root=None, name=DatasetLoader.CIFAR10, batch_size=8, seed=0, device=gpu, num_images=8)
+    dsl.set_poison(trigger_type="BOX_14", target_type="CORNER", clean_rate=1.0, poison_rate=0.25).prepare_dataset(mode="FIXED")
+
+    class Pipe(DDPMPipeline):
+        def __call__(self, **kw):
+            return super().__call__(num_inference_steps=6, **kw)
+
+        def noise_draws(self, **kw):
+            return super().noise_draws(num_inference_steps=6)
+
+    def run(out, rank, world):
+        config = cli.TrainingConfig()
+        config.output_dir = str(out); config.seed = 3; config.clip = False; config.sample_ep = None
+        config.measure_sample_n = 6; config.eval_max_batch = 4
+        os.makedirs(config.output_dir, exist_ok=True)
+        return config, cli.measure(config, dsl, "measure", Pipe(m, DDPMScheduler(clip_sample=False)), rank=rank, world=world)
+
+    def load(d, folder):
+        return np.stack([np.asarray(Image.open(os.path.join(d, "measure", folder, f"{i}.png"))).astype(np.int32) for i in range(6)])
+
+    c1, s1 = run(tmp_path / "one", 0, 1)
+    monkeypatch.setenv("BD_SHARDED_NOISE", "reference")
+    sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1)      # measure() barriers between sampling and scoring
+    try:
+        run(tmp_path / "two", 1, 2)
+        c2, s2 = run(tmp_path / "two", 0, 2)
+    finally:
+        dist.destroy_process_group()
+    for folder in ("clean_noclip", "backdoor_noclip"):
+        a, b = load(c1.output_dir, folder), load(c2.output_dir, folder)
+        assert np.abs(a - b).max() <= 1 and (a != b).mean() < 0.01, (folder, np.abs(a - b).max(), (a != b).mean())
+    k = [k for k in s1 if k.startswith("MSE")][0]
+    assert abs(s1[k] - s2[k]) <= 1e-4 * max(abs(s1[k]), 1e-6) + 1e-6
