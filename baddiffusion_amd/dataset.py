@@ -76,7 +76,11 @@ class Backdoor:
     def __init__(self, root: Optional[str]):
         self._root = root
 
-    # ---- image-file triggers / targets (PIL restatement of the torchvision pipeline; parity unpinned) -----
+    # ---- image-file triggers / targets: the reference's transform chain (dataset.py:427-441: convert -> transforms.Resize(int) ->
+    # ToTensor -> normalize -> Pad) applied to PIL images.  On a PIL image torchvision's Resize IS PIL's: transforms.functional.resize ->
+    # _compute_resized_output_size (shorter side -> size, longer = int(size * long / short)) -> img.resize((w, h), Image.BILINEAR), and ToTensor
+    # is uint8 -> float32 / 255 in CHW; the same calls are made here.  torchvision itself is absent from this image, so the equality is by
+    # construction, not by a run against it (unpinned) -----
     def _asset(self, rel):
         for base in (self._root, os.getcwd(), os.path.dirname(os.path.dirname(os.path.abspath(__file__)))):
             if base and os.path.exists(os.path.join(base, rel)):
