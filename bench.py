@@ -46,8 +46,8 @@ _PMC_OPERANDS = {"conv_fwd": ("ConvKC", ("WgtKC", "WgtKCs")), "conv_dgrad": ("TC
                  "conv_wgrad": ("DenseRC", ("ConvRC", "ConvRCs")), "gemm_nt": ("DenseKC", ("DenseKC",)),
                  "gemm_nn": ("DenseKC", ("DenseRC",)), "gemm_tn": ("DenseRC", ("DenseRC",))}
 # kernel classes of the LDS-DMA family (conv_ps.hip) -> kernel-name patterns whose HBM traffic makes up one call
-_PMC_PS = {"conv_ps_wgrad3": (r"conv_ps_wgrad3_kernel", r"conv_ps_wgrad_reduce(<true>)?"),      # (<true>: round 6 names the large layers' second pass)
-           "conv_ps_wgrad": (r"conv_ps_wgrad_kernel<2, 8, false>", r"conv_ps_wgrad_reduce(<false>)?"), "conv_ps_fwd": (r"conv_ps3?_kernel<[12]>",),
+_PMC_PS = {"conv_ps_wgrad3": (r"conv_ps_wgrad3_kernel", r"conv_ps_wgrad_reduce(<true>|\()"),      # (<true>: round 6 names the large layers' second pass)
+           "conv_ps_wgrad": (r"conv_ps_wgrad_kernel<2, 8, false>", r"conv_ps_wgrad_reduce(<false>|\()"), "conv_ps_fwd": (r"conv_ps3?_kernel<[12]>",),
            "conv_ps_dgrad": (r"conv_ps3?_kernel<0>",), "conv_ps128_fwd": (r"conv_ps128_kernel<", r"conv_ps128_reduce"),
            "conv_ps128_dgrad": (r"conv_ps128_kernel<", r"conv_ps128_reduce"),
            "conv_ph_ups_fwd": (r"conv_ph_kernel",), "conv_ph_ups_dgrad": (r"conv_ph_kernel",), "conv_ph_s2_dgrad": (r"conv_ph_kernel",),

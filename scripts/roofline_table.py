@@ -19,18 +19,37 @@ iso = {c["kernel"]: c for c in d["kernel_classes_standalone"]}
 
 
 def pmc_of(cls):
+    """HBM-side bytes per call of class `cls` from the GIVEN PMC file: the class's own kernels (launch-weighted) + the mean of each second-pass
+    kernel -- bench.py's class -> kernel-name patterns (_PMC_PS, _PMC_OPERANDS), applied to this file"""
     import re
-    if cls.startswith("gn_"):
-        pat = re.compile(cls + "_kernel")
+    by = lambda v: (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0
+
+    def mean(pat):
+        rx = re.compile(pat)
         tot = n = 0.0
         for name, v in pmc.items():
-            if pat.search(name):
-                tot += (2.0 * v.get("FETCH_SIZE_KB_per_launch", 0.0) + v.get("WRITE_SIZE_KB_per_launch", 0.0)) * 1024.0 * v["launches"]; n += v["launches"]
+            if rx.search(name):
+                tot += by(v) * v["launches"]; n += v["launches"]
         return tot / n if n else None
-    # bench.py's own mapping (class -> kernel-name patterns, second passes included), pointed at the given file
-    bench.PMC_FILE = os.path.relpath(sys.argv[2], ROOT).replace("r06_", "{rnd}_").replace("bench_bf16x3", "bench_{wl}{mode}") if False else bench.PMC_FILE
-    b, _ = bench._pmc_traffic(cls, "")
-    return b
+
+    if cls.startswith("gn_"):
+        return mean(cls + "_kernel")
+    if cls in bench._PMC_PS:
+        pats = bench._PMC_PS[cls]
+        main = mean(pats[0])
+        return None if main is None else main + sum(mean(p) or 0.0 for p in pats[1:])
+    m = re.match(r"igemm_(\w+?)_(\d+)(_bf16x3)?$", cls)
+    if not m or m.group(1) not in bench._PMC_OPERANDS:
+        return None
+    la, lbs = bench._PMC_OPERANDS[m.group(1)]
+    kname = "igemm_bf16x3_kernel" if m.group(3) else "igemm_kernel"
+    rx = re.compile(rf"{kname}<{m.group(2)}, {m.group(2)}, bd::(\w+)<[^>]*>, bd::(\w+)<[^>]*>")
+    tot = n = 0.0
+    for name, v in pmc.items():
+        mm = rx.search(name)
+        if mm and mm.group(1) == la and mm.group(2) in lbs:
+            tot += by(v) * v["launches"]; n += v["launches"]
+    return tot / n if n else None
 
 
 print(f"# {sys.argv[1]} + {sys.argv[2]}: CIFAR-32 UNet train step, B = 128, {d['ms_per_step']:.2f} ms/step, MFMA probe "
